@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec end-to-end (encode + score + fuse) on synthetic LLeQA-shaped batches.
+
+One "step" = one pass of the hot path over one batch of Q synthetic queries, inputs resident in HBM:
+    1. encode      query token ids -> CamemBERT-base-shaped encoder (random init, fp32, PyTorch-ROCm) -> mean pool
+    2. dpr score   normalise + fp32-MFMA cos-sim GEMM against the resident corpus embeddings   [Q, N]
+    3. dpr rank    stable descending row sort -> order + rank planes
+    4. bm25 score  float64 BM25 of the same batch against a resident synthetic index            [Q, N]
+    5. bm25 rank   stable descending row sort (float64 keys)
+    6. fuse        reciprocal-rank fusion in float64 (hybrid.py:252)
+    7. order       stable sort of the fused scores in first-insertion order -> final ranked lists [Q, N]
+(the BM25+DPR RRF hybrid of BASELINE.json configs[0] run on the configs[1] scale: N = 27,942, d = 768, Q = 1024).
+The corpus side (document embeddings, BM25 index) is built once, untimed: the corpus is static.
+
+Launch: `python bench.py --gpus 1 --steps K --warmup W`, or under torch.distributed.run for N > 1 (one rank per
+GPU; queries are sharded across ranks, each rank holds a corpus replica, no data-path collective: weak scaling).
+`--workload mmarco` runs the corpus-sharded config 5 instead (RCCL all-gather of per-shard top-k).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="lleqa", choices=["lleqa", "mmarco"])
+    p.add_argument("--queries", type=int, default=1024)
+    p.add_argument("--corpus", type=int, default=27942)
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--no-encode", action="store_true", help="skip the transformer forward (score+fuse only; not the headline metric)")
+    p.add_argument("--encoder-size", default="base", choices=["base", "tiny"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--mmarco-docs", type=int, default=8841823)
+    p.add_argument("--topk", type=int, default=1000)
+    return p.parse_args()
+
+
+class Events:
+    """HIP events on torch's current stream (every kernel of the step is launched on it)."""
+
+    def __init__(self):
+        self.marks = []
+
+    def mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.marks.append((name, e))
+
+    def durations_ms(self):
+        out = {}
+        for (n0, e0), (n1, e1) in zip(self.marks[:-1], self.marks[1:]):
+            out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
+def synth_bm25_index(N, rng):
+    """Synthetic LLeQA-shaped corpus text statistics: Zipf vocabulary of 20k lemmas, ~150 tokens per article."""
+    V = 20000
+    p = 1.0 / np.arange(1, V + 1) ** 1.05
+    p /= p.sum()
+    lens = np.clip(rng.normal(150, 60, N), 16, 512).astype(np.int64)
+    tok = rng.choice(V, size=int(lens.sum()), p=p)
+    doc = np.repeat(np.arange(N), lens)
+    return V, lens, tok, doc, p
+
+
+def build_lleqa(args, dev, rank):
+    from fusion_amd import encoders, ops
+    rng = np.random.default_rng(1234 + rank)
+    Q, N, d = args.queries, args.corpus, args.dim
+    st = {}
+    # encoder + query tokens (LLeQA questions: ~15-40 word pieces, padded to the batch maximum <= 64)
+    if not args.no_encode:
+        enc = encoders.random_init("dpr", device=dev, size=args.encoder_size, seed=0)
+        d = enc.dim
+        L = 64
+        qlen = rng.integers(8, L + 1, Q)
+        ids = rng.integers(7, enc.backbone.config.vocab_size - 1, (Q, L))
+        mask = (np.arange(L)[None, :] < qlen[:, None]).astype(np.int64)
+        ids = np.where(mask == 1, ids, enc.backbone.config.pad_token_id)
+        st["enc"], st["ids"], st["mask"] = enc, torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    else:
+        st["q_emb"] = torch.from_numpy(rng.normal(0, 1, (Q, d)).astype(np.float32)).to(dev)
+    # corpus embeddings: encoded + normalised once (static corpus), resident in HBM
+    g = torch.Generator(device=dev).manual_seed(7)
+    De = torch.randn((N, d), generator=g, device=dev, dtype=torch.float32)
+    st["Dn"] = ops.normalize_rows(De)
+    del De
+    # BM25 index (device CSR) + the batch's query terms
+    V, lens, tok, doc, p = synth_bm25_index(N, np.random.default_rng(99))
+    key = tok.astype(np.int64) * N + doc
+    uniq, tf = np.unique(key, return_counts=True)
+    pt, pd = uniq // N, uniq % N
+    df = np.bincount(pt, minlength=V)
+    idf = np.log10((N - df + 0.5) / (df + 0.5))
+    toff = np.zeros(V + 1, dtype=np.int64); np.cumsum(df, out=toff[1:])
+    qn = rng.integers(4, 16, Q)
+    qterms = rng.choice(V, size=int(qn.sum()), p=p).astype(np.int32)
+    qoff = np.zeros(Q + 1, dtype=np.int64); np.cumsum(qn, out=qoff[1:])
+    st["bm25"] = dict(toff=torch.from_numpy(toff).to(dev), pdoc=torch.from_numpy(pd.astype(np.int32)).to(dev),
+                      ptf=torch.from_numpy(tf.astype(np.int32)).to(dev), idf=torch.from_numpy(idf).to(dev),
+                      doc_len=torch.from_numpy(lens.astype(np.int32)).to(dev), avgdl=float(lens.mean()),
+                      qoff=torch.from_numpy(qoff).to(dev), qterms=torch.from_numpy(qterms).to(dev))
+    st["lens2"] = torch.full((2, Q), N, dtype=torch.int32, device=dev)
+    st["Q"], st["N"], st["d"] = Q, N, d
+    st["host"] = dict(idf=idf, toff=toff, pd=pd, tf=tf, lens=lens, qoff=qoff, qterms=qterms)
+    return st
+
+
+def step_lleqa(st, ev=None):
+    from fusion_amd import ops
+    Q, N = st["Q"], st["N"]
+    b = st["bm25"]
+    if ev: ev.mark("start")
+    q_emb = st["enc"].encode_ids(st["ids"], st["mask"]) if "enc" in st else st["q_emb"]
+    if ev: ev.mark("encode")
+    Qn = ops.normalize_rows(q_emb)
+    S = ops.dot_scores(Qn, st["Dn"])
+    if ev: ev.mark("dpr_score")
+    o_d, _, r_d = ops.sort_rows_desc(S, want_keys=False, want_rank=True)
+    if ev: ev.mark("dpr_rank")
+    B = ops.bm25_scores(b["toff"], b["pdoc"], b["ptf"], b["idf"], b["doc_len"], b["avgdl"], 2.5, 0.2, b["qoff"], b["qterms"], Q, N)
+    if ev: ev.mark("bm25_score")
+    o_b, _, r_b = ops.sort_rows_desc(B, want_keys=False, want_rank=True)
+    if ev: ev.mark("bm25_rank")
+    fused = ops.fuse_rank([r_b, r_d], st["lens2"], "rrf")
+    if ev: ev.mark("fuse_rrf")
+    order, scores, _ = ops.sort_rows_desc(fused, init_order=o_b)
+    if ev: ev.mark("final_order")
+    return order, scores, (S, B)
+
+
+def algorithmic_work(st):
+    """Algorithmic bytes / flops per launch of each hand-written kernel (SURVEY.md 8d figures x units per launch)."""
+    Q, N, d = st["Q"], st["N"], st["d"]
+    e = Q * N
+    return {
+        "dpr_score": dict(kernel="dot_scores_kernel", bound="mfma", work=2.0 * Q * N * d, peak=MFMA_F32_PEAK_TF * 1e12, unit="TFLOP/s"),
+        "dpr_rank": dict(kernel="sort_rows_kernel<1024,28,1>", bound="hbm", work=e * (4 + 4 + 4), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
+        "bm25_rank": dict(kernel="sort_rows_kernel<1024,28,2>", bound="hbm", work=e * (8 + 4 + 4), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
+        "fuse_rrf": dict(kernel="fuse_rank_kernel", bound="hbm", work=e * (2 * 4 + 8), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
+        "final_order": dict(kernel="sort_rows_kernel<1024,28,2>+gather", bound="hbm", work=e * (8 + 4 + 4 + 8), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
+    }
+
+
+def cpu_baseline_lleqa(st, S_dev, B_dev, budget_s=20.0):
+    """The CPU oracle ("port") on a bounded sample of the SAME batch: score + rank + fuse + order for the first
+    q queries (no transformer forward on the CPU side), all host cores via OpenMP."""
+    from oracle import oracle
+    oracle.build()
+    N, d = st["N"], st["d"]
+    h = st["host"]
+    qs = 8
+    Dn = st["Dn"].cpu().numpy()[:, :d]
+    if "enc" in st:
+        with torch.no_grad():
+            q_emb = st["enc"].encode_ids(st["ids"][:64], st["mask"][:64]).cpu().numpy()
+    else:
+        q_emb = st["q_emb"][:64].cpu().numpy()
+
+    def run(q):
+        t0 = time.perf_counter()
+        Qn = oracle.normalize_rows(q_emb[:q])
+        S = oracle.dot_scores(Qn, Dn, fma_chain=True)
+        _, _, r_d = oracle.sort_rows_desc(S, want_rank=True)
+        import ctypes as C
+        B = np.empty((q, N), dtype=np.float64)
+        lib = oracle.lib()
+        qoff = np.ascontiguousarray(h["qoff"][: q + 1]); qterms = np.ascontiguousarray(h["qterms"][: int(qoff[-1]) + 1])
+        oracle._chk(lib.fzo_bm25_scores_f64(oracle._p(h["toff"]), oracle._p(h["pd"].astype(np.int32)), oracle._p(h["tf"].astype(np.int32)),
+                                            oracle._p(np.ascontiguousarray(h["idf"])), oracle._p(h["lens"].astype(np.int32)),
+                                            C.c_double(float(h["lens"].mean())), C.c_double(2.5), C.c_double(0.2), oracle._p(qoff),
+                                            oracle._p(qterms), q, N, oracle._p(B), N), "bm25")
+        o_b, _, r_b = oracle.sort_rows_desc(B, want_rank=True)
+        f = oracle.fuse_rank([r_b, r_d], np.full((2, q), N, dtype=np.int32), "rrf")
+        o_f, k_f = oracle.sort_rows_desc(f, init_order=o_b)
+        return time.perf_counter() - t0, (S, B, o_f, k_f)
+    t, _ = run(qs)
+    q = int(min(64, max(qs, qs * min(8.0, (budget_s / 2) / max(t, 1e-3)))))
+    t, out = run(q)
+    return dict(value=q / t, unit="queries/s", cores=oracle.num_threads(), kind="port",
+                sample=f"first {q} queries of the batch, score+rank+fuse+order only (no encoder forward), N={N}, d={d}, OpenMP"), out, q
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload == "mmarco":
+        from fusion_amd import distributed as fd
+        res = fd.bench_sharded(args, dev, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(res))
+        if dist: dist.destroy_process_group()
+        return
+
+    st = build_lleqa(args, dev, rank)
+    for _ in range(args.warmup):
+        step_lleqa(st)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist: dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step_lleqa(st)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations, live, with HIP events over a second instrumented region of the same K steps
+    ev_tot = {}
+    for _ in range(args.steps):
+        ev = Events()
+        step_lleqa(st, ev)
+        torch.cuda.synchronize()
+        for k, v in ev.durations_ms().items():
+            ev_tot[k] = ev_tot.get(k, 0.0) + v
+    stages = {k: v / args.steps for k, v in ev_tot.items()}
+
+    if rank == 0:
+        Q, N, d = st["Q"], st["N"], st["d"]
+        work = algorithmic_work(st)
+        kern = {k: v for k, v in stages.items() if k in work}
+        dom = max(kern, key=kern.get)
+        w = work[dom]
+        achieved = w["work"] / (kern[dom] * 1e-3)
+        scale = 1e12 if w["unit"] == "TFLOP/s" else 1e9
+        roof = dict(kernel=w["kernel"], stage=dom, bound=w["bound"], achieved=achieved / scale, peak=w["peak"] / scale, unit=w["unit"],
+                    frac=achieved / w["peak"], traffic=None, ms=kern[dom])
+        all_roof = {k: dict(kernel=work[k]["kernel"], ms=kern[k], achieved=work[k]["work"] / (kern[k] * 1e-3) / (1e12 if work[k]["unit"] == "TFLOP/s" else 1e9),
+                            unit=work[k]["unit"], frac=work[k]["work"] / (kern[k] * 1e-3) / work[k]["peak"]) for k in kern}
+        res = {
+            "metric": "queries/sec end-to-end (encode+score+fuse), LLeQA test; recall@500 parity",
+            "value": world * Q * args.steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if not args.no_encode else "f32", "data": "synthetic",
+            "config": {"workload": f"LLeQA-shaped BM25+DPR RRF hybrid: Q={Q} queries/GPU x N={N} articles, d={d}; "
+                                   f"{'CamemBERT-base-shaped fp32 query encoder (random init) + ' if not args.no_encode else 'NO encoder + '}"
+                                   "fp32-MFMA cos-sim + BM25(f64) + full stable ranking + RRF(f64) + final order",
+                       "queries_per_gpu": Q, "corpus": N, "dim": d, "fusion": "rrf", "systems": ["bm25", "dpr"],
+                       "encode_in_step": not args.no_encode, "parallelism": f"query-sharded x{world}, corpus replicated"},
+            "stages_ms": stages,
+            "score_fuse_qps_per_gpu": Q / (sum(v for k, v in stages.items() if k != "encode") * 1e-3),
+            "roofline": roof, "roofline_all": all_roof,
+        }
+        if not args.no_cpu_baseline:
+            _, _, (S, B) = out
+            cb, (S_o, B_o, o_f, k_f), q = cpu_baseline_lleqa(st, S, B)
+            res["cpu_baseline"] = cb
+            # parity on the sample while we are here: device scores vs oracle scores, device order vs oracle order
+            # (the order is compared on the oracle fed with the DEVICE's own scores: stage-wise parity)
+            res["parity_sample"] = {"cos_max_abs_err": float(np.max(np.abs(S[:q].cpu().numpy() - S_o))),
+                                    "bm25_bit_exact": bool(np.array_equal(B[:q].cpu().numpy(), B_o))}
+        print(json.dumps(res))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,218 @@
+// maxsim.hip -- K2: exact ColBERT late interaction on gfx950.
+//
+// Reference: Ranker.multi_vector_search (hybrid.py:108-137) -> colbert-ai Searcher.search_all; the score
+// PLAID approximates is   s(q,d) = sum_{i<Lq} max_{t in d} <Q[q][i], D[t]>    on 128-d
+// L2-normalised token vectors (run_colbert.sh:26-27), query padded to 64 tokens (hybrid.py:129).
+//
+// Mapping: v_mfma_f32_32x32x16_f16 with A = 32 DOCUMENT tokens (rows), B = 32 QUERY tokens (cols), K = dim.
+// The C layout puts the query token on the lane (col = lane&31) and the 32 document tokens in the 16
+// accumulator registers x 2 lane halves, so
+//     max over document tokens = in-lane max of 16 registers (+ one exchange between lane l and l^32),
+//     sum over query tokens    = a wave reduction over 32 lanes, once per (query, document).
+// A workgroup = 8 waves; every wave keeps the B fragments of 4 query blocks (2 queries x 64 tokens)
+// in 128 VGPRs for the whole kernel, and all 8 waves consume the same document tile, which is staged
+// global -> LDS once per workgroup (16-B chunks XOR-swizzled by row so that ds_read_b128 of 32 rows is
+// conflict-free) and double-buffered.  Tiles are aligned to document starts (rows past the end are masked
+// to -inf).  Workgroups that share a 32-document range run back-to-back on one XCD, so the range (about
+// 2.4 MB) is fetched from HBM once and served from that XCD's L2 to the other query groups.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace fz {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MS_DIM = 128;
+constexpr int MS_WAVES = 8;
+constexpr int MS_BLOCKS_PER_WAVE = 4;   // query blocks of 32 tokens held per wave
+constexpr int MS_DOCS_PER_WG = 32;
+constexpr int MS_TILE_BYTES = 32 * MS_DIM * 2;  // 8 KiB
+
+struct MaxSimArgs {
+    const _Float16* Qtok;   // [Q][Lq][128]
+    const _Float16* Dtok;   // [sumL][128]
+    const int64_t* Doff;    // [N+1]
+    float* scores; int lds;
+    int Q, Lq, N;
+    int QB;                 // Lq / 32
+    int QG;                 // query groups = ceil(Q*QB / (MS_WAVES*MS_BLOCKS_PER_WAVE))
+    int DR;                 // document ranges = ceil(N / MS_DOCS_PER_WG)
+    int64_t sumL;
+};
+
+__global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char tile[2][MS_TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int qg = idx % a.QG;
+    const int dr = (idx / a.QG) * 8 + x;
+    if (dr >= a.DR) return;
+
+    // ---- B fragments: this wave's 4 query blocks, all of K, resident for the whole kernel ----
+    // lane l holds B[k = 8*(l>>5) + j][col = l&31] = Qtok[token l&31 of the block][dim 16*ks + 8*(l>>5) + j]
+    const int blk0 = (qg * MS_WAVES + w) * MS_BLOCKS_PER_WAVE;   // global query-block index of this wave's first block
+    const int nblk_total = a.Q * a.QB;
+    f16x8 bq[MS_BLOCKS_PER_WAVE][8];
+#pragma unroll
+    for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) {
+        const int blk = blk0 + b;
+        const bool okb = blk < nblk_total;
+        const size_t tok = okb ? (size_t)blk * 32 + (lane & 31) : 0;   // blocks are consecutive 32-token slices of [Q*Lq]
+        const _Float16* src = a.Qtok + tok * MS_DIM + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            f16x8 v = *reinterpret_cast<const f16x8*>(src + 16 * ks);
+            if (!okb) v = (f16x8)(_Float16)0;
+            bq[b][ks] = v;
+        }
+    }
+
+    const int d_begin = dr * MS_DOCS_PER_WG;
+    const int d_end = (d_begin + MS_DOCS_PER_WG < a.N) ? d_begin + MS_DOCS_PER_WG : a.N;
+
+    // ---- tile walk: tiles are aligned to document starts -------------------------------
+    // staging: 512 threads x one 16-B chunk = one 32-token tile; thread -> (row = tid/16, chunk = tid%16)
+    const int srow = tid >> 4, schunk = tid & 15;
+    const int swz = (srow * 256) + ((schunk ^ (srow & 15)) << 4);
+    auto stage_load = [&](int64_t tok0) -> uint4 {
+        int64_t t = tok0 + srow;
+        t = t < a.sumL ? t : a.sumL - 1;   // rows past the end of the corpus: clamp (they are masked)
+        return *reinterpret_cast<const uint4*>(a.Dtok + (size_t)t * MS_DIM + schunk * 8);
+    };
+
+    auto doc_len = [&](int d) -> int { return (int)(a.Doff[d + 1] - a.Doff[d]); };
+    // vals[b]: per-block sums already reduced over the wave; lane 0 writes one score per query.
+    // An empty document scores 0 for every query (sum of an empty max := 0, as in the oracle).
+    auto write_scores = [&](int d, const float* vals) {
+        if (lane == 0) {
+            const int qpw = MS_BLOCKS_PER_WAVE / a.QB;   // queries per wave
+            for (int qi = 0; qi < qpw; ++qi) {
+                const int q = blk0 / a.QB + qi;
+                if (q < a.Q) {
+                    float s = 0.f;
+                    for (int b = 0; b < a.QB; ++b) s += vals[qi * a.QB + b];
+                    a.scores[(size_t)q * a.lds + d] = s;
+                }
+            }
+        }
+    };
+    const float zeros[MS_BLOCKS_PER_WAVE] = {0.f, 0.f, 0.f, 0.f};
+
+    // (document, tile) walk; all bookkeeping below is block-uniform
+    int cur_doc = d_begin;
+    while (cur_doc < d_end && doc_len(cur_doc) == 0) { write_scores(cur_doc, zeros); ++cur_doc; }
+    if (cur_doc >= d_end) return;
+    const int64_t cur_tok = a.Doff[cur_doc];
+    int cur_len = doc_len(cur_doc);
+    int tile_in_doc = 0;
+    int buf = 0;
+    float run[MS_BLOCKS_PER_WAVE];
+
+    uint4 stage = stage_load(cur_tok);
+    *reinterpret_cast<uint4*>(&tile[0][swz]) = stage;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) run[b] = -INFINITY;
+
+    while (true) {
+        // ---- what comes next (block-uniform scalar bookkeeping) ------------------------
+        const int rows_valid = cur_len - tile_in_doc * 32;          // > 0
+        const bool last_tile_of_doc = rows_valid <= 32;
+        int nxt_doc = cur_doc, nxt_tile = tile_in_doc + 1, nxt_len = cur_len;
+        if (last_tile_of_doc) {
+            nxt_doc = cur_doc + 1; nxt_tile = 0;
+            while (nxt_doc < d_end && doc_len(nxt_doc) == 0) ++nxt_doc;
+            nxt_len = nxt_doc < d_end ? doc_len(nxt_doc) : 0;
+        }
+        const bool have_next = nxt_doc < d_end;
+        if (have_next) stage = stage_load(a.Doff[nxt_doc] + (int64_t)nxt_tile * 32);
+
+        // ---- A fragments from LDS: lane l -> row l&31, k = 16*ks + 8*(l>>5) .. +7 ------------
+        f16x8 af[8];
+        {
+            const int r = lane & 31, h = lane >> 5;
+            const unsigned char* base = &tile[buf][r * 256];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int chunk = 2 * ks + h;
+                af[ks] = *reinterpret_cast<const f16x8*>(base + ((chunk ^ (r & 15)) << 4));
+            }
+        }
+        // ---- 4 query blocks x 8 k-steps ------------------------------------------------
+#pragma unroll
+        for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bq[b][ks], acc, 0, 0, 0);
+            if (last_tile_of_doc && rows_valid < 32) {
+                // row of register r = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row >= rows_valid) acc[r] = -INFINITY;
+                }
+            }
+            float m = run[b];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[r]);
+            run[b] = m;
+        }
+        // ---- end of a document: finish max over the two lane halves, sum over query tokens
+        if (last_tile_of_doc) {
+            float sums[MS_BLOCKS_PER_WAVE];
+#pragma unroll
+            for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) {
+                float m = fmaxf(run[b], __shfl_xor(run[b], 32, 64));   // both halves now hold the column max
+                // sum over the 32 columns (lanes 0..31); lanes 32..63 duplicate them
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+                sums[b] = m;
+                run[b] = -INFINITY;
+            }
+            write_scores(cur_doc, sums);
+            for (int d = cur_doc + 1; d < nxt_doc && d < d_end; ++d) write_scores(d, zeros);  // skipped empty documents
+        }
+        if (!have_next) break;
+        // ---- publish the prefetched tile into the other buffer --------------------------
+        *reinterpret_cast<uint4*>(&tile[buf ^ 1][swz]) = stage;
+        __syncthreads();
+        buf ^= 1;
+        cur_doc = nxt_doc; tile_in_doc = nxt_tile; cur_len = nxt_len;
+    }
+}
+
+}  // namespace fz
+
+using namespace fz;
+
+extern "C" int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* Doff, int64_t sumL, int Q, int Lq, int N, int dim,
+                             float* scores, int lds, void* stream) {
+    if (!Qtok || !Dtok || !Doff || !scores || Q < 0 || N < 0 || Lq <= 0 || lds < N) return FZ_ERR_ARG;
+    if (dim != MS_DIM) return FZ_ERR_UNSUPPORTED;
+    if (Lq % 32 != 0 || (MS_BLOCKS_PER_WAVE % (Lq / 32)) != 0) return FZ_ERR_UNSUPPORTED;  // Lq in {32, 64, 128}
+    if (((uintptr_t)Qtok % 16) || ((uintptr_t)Dtok % 16)) return FZ_ERR_UNSUPPORTED;
+    if (Q == 0 || N == 0) return FZ_OK;
+    hipStream_t st = as_stream(stream);
+    if (sumL < 0) return FZ_ERR_ARG;
+    if (sumL == 0) {  // every document empty: all scores 0
+        FZ_HIP_TRY(hipMemset2DAsync(scores, (size_t)lds * 4, 0, (size_t)N * 4, (size_t)Q, st));
+        return FZ_OK;
+    }
+    MaxSimArgs a{};
+    a.Qtok = reinterpret_cast<const _Float16*>(Qtok);
+    a.Dtok = reinterpret_cast<const _Float16*>(Dtok);
+    a.Doff = Doff; a.scores = scores; a.lds = lds; a.Q = Q; a.Lq = Lq; a.N = N; a.sumL = sumL;
+    a.QB = Lq / 32;
+    const int blocks_per_wg = MS_WAVES * MS_BLOCKS_PER_WAVE;
+    a.QG = (Q * a.QB + blocks_per_wg - 1) / blocks_per_wg;
+    a.DR = (N + MS_DOCS_PER_WG - 1) / MS_DOCS_PER_WG;
+    const long nblk = 8L * a.QG * ((a.DR + 7) / 8);
+    if (nblk > 0x7fffffffL) return FZ_ERR_UNSUPPORTED;
+    maxsim_kernel<<<(unsigned)nblk, 512, 0, st>>>(a);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}

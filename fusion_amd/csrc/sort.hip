@@ -1,0 +1,419 @@
+// sort.hip -- stable descending row sort (K5a/K6) and top-k (A12) for gfx950.
+//
+// Reference semantics: Python sorted(items, key=score, reverse=True) is stable
+// (bm25.py:104, hybrid.py:306); util.semantic_search / torch.topk + heap merge
+// (hybrid.py:103, sentence_transformers.py:346-364) for top-k.
+//
+// Design (MI355X-first): one workgroup owns one row.  A row (<= 35,840 keys) lives entirely in
+// the workgroup's registers (E keys per thread, "wave-striped": wave w, item i, lane l holds
+// sequence position w*E*64 + i*64 + l), so HBM sees each key once in and once out.  Each of
+// the 4 (fp32) / 8 (fp64) LSD passes over an 8-bit digit is
+//   1. rank:     per item, the 64 lanes of a wave find their same-digit peers with 8 ballots
+//                (wave64 match-any), and bump a wave-private LDS counter (no atomics, stable);
+//   2. scan:     256 digits x NW waves counters -> exclusive prefix (digit-major);
+//   3. exchange: scatter keys (then the 16-bit payload) through a T*E*4-byte LDS buffer
+//                and read them back in striped order.
+// Passes whose digit is constant over the row are skipped.  LDS: up to 156 KiB of the CU's
+// 160 KiB, i.e. one 1024-thread workgroup per CU.
+#include "common.h"
+
+namespace fz {
+
+struct SortArgs {
+    const void* keys;            // fp32 or fp64
+    const int32_t* init_order;   // nullable [rows][key_row_stride]
+    const int32_t* row_len;      // nullable [rows]
+    int n_total;                 // elements per row (before chunking)
+    long key_row_stride;         // elements between consecutive rows
+    int seg_len;                 // element e lives at (e / seg_len) * seg_stride + row*key_row_stride + e % seg_len
+    long seg_stride;             //   (seg_len >= n_total -> plain rows)
+    int chunks;                  // pseudo-rows per row
+    int chunk_len;               // chunk c covers [c*chunk_len, min(n_total,(c+1)*chunk_len))
+    int32_t* order;              // nullable
+    void* sorted_keys;           // nullable, same type as keys
+    int32_t* rank;               // nullable (only chunks == 1)
+    long out_row_stride;         // elements between rows of order / sorted_keys
+    int out_chunk_stride;        // elements between chunks inside a row
+    int out_limit;               // only the first out_limit entries of each pseudo-row are written
+    const int32_t* colmap;       // nullable: order value = colmap[row*colmap_row_stride + col]
+    long colmap_row_stride;
+    const int64_t* idmap;        // nullable: out_ids = idmap[addr(col)] (same segment addressing as keys)
+    int64_t id_base;             // else out_ids = id_base + col
+    int64_t* out_ids;            // nullable, [rows][out_row_stride] like order
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+template <int T, int E, int KW>
+__global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
+    constexpr int NW = T / 64;
+    constexpr uint32_t SENT = 0xffffffffu;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* exch = smem;                         // [T*E]
+    uint32_t* cnt = smem + T * E;                  // [NW*256] (plain LDS pointer: volatile would lower to flat sc0 sc1 accesses)
+    uint32_t* misc = smem + T * E + NW * 256;      // [32]
+
+    const int prow = blockIdx.x;
+    const int row = prow / a.chunks;
+    const int chunk = prow - row * a.chunks;
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int c0 = chunk * a.chunk_len;
+
+    int m_row = a.row_len ? a.row_len[row] : a.n_total;
+    m_row = m_row < 0 ? 0 : (m_row > a.n_total ? a.n_total : m_row);
+    int m = m_row - c0;
+    m = m < 0 ? 0 : (m > a.chunk_len ? a.chunk_len : m);
+    if (m == 0) return;  // block-uniform: empty (pseudo-)row
+
+    // uniform row bases + 32-bit per-lane indices (saddr+voffset addressing; no 64-bit per-item addresses)
+    const size_t krow = (size_t)row * a.key_row_stride;
+    const bool seg = a.seg_len < a.n_total;  // block-uniform: segmented rows ([G][rows][k] top-k lists)
+    const float* __restrict__ kf = reinterpret_cast<const float*>(a.keys) + krow;
+    const double* __restrict__ kd = reinterpret_cast<const double*>(a.keys) + krow;
+    const int32_t* __restrict__ init_row = a.init_order ? a.init_order + krow : nullptr;
+    auto elem = [&](int col) -> long {  // element offset of column `col` relative to the row base
+        return seg ? (long)(col / a.seg_len) * a.seg_stride + (col % a.seg_len) : (long)col;
+    };
+
+    uint32_t k0[E];
+    uint32_t k1[KW == 2 ? E : 1];
+    uint32_t meta[E];  // low 16: payload (column inside the chunk); high 16: scratch (offset / destination)
+
+    if (threadIdx.x < 4) misc[8 + threadIdx.x] = (threadIdx.x & 1) ? 0xffffffffu : 0u;  // [8]=or0 [9]=and0 [10]=or1 [11]=and1
+    __syncthreads();
+    uint32_t or0 = 0, and0 = 0xffffffffu, or1 = 0, and1 = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        // branch-free: out-of-range lanes load a safe element (column c0 exists because m > 0) and discard it
+        const int p = w * E * 64 + i * 64 + lane;
+        const bool valid = p < m;
+        int col = valid ? c0 + p : c0;
+        if (init_row) col = init_row[col];
+        const bool ok = valid && (unsigned)col < (unsigned)a.n_total;
+        col = ok ? col : c0;
+        if (KW == 1) {
+            const uint32_t kk = desc_key_f32(kf[elem(col)]);
+            k0[i] = ok ? kk : SENT;
+        } else {
+            const uint64_t kk = desc_key_f64(kd[elem(col)]);
+            k0[i] = ok ? (uint32_t)kk : SENT;
+            k1[KW == 2 ? i : 0] = ok ? (uint32_t)(kk >> 32) : SENT;
+            or1 |= ok ? k1[KW == 2 ? i : 0] : 0u; and1 &= ok ? k1[KW == 2 ? i : 0] : 0xffffffffu;
+        }
+        or0 |= ok ? k0[i] : 0u; and0 &= ok ? k0[i] : 0xffffffffu;
+        // payload: the source column (gathered sequence) or the column inside the chunk
+        meta[i] = ok ? (uint32_t)(init_row ? col : col - c0) & 0xffffu : 0xffffu;
+        if ((i & (KW == 2 ? 1 : 3)) == (KW == 2 ? 1 : 3)) __builtin_amdgcn_sched_barrier(0);  // few items in flight
+    }
+    // which digits vary over the row?
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        or0 |= __shfl_xor(or0, o, 64); and0 &= __shfl_xor(and0, o, 64);
+        if (KW == 2) { or1 |= __shfl_xor(or1, o, 64); and1 &= __shfl_xor(and1, o, 64); }
+    }
+    if (lane == 0) {
+        atomicOr(&misc[8], or0); atomicAnd(&misc[9], and0);
+        if (KW == 2) { atomicOr(&misc[10], or1); atomicAnd(&misc[11], and1); }
+    }
+    __syncthreads();
+    const uint32_t diff0 = misc[8] ^ misc[9];
+    const uint32_t diff1 = (KW == 2) ? (misc[10] ^ misc[11]) : 0u;
+
+    for (int pass = 0; pass < 4 * KW; ++pass) {
+        const int shift = (pass & 3) * 8;
+        const bool hi = (KW == 2) && pass >= 4;
+        const uint32_t diff = hi ? diff1 : diff0;
+        if (((diff >> shift) & 0xffu) == 0u) continue;  // constant digit among real keys: order unchanged
+
+        // ---- 1. rank inside the wave ------------------------------------------------
+        uint32_t* my = cnt + w * 256;
+        my[lane] = 0; my[lane + 64] = 0; my[lane + 128] = 0; my[lane + 192] = 0;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint32_t kw = hi ? k1[KW == 2 ? i : 0] : k0[i];
+            const uint32_t d = (kw >> shift) & 0xffu;
+            uint32_t mlo = 0xffffffffu, mhi = 0xffffffffu;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                const uint32_t neg = bit ? 0u : 0xffffffffu;
+                mlo &= ((uint32_t)bal) ^ neg;
+                mhi &= ((uint32_t)(bal >> 32)) ^ neg;
+            }
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+            const uint32_t npeer = __popc(mlo) + __popc(mhi);
+            const uint32_t old = my[d];
+            if (below == 0) my[d] = old + npeer;
+            meta[i] = (meta[i] & 0xffffu) | ((old + below) << 16);
+            // opaque to the optimiser: otherwise hipcc keeps old, below, payload and &my[d] in four separate
+            // registers per item across the barrier (6.6 VGPRs/item -> scratch spills at E = 28)
+            asm volatile("" : "+v"(meta[i]));
+        }
+        __syncthreads();
+        // ---- 2. exclusive prefix over (digit, wave), digit-major ----------------------
+        uint32_t tot = 0, incl = 0;
+        if (threadIdx.x < 256) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                uint32_t c = cnt[ww * 256 + threadIdx.x];
+                cnt[ww * 256 + threadIdx.x] = run;
+                run += c;
+            }
+            tot = run;
+            incl = wave_incl_scan_u32(tot, lane);
+            if (lane == 63) misc[w] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            uint32_t base = incl - tot;
+            for (int ww = 0; ww < w; ++ww) base += misc[ww];
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) cnt[ww * 256 + threadIdx.x] += base;
+        }
+        __syncthreads();
+        // ---- 3. destination, exchange --------------------------------------------------
+        // (sched_barrier every 4 items: without it hipcc hoists all E LDS addresses/values and spills)
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            uint32_t kw = hi ? k1[KW == 2 ? i : 0] : k0[i];
+            asm volatile("" : "+v"(kw));  // recompute the digit here instead of keeping &my[d] alive per item
+            const uint32_t d = (kw >> shift) & 0xffu;
+            const uint32_t dst = my[d] + (meta[i] >> 16);
+            meta[i] = (meta[i] & 0xffffu) | (dst << 16);
+            asm volatile("" : "+v"(meta[i]));
+            exch[dst] = k0[i];
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            k0[i] = exch[w * E * 64 + i * 64 + lane];
+            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (KW == 2) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                exch[meta[i] >> 16] = k1[KW == 2 ? i : 0];
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                k1[KW == 2 ? i : 0] = exch[w * E * 64 + i * 64 + lane];
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            exch[meta[i] >> 16] = meta[i] & 0xffffu;
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            meta[i] = exch[w * E * 64 + i * 64 + lane];
+            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- output (coalesced: consecutive lanes = consecutive ranks) -------------------------
+    const int lim = m < a.out_limit ? m : a.out_limit;
+    const size_t obase = (size_t)row * a.out_row_stride + (size_t)chunk * a.out_chunk_stride;
+    int32_t* __restrict__ o_order = a.order ? a.order + obase : nullptr;
+    int64_t* __restrict__ o_ids = a.out_ids ? a.out_ids + obase : nullptr;
+    float* __restrict__ o_kf = a.sorted_keys ? reinterpret_cast<float*>(a.sorted_keys) + obase : nullptr;
+    double* __restrict__ o_kd = a.sorted_keys ? reinterpret_cast<double*>(a.sorted_keys) + obase : nullptr;
+    int32_t* __restrict__ o_rank = a.rank ? a.rank + (size_t)row * a.out_row_stride : nullptr;
+    const int32_t* __restrict__ cmap = a.colmap ? a.colmap + (size_t)row * a.colmap_row_stride : nullptr;
+    const int64_t* __restrict__ imap = a.idmap ? a.idmap + krow : nullptr;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int p = w * E * 64 + i * 64 + lane;
+        if (p < lim) {
+            int col = (int)(meta[i] & 0xffffu);
+            if (!init_row) col += c0;
+            const int oc = cmap ? cmap[col] : col;  // -1 = padding candidate of a short top-k chunk
+            if (o_order) o_order[p] = oc;
+            if (o_ids) o_ids[p] = imap ? imap[elem(col)] : (oc < 0 ? (int64_t)-1 : a.id_base + (int64_t)oc);
+            if (o_kf) {
+                if (KW == 1) o_kf[p] = desc_key_f32_inv(k0[i]);
+                else o_kd[p] = desc_key_f64_inv(((uint64_t)k1[KW == 2 ? i : 0] << 32) | (uint64_t)k0[i]);
+            }
+            if (o_rank && oc >= 0) o_rank[oc] = p;
+        }
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// pad the tail of top-k outputs with (-inf, -1)
+__global__ void topk_pad_kernel(float* out_scores, int64_t* out_ids, int rows, int k, int have) {
+    const int r = blockIdx.y;
+    for (int i = have + blockIdx.x * blockDim.x + threadIdx.x; i < k; i += gridDim.x * blockDim.x) {
+        out_scores[(size_t)r * k + i] = -INFINITY;
+        out_ids[(size_t)r * k + i] = -1;
+    }
+}
+
+struct SortCfg { int T, E; };
+
+static inline bool pick_cfg(int n, int kw, SortCfg& c) {
+    if (n <= 1024) c = {256, 4};
+    else if (n <= 4096) c = {256, 16};
+    else if (n <= 8192) c = {512, 16};
+    else if (n <= 16384) c = {1024, 16};
+    else if (n <= 28672) c = {1024, 28};
+    else if (n <= 35840 && kw == 1) c = {1024, 35};
+    else return false;
+    return true;
+}
+
+template <int T, int E, int KW>
+static int launch_cfg(const SortArgs& a, int prows, hipStream_t st) {
+    constexpr size_t lds = ((size_t)T * E + (T / 64) * 256 + 32) * 4;
+    static bool attr_set = false;  // per (T,E,KW) instantiation
+    if (!attr_set) {
+        FZ_HIP_TRY(hipFuncSetAttribute((const void*)sort_rows_kernel<T, E, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    sort_rows_kernel<T, E, KW><<<prows, T, lds, st>>>(a);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+static int launch_sort(const SortArgs& a, int kw, int prows, int n_chunk, hipStream_t st) {
+    SortCfg c;
+    if (!pick_cfg(n_chunk, kw, c)) return FZ_ERR_UNSUPPORTED;
+#define FZ_SORT_CASE(TT, EE)                                                      \
+    if (c.T == TT && c.E == EE) return kw == 1 ? launch_cfg<TT, EE, 1>(a, prows, st) : launch_cfg<TT, EE, 2>(a, prows, st);
+    FZ_SORT_CASE(256, 4) FZ_SORT_CASE(256, 16) FZ_SORT_CASE(512, 16) FZ_SORT_CASE(1024, 16) FZ_SORT_CASE(1024, 28)
+#undef FZ_SORT_CASE
+    if (c.T == 1024 && c.E == 35 && kw == 1) return launch_cfg<1024, 35, 1>(a, prows, st);
+    return FZ_ERR_UNSUPPORTED;
+}
+
+}  // namespace fz
+
+using namespace fz;
+
+extern "C" int fz_sort_max_n(void) { return 35840; }   // fp32 keys; fp64 keys: 28672
+extern "C" int fz_sort_max_n_f64(void) { return 28672; }
+
+extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows,
+                                 int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream) {
+    if (!keys || (key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
+    if (rows == 0 || n == 0) return FZ_OK;
+    if (n > (key_bits == 32 ? 35840 : 28672)) return FZ_ERR_UNSUPPORTED;
+    SortArgs a{};
+    a.keys = keys; a.init_order = init_order; a.row_len = row_len;
+    a.n_total = n; a.key_row_stride = ld; a.seg_len = n; a.seg_stride = 0;
+    a.chunks = 1; a.chunk_len = n;
+    a.order = order; a.sorted_keys = sorted_keys; a.rank = rank;
+    a.out_row_stride = ld; a.out_chunk_stride = 0; a.out_limit = n;
+    return launch_sort(a, key_bits / 32, rows, n, as_stream(stream));
+}
+
+// ---- top-k: chunk-sort-truncate levels until one workgroup can finish the row ---------------
+static const int TOPK_CHUNK = 28672;
+extern "C" int fz_topk_max_k(void) { return 8192; }
+
+static void topk_plan(int n, int k, int* levels_out, size_t* elems_out) {
+    // level l: cur columns -> chunks of TOPK_CHUNK -> kk = min(k, TOPK_CHUNK) survivors per chunk
+    int cur = n, levels = 0;
+    size_t elems = 0;
+    while (cur > 35840) {
+        int nch = (cur + TOPK_CHUNK - 1) / TOPK_CHUNK;
+        int kk = k < TOPK_CHUNK ? k : TOPK_CHUNK;
+        cur = nch * kk;
+        elems += (size_t)cur;
+        ++levels;
+    }
+    *levels_out = levels;
+    *elems_out = elems;
+}
+
+__global__ void topk_fill_kernel(float* keys, int32_t* cols, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        keys[i] = -INFINITY;
+        cols[i] = -1;
+    }
+}
+
+extern "C" size_t fz_topk_workspace_bytes(int rows, int n, int k) {
+    if (rows <= 0 || n <= 0 || k <= 0) return 0;
+    int levels; size_t elems;
+    topk_plan(n, k, &levels, &elems);
+    return (size_t)rows * elems * 8 + 256;  // fp32 score + int32 column per surviving candidate
+}
+
+extern "C" int fz_topk_rows_f32(const float* scores, int rows, int n, int ld, int k, int64_t id_base, float* out_scores,
+                                int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!scores || !out_scores || !out_ids || rows < 0 || n < 0 || ld < n || k <= 0) return FZ_ERR_ARG;
+    if (k > fz_topk_max_k()) return FZ_ERR_UNSUPPORTED;
+    if (rows == 0) return FZ_OK;
+    hipStream_t st = as_stream(stream);
+    const int have = n < k ? n : k;
+    if (have < k) {
+        dim3 g((unsigned)((k - have + 255) / 256), (unsigned)rows);
+        topk_pad_kernel<<<g, 256, 0, st>>>(out_scores, out_ids, rows, k, have);
+        FZ_LAUNCH_CHECK();
+    }
+    if (n == 0) return FZ_OK;
+    if (workspace_bytes < fz_topk_workspace_bytes(rows, n, k)) return FZ_ERR_WORKSPACE;
+    if (n > 35840 && !workspace) return FZ_ERR_WORKSPACE;
+
+    const float* cur_keys = scores;
+    const int32_t* cur_cols = nullptr;
+    long cur_stride = ld;
+    int cur = n, level = 0;
+    char* ws = reinterpret_cast<char*>(workspace);
+    while (cur > 35840) {
+        const int per = TOPK_CHUNK;
+        int nch = (cur + per - 1) / per;
+        int kk = k < per ? k : per;
+        int next = nch * kk;
+        float* nk = reinterpret_cast<float*>(ws); ws += (size_t)rows * next * 4;
+        int32_t* nc = reinterpret_cast<int32_t*>(ws); ws += (size_t)rows * next * 4;
+        if (cur - (nch - 1) * per < kk) {
+            // the short last chunk leaves a tail unwritten: make it (-inf, col -1) so it cannot win
+            topk_fill_kernel<<<1024, 256, 0, st>>>(nk, nc, (size_t)rows * next);
+            FZ_LAUNCH_CHECK();
+        }
+        SortArgs a{};
+        a.keys = cur_keys; a.n_total = cur; a.key_row_stride = cur_stride; a.seg_len = cur; a.chunks = nch; a.chunk_len = per;
+        a.order = nc; a.sorted_keys = nk; a.out_row_stride = next; a.out_chunk_stride = kk; a.out_limit = kk;
+        a.colmap = cur_cols; a.colmap_row_stride = cur_stride;
+        int rc = launch_sort(a, 1, rows * nch, per, st);
+        if (rc != FZ_OK) return rc;
+        cur_keys = nk; cur_cols = nc; cur_stride = next; cur = next; ++level;
+    }
+    SortArgs a{};
+    a.keys = cur_keys; a.n_total = cur; a.key_row_stride = cur_stride; a.seg_len = cur; a.chunks = 1; a.chunk_len = cur;
+    a.sorted_keys = out_scores; a.out_ids = out_ids; a.id_base = id_base; a.out_row_stride = k; a.out_limit = have;
+    a.colmap = cur_cols; a.colmap_row_stride = cur_stride;
+    return launch_sort(a, 1, rows, cur, st);
+}
+
+extern "C" int fz_topk_merge(const float* in_scores, const int64_t* in_ids, int G, int rows, int k, float* out_scores,
+                             int64_t* out_ids, void* stream) {
+    if (!in_scores || !in_ids || !out_scores || !out_ids || G <= 0 || rows < 0 || k <= 0) return FZ_ERR_ARG;
+    if ((long)G * k > 35840) return FZ_ERR_UNSUPPORTED;
+    if (rows == 0) return FZ_OK;
+    SortArgs a{};
+    a.keys = in_scores; a.n_total = G * k; a.key_row_stride = k; a.seg_len = k; a.seg_stride = (long)rows * k;
+    a.chunks = 1; a.chunk_len = G * k;
+    a.sorted_keys = out_scores; a.out_ids = out_ids; a.idmap = in_ids; a.out_row_stride = k; a.out_limit = k;
+    return launch_sort(a, 1, rows, G * k, as_stream(stream));
+}

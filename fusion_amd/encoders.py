@@ -1,0 +1,200 @@
+"""PyTorch-ROCm transformer forwards for the encode stage (plumbing, not the product).
+
+Reference call sites:
+  DPR     SentenceTransformerCustom(...).encode(batch_size=64, convert_to_tensor=True)  hybrid.py:98-102,
+          built as Transformer + mean Pooling (src/utils/common.py:13-20, scripts/run_dpr.sh:27), fp32, max_seq_length 512
+  SPLADE  SPLADE.forward: amax_L log1p(relu(logits * mask))  (splade/splade.py:88-99), encode() splade/base.py:253-291,
+          max_query_length 64 / max_doc_length 512 (hybrid.py:96)
+  ColBERT query_maxlen 64 (queries padded with [MASK] and attended, run_colbert.sh:29), doc_maxlen 512, dim 128,
+          cosine similarity = L2-normalised token vectors (run_colbert.sh:26-27), punctuation masked in documents (:28)
+
+No checkpoints or tokenizer files exist offline, so `random_init()` builds CamemBERT-base-SHAPED modules with random
+weights (same FLOPs / bytes as the real ones) and `HashTokenizer` maps whitespace tokens to ids deterministically.
+With real checkpoints on disk, `from_pretrained()` loads them through transformers.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import torch
+import torch.nn as nn
+
+CAMEMBERT_BASE = dict(vocab_size=32005, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                      max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, bos_token_id=5, eos_token_id=6)
+TINY = dict(vocab_size=512, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+            max_position_embeddings=130, type_vocab_size=1, pad_token_id=1, bos_token_id=5, eos_token_id=6)
+MASK_TOKEN_ID = 32004  # camembert <mask>
+
+
+class HashTokenizer:
+    """Deterministic whitespace tokenizer for synthetic text (no sentencepiece model offline)."""
+
+    def __init__(self, vocab_size: int, pad_id: int = 1, bos_id: int = 5, eos_id: int = 6, mask_id: int | None = None):
+        self.vocab_size, self.pad_token_id, self.bos_id, self.eos_id = vocab_size, pad_id, bos_id, eos_id
+        self.mask_token_id = mask_id if mask_id is not None else vocab_size - 1
+        self._first = 7
+
+    def _tok(self, w: str) -> int:
+        h = int.from_bytes(hashlib.blake2b(w.encode("utf-8"), digest_size=4).digest(), "little")
+        return self._first + h % (self.vocab_size - self._first - 1)
+
+    def __call__(self, texts: list[str], max_length: int, pad_to_max: bool = False):
+        rows = [[self.bos_id] + [self._tok(w) for w in t.split()][: max_length - 2] + [self.eos_id] for t in texts]
+        L = max_length if pad_to_max else max(len(r) for r in rows)
+        ids = torch.full((len(rows), L), self.pad_token_id, dtype=torch.long)
+        mask = torch.zeros((len(rows), L), dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, : len(r)] = torch.tensor(r)
+            mask[i, : len(r)] = 1
+        return ids, mask
+
+
+def _backbone(cfg: dict, mlm: bool = False):
+    from transformers import CamembertConfig, CamembertForMaskedLM, CamembertModel
+    c = CamembertConfig(**cfg)
+    return CamembertForMaskedLM(c) if mlm else CamembertModel(c, add_pooling_layer=False)
+
+
+class _Base(nn.Module):
+    max_query_length = 64
+    max_doc_length = 512
+
+    def __init__(self, tokenizer, device):
+        super().__init__()
+        self.tokenizer = tokenizer
+        self._device = torch.device(device)
+
+    def _batches(self, sentences, batch_size, max_len, pad_to_max=False):
+        # sort by length as SentenceTransformer.encode does, restore order afterwards
+        order = sorted(range(len(sentences)), key=lambda i: -len(sentences[i]))
+        for s in range(0, len(order), batch_size):
+            idx = order[s: s + batch_size]
+            ids, mask = self.tokenizer([sentences[i] for i in idx], max_len, pad_to_max)
+            yield idx, ids.to(self._device, non_blocking=True), mask.to(self._device, non_blocking=True)
+
+
+class DenseEncoder(_Base):
+    """DPR bi-encoder: CamemBERT + mean pooling over the attention mask, fp32."""
+
+    def __init__(self, backbone, tokenizer, device):
+        super().__init__(tokenizer, device)
+        self.backbone = backbone.to(self._device).eval()
+        self.dim = backbone.config.hidden_size
+
+    @torch.no_grad()
+    def encode_ids(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        h = self.backbone(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+        m = attention_mask.unsqueeze(-1).to(h.dtype)
+        return (h * m).sum(1) / m.sum(1).clamp_min(1e-9)   # sentence-transformers Pooling(mean)
+
+    @torch.no_grad()
+    def encode(self, sentences: list[str], batch_size: int = 64, query_mode: bool = True, **_) -> torch.Tensor:
+        out = torch.empty((len(sentences), self.dim), dtype=torch.float32, device=self._device)
+        for idx, ids, mask in self._batches(sentences, batch_size, 512):
+            out[torch.tensor(idx, device=self._device)] = self.encode_ids(ids, mask).float()
+        return out
+
+
+class SpladeEncoder(_Base):
+    """SPLADE-max: amax over tokens of log1p(relu(MLM logits * mask))  (splade/splade.py:88-99)."""
+
+    def __init__(self, mlm, tokenizer, device):
+        super().__init__(tokenizer, device)
+        self.mlm = mlm.to(self._device).eval()
+        self.dim = mlm.config.vocab_size
+
+    @torch.no_grad()
+    def encode_ids(self, input_ids, attention_mask) -> torch.Tensor:
+        logits = self.mlm(input_ids=input_ids, attention_mask=attention_mask).logits
+        return torch.amax(torch.log1p(torch.relu(logits * attention_mask.unsqueeze(-1))), dim=1)
+
+    @torch.no_grad()
+    def encode(self, sentences, batch_size: int = 64, query_mode: bool = True, **_) -> torch.Tensor:
+        out = torch.empty((len(sentences), self.dim), dtype=torch.float32, device=self._device)
+        max_len = self.max_query_length if query_mode else self.max_doc_length
+        for idx, ids, mask in self._batches(sentences, batch_size, max_len):
+            out[torch.tensor(idx, device=self._device)] = self.encode_ids(ids, mask).float()
+        return out
+
+
+class ColbertEncoder(_Base):
+    """ColBERT: CamemBERT -> Linear(768,128, bias=False) -> L2-normalised token vectors (fp16)."""
+    dim = 128
+
+    def __init__(self, backbone, tokenizer, device, punct_ids: tuple[int, ...] = ()):
+        super().__init__(tokenizer, device)
+        self.backbone = backbone.to(self._device).eval()
+        self.linear = nn.Linear(backbone.config.hidden_size, self.dim, bias=False).to(self._device)
+        self.punct_ids = torch.tensor(list(punct_ids), dtype=torch.long, device=self._device)
+
+    @torch.no_grad()
+    def _tokens(self, ids, mask):
+        h = self.backbone(input_ids=ids, attention_mask=mask).last_hidden_state
+        v = self.linear(h)
+        return torch.nn.functional.normalize(v.float(), p=2, dim=-1)
+
+    @torch.no_grad()
+    def encode_queries(self, queries: list[str], batch_size: int = 64) -> torch.Tensor:
+        """-> [Q, 64, 128] fp16; pads with the mask token and attends to it (run_colbert.sh:29)."""
+        out = torch.empty((len(queries), self.max_query_length, self.dim), dtype=torch.float16, device=self._device)
+        for idx, ids, mask in self._batches(queries, batch_size, self.max_query_length, pad_to_max=True):
+            ids = torch.where(mask.bool(), ids, torch.full_like(ids, self.tokenizer.mask_token_id))
+            v = self._tokens(ids, torch.ones_like(mask))
+            out[torch.tensor(idx, device=self._device)] = v.half()
+        return out
+
+    @torch.no_grad()
+    def encode_docs(self, docs: list[str], batch_size: int = 64):
+        """-> (Dtok [sumL,128] fp16 packed in corpus order, Doff [N+1] int64): padding and punctuation tokens dropped."""
+        per_doc: list[torch.Tensor | None] = [None] * len(docs)
+        for idx, ids, mask in self._batches(docs, batch_size, self.max_doc_length):
+            v = self._tokens(ids, mask).half()
+            keep = mask.bool()
+            if self.punct_ids.numel():
+                keep &= ~torch.isin(ids, self.punct_ids)
+            for r, i in enumerate(idx):
+                per_doc[i] = v[r][keep[r]]
+        lens = torch.tensor([t.shape[0] for t in per_doc], dtype=torch.int64)
+        off = torch.zeros(len(docs) + 1, dtype=torch.int64)
+        off[1:] = torch.cumsum(lens, 0)
+        tok = torch.cat(per_doc, 0) if per_doc else torch.empty((0, self.dim), dtype=torch.float16, device=self._device)
+        return tok.contiguous(), off.to(self._device)
+
+
+def random_init(kind: str, device="cuda", size: str = "base", seed: int = 0):
+    """CamemBERT-base-shaped (or tiny) encoder with random weights: `kind` in {'dpr','splade','colbert'}."""
+    cfg = dict(CAMEMBERT_BASE if size == "base" else TINY)
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        tok = HashTokenizer(cfg["vocab_size"], cfg["pad_token_id"], cfg["bos_token_id"], cfg["eos_token_id"])
+        if kind == "dpr":
+            return DenseEncoder(_backbone(cfg), tok, device)
+        if kind == "splade":
+            return SpladeEncoder(_backbone(cfg, mlm=True), tok, device)
+        if kind == "colbert":
+            return ColbertEncoder(_backbone(cfg), tok, device)
+        raise ValueError(kind)
+    finally:
+        torch.random.set_rng_state(g)
+
+
+def from_pretrained(model_name_or_path: str, kind: str, device="cuda"):
+    """Load a real checkpoint from a local directory / HF cache (no network on the build boxes)."""
+    from transformers import AutoModel, AutoModelForMaskedLM, AutoTokenizer
+    hf_tok = AutoTokenizer.from_pretrained(model_name_or_path, local_files_only=True)
+
+    class _Tok:
+        pad_token_id, mask_token_id = hf_tok.pad_token_id, hf_tok.mask_token_id
+
+        def __call__(self, texts, max_length, pad_to_max=False):
+            e = hf_tok(texts, padding="max_length" if pad_to_max else True, truncation=True, max_length=max_length, return_tensors="pt")
+            return e["input_ids"], e["attention_mask"]
+    if kind == "dpr":
+        return DenseEncoder(AutoModel.from_pretrained(model_name_or_path, local_files_only=True), _Tok(), device)
+    if kind == "splade":
+        return SpladeEncoder(AutoModelForMaskedLM.from_pretrained(model_name_or_path, local_files_only=True), _Tok(), device)
+    if kind == "colbert":
+        enc = ColbertEncoder(AutoModel.from_pretrained(model_name_or_path, local_files_only=True), _Tok(), device)
+        return enc
+    raise ValueError(kind)

@@ -1,0 +1,335 @@
+"""torch-tensor wrappers over the C ABI (include/fusion_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every op below passes
+raw device pointers + the stream to libfusion_hip.so.  No op has a PyTorch/CPU fallback: a CPU tensor
+raises, a missing library raises (see _lib.lib()).
+
+"Plane" = 2-D tensor [rows, n] with stride (ld, 1), ld >= n, ld a multiple of 64 elements so every row
+starts on a 256-byte boundary (16-byte vector loads).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import NORMS, RANK_METHODS, check
+
+_PAD = 64
+
+
+def round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def alloc_plane(rows: int, n: int, dtype, device, fill=None) -> torch.Tensor:
+    ld = max(round_up(n, _PAD), _PAD)
+    base = torch.empty((max(rows, 1), ld), dtype=dtype, device=device) if fill is None else \
+        torch.full((max(rows, 1), ld), fill, dtype=dtype, device=device)
+    return base[:rows, :n]
+
+
+def as_plane(t: torch.Tensor) -> torch.Tensor:
+    """Return t if rows are 16-byte aligned with unit inner stride, else copy it into a padded plane."""
+    assert t.dim() == 2
+    esz = t.element_size()
+    row_ok = t.shape[0] <= 1 or (t.stride(0) >= t.shape[1] and (t.stride(0) * esz) % 16 == 0)
+    if t.stride(1) == 1 and row_ok and t.data_ptr() % 16 == 0:
+        return t
+    p = alloc_plane(t.shape[0], t.shape[1], t.dtype, t.device)
+    p.copy_(t)
+    return p
+
+
+def _ld(t: torch.Tensor) -> int:
+    if t.shape[0] > 1:
+        return t.stride(0)
+    return max(t.stride(0), t.shape[1]) if t.dim() == 2 else t.shape[-1]
+
+
+def _dev(t: torch.Tensor, dtype=None, what="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{what}: expected a tensor on the GPU (fusion_amd has no CPU path), got {type(t).__name__}"
+                        f"{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)}")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{what}: expected dtype {dtype}, got {t.dtype}")
+    if t.dim() >= 1 and t.numel() > 0 and t.stride(-1) != 1:
+        raise ValueError(f"{what}: innermost dimension must be contiguous")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr_array(ts):
+    A = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        A[i] = None if t is None else t.data_ptr()
+    return A
+
+
+def _same_ld(*ts):
+    lds = {_ld(t) for t in ts if t is not None and t.shape[0] > 1}
+    if len(lds) > 1:
+        raise ValueError(f"planes passed to one call must share the row stride, got {sorted(lds)}")
+    return lds.pop() if lds else max(_ld(t) for t in ts if t is not None)
+
+
+# ---------------------------------------------------------------------------------------
+# K1 scoring
+# ---------------------------------------------------------------------------------------
+def pad_dim(X: torch.Tensor, mult: int = 4) -> torch.Tensor:
+    """Zero-pad the embedding dimension to a multiple of `mult` floats and 16-byte row alignment
+    (zeros change neither norms nor dot products)."""
+    d = X.shape[1]
+    dp = round_up(d, mult)
+    if dp == d and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and X.stride(1) == 1:
+        return X
+    Y = torch.zeros((X.shape[0], dp), dtype=X.dtype, device=X.device)
+    Y[:, :d] = X
+    return Y
+
+
+def normalize_rows(X: torch.Tensor) -> torch.Tensor:
+    """F.normalize(x, p=2, dim=-1) -- reference: util.cos_sim / splade/base.py:195-196."""
+    _dev(X, torch.float32, "normalize_rows(X)")
+    X = pad_dim(X)
+    Y = torch.empty_like(X, memory_format=torch.contiguous_format)
+    ldx = X.stride(0) if X.shape[0] > 1 else X.shape[1]
+    check(_lib.lib().fz_normalize_rows_f32(_ptr(X), X.shape[0], X.shape[1], ldx, _ptr(Y), Y.shape[1], _stream(X)), "fz_normalize_rows_f32")
+    return Y
+
+
+def dot_scores(Qn: torch.Tensor, Dn: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """scores = Qn @ Dn.T on fp32 MFMA -- reference: torch.mm (splade/base.py:197), util.dot_score."""
+    _dev(Qn, torch.float32, "dot_scores(Qn)")
+    _dev(Dn, torch.float32, "dot_scores(Dn)")
+    Qn, Dn = pad_dim(Qn), pad_dim(Dn)
+    if Qn.shape[1] != Dn.shape[1]:
+        raise ValueError(f"embedding dims differ: {Qn.shape[1]} vs {Dn.shape[1]}")
+    Q, N, d = Qn.shape[0], Dn.shape[0], Qn.shape[1]
+    if out is None:
+        out = alloc_plane(Q, N, torch.float32, Qn.device)
+    check(_lib.lib().fz_dot_scores_f32(_ptr(Qn), Qn.stride(0) if Q > 1 else d, _ptr(Dn), Dn.stride(0) if N > 1 else d, Q, N, d,
+                                       _ptr(out), _ld(out), _stream(Qn)), "fz_dot_scores_f32")
+    return out
+
+
+def cos_scores(Qe: torch.Tensor, De: torch.Tensor) -> torch.Tensor:
+    """util.cos_sim as called at hybrid.py:103."""
+    return dot_scores(normalize_rows(Qe), normalize_rows(De))
+
+
+# ---------------------------------------------------------------------------------------
+# K2 MaxSim
+# ---------------------------------------------------------------------------------------
+def maxsim(Qtok: torch.Tensor, Dtok: torch.Tensor, Doff: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Exact ColBERT late interaction. Qtok [Q,Lq,128] f16, Dtok [sumL,128] f16 packed, Doff [N+1] int64."""
+    _dev(Qtok, torch.float16, "maxsim(Qtok)")
+    _dev(Dtok, torch.float16, "maxsim(Dtok)")
+    _dev(Doff, torch.int64, "maxsim(Doff)")
+    Qtok, Dtok, Doff = Qtok.contiguous(), Dtok.contiguous(), Doff.contiguous()
+    Q, Lq, dim = Qtok.shape
+    N = Doff.numel() - 1
+    if out is None:
+        out = alloc_plane(Q, N, torch.float32, Qtok.device)
+    check(_lib.lib().fz_maxsim_f16(_ptr(Qtok), _ptr(Dtok), _ptr(Doff), int(Dtok.shape[0]), Q, Lq, N, dim, _ptr(out), _ld(out),
+                                   _stream(Qtok)), "fz_maxsim_f16")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# K5a / K6 sort
+# ---------------------------------------------------------------------------------------
+def sort_max_n(dtype=torch.float32) -> int:
+    return int(_lib.lib().fz_sort_max_n() if dtype == torch.float32 else _lib.lib().fz_sort_max_n_f64())
+
+
+def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, row_len: torch.Tensor | None = None,
+                   want_order=True, want_keys=True, want_rank=False):
+    """Stable descending row sort (Python sorted(reverse=True): bm25.py:104, hybrid.py:306).
+    Returns (order|None, sorted_keys|None, rank|None); order/sorted_keys entries beyond row_len are -1 / -inf,
+    rank entries of elements outside the sequence are -1."""
+    _dev(keys, None, "sort_rows_desc(keys)")
+    if keys.dtype not in (torch.float32, torch.float64):
+        raise TypeError("keys must be float32 or float64")
+    keys = as_plane(keys)
+    rows, n = keys.shape
+    ld = _ld(keys)
+    dev = keys.device
+
+    partial = row_len is not None or init_order is not None  # some slots may stay unwritten: pre-fill them
+
+    def mk(dtype, fill):
+        shape = (max(rows, 1), ld)
+        base = torch.full(shape, fill, dtype=dtype, device=dev) if partial else torch.empty(shape, dtype=dtype, device=dev)
+        return base[:rows, :n]
+    order = mk(torch.int32, -1) if want_order else None
+    sk = mk(keys.dtype, float("-inf")) if want_keys else None
+    rank = mk(torch.int32, -1) if want_rank else None
+    if init_order is not None:
+        _dev(init_order, torch.int32, "init_order")
+        if _ld(init_order) != ld and rows > 1:
+            t = mk(torch.int32, -1)
+            t.copy_(init_order)
+            init_order = t
+    if row_len is not None:
+        _dev(row_len, torch.int32, "row_len")
+        row_len = row_len.contiguous()
+    check(_lib.lib().fz_sort_rows_desc(_ptr(keys), 32 if keys.dtype == torch.float32 else 64, _ptr(init_order), _ptr(row_len),
+                                       rows, n, ld, _ptr(order), _ptr(sk), _ptr(rank), _stream(keys)), "fz_sort_rows_desc")
+    return order, sk, rank
+
+
+# ---------------------------------------------------------------------------------------
+# fusion
+# ---------------------------------------------------------------------------------------
+def fuse_rank(ranks: list[torch.Tensor], lens: torch.Tensor, method: str) -> torch.Tensor:
+    """rrf / bcf in float64 (hybrid.py:248-252,301-304). ranks[s] [Q,N] int32 planes, lens [S,Q] int32."""
+    for r in ranks:
+        _dev(r, torch.int32, "fuse_rank(ranks)")
+    _dev(lens, torch.int32, "fuse_rank(lens)")
+    lens = lens.contiguous()
+    Q, N = ranks[0].shape
+    ld = _same_ld(*ranks)
+    fused = torch.empty((max(Q, 1), ld), dtype=torch.float64, device=ranks[0].device)[:Q, :N]
+    check(_lib.lib().fz_fuse_rank_f64(_ptr_array(ranks), _ptr(lens), len(ranks), Q, N, ld, RANK_METHODS[method], _ptr(fused),
+                                      _stream(ranks[0])), "fz_fuse_rank_f64")
+    return fused
+
+
+def row_stats(scores: torch.Tensor, rank: torch.Tensor | None, norm: str):
+    _dev(scores, torch.float32, "row_stats(scores)")
+    rows, N = scores.shape
+    a = torch.empty(rows, dtype=torch.float32, device=scores.device)
+    b = torch.empty(rows, dtype=torch.float32, device=scores.device)
+    if rank is not None:
+        _dev(rank, torch.int32, "row_stats(rank)")
+        _same_ld(scores, rank)
+    check(_lib.lib().fz_row_stats_f32(_ptr(scores), _ptr(rank), rows, N, _ld(scores), NORMS[norm], _ptr(a), _ptr(b), _stream(scores)),
+          "fz_row_stats_f32")
+    return a, b
+
+
+def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None, weights, norm: str,
+             distr: list[torch.Tensor] | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """normalise -> weight -> sum in one HBM pass (hybrid.py:212-214,254-280,291,301-304)."""
+    for p in planes:
+        _dev(p, torch.float32, "fuse_nsf(planes)")
+    S = len(planes)
+    Q, N = planes[0].shape
+    ld = _same_ld(*planes, *([r for r in ranks if r is not None] if ranks else []))
+    dev = planes[0].device
+    fused = out if out is not None else torch.empty((max(Q, 1), ld), dtype=torch.float32, device=dev)[:Q, :N]
+    w = (C.c_double * S)(*[float(x) for x in weights])
+    dptr, P = None, None
+    if norm in ("percentile-rank", "normal-curve-equivalent"):
+        if distr is None or any(d is None for d in distr):
+            raise AttributeError("percentile distributions are required for percentile-rank / normal-curve-equivalent")
+        distr = [_dev(d, torch.float32, "distr").contiguous() for d in distr]
+        dptr = _ptr_array(distr)
+        P = (C.c_int32 * S)(*[int(d.numel()) for d in distr])
+    lib = _lib.lib()
+    rc = lib.fz_fuse_nsf_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm], dptr, P,
+                             _ptr(fused), _stream(planes[0]))
+    if rc == _lib.FZ_ERR_UNSUPPORTED:
+        # rows longer than the register-resident kernel holds (N > 32768): statistics pass + elementwise pass
+        sa = torch.zeros(S * Q, dtype=torch.float32, device=dev)
+        sb = torch.zeros(S * Q, dtype=torch.float32, device=dev)
+        if norm in ("min-max", "z-score"):
+            for s in range(S):
+                a, b = row_stats(planes[s], None if ranks is None else ranks[s], norm)
+                sa[s * Q:(s + 1) * Q] = a
+                sb[s * Q:(s + 1) * Q] = b
+        rc = lib.fz_fuse_nsf_stats_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm],
+                                       dptr, P, _ptr(sa), _ptr(sb), _ptr(fused), _stream(planes[0]))
+    check(rc, "fz_fuse_nsf_f32")
+    return fused
+
+
+def fuse_none(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None, weights) -> torch.Tensor:
+    """'none' / unknown normalisation: float64 passthrough (hybrid.py:280,291,304)."""
+    for p in planes:
+        _dev(p, torch.float32, "fuse_none(planes)")
+    S = len(planes)
+    Q, N = planes[0].shape
+    ld = _same_ld(*planes, *([r for r in ranks if r is not None] if ranks else []))
+    fused = torch.empty((max(Q, 1), ld), dtype=torch.float64, device=planes[0].device)[:Q, :N]
+    w = (C.c_double * S)(*[float(x) for x in weights])
+    check(_lib.lib().fz_fuse_none_f64(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, _ptr(fused),
+                                      _stream(planes[0])), "fz_fuse_none_f64")
+    return fused
+
+
+def insertion_order(orders: list[torch.Tensor], lens: torch.Tensor, N: int):
+    """First-insertion order of the fused dict (hybrid.py:301-304). Returns (ins_order [Q,N] int32, U [Q] int32)."""
+    for o in orders:
+        _dev(o, torch.int32, "insertion_order(orders)")
+    _dev(lens, torch.int32, "insertion_order(lens)")
+    lens = lens.contiguous()
+    Q = orders[0].shape[0]
+    ld = _same_ld(*orders)
+    dev = orders[0].device
+    ins = torch.full((max(Q, 1), ld), -1, dtype=torch.int32, device=dev)[:Q, :N]
+    U = torch.zeros(Q, dtype=torch.int32, device=dev)
+    check(_lib.lib().fz_insertion_order(_ptr_array(orders), _ptr(lens), len(orders), Q, N, ld, _ptr(ins), _ptr(U), None, 0,
+                                        _stream(orders[0])), "fz_insertion_order")
+    return ins, U
+
+
+# ---------------------------------------------------------------------------------------
+# top-k
+# ---------------------------------------------------------------------------------------
+def topk_rows(scores: torch.Tensor, k: int, id_base: int = 0):
+    """k best per row by (score desc, id asc) -> (scores [rows,k] f32, ids [rows,k] int64)."""
+    _dev(scores, torch.float32, "topk_rows(scores)")
+    rows, n = scores.shape
+    dev = scores.device
+    os_ = torch.empty((rows, k), dtype=torch.float32, device=dev)
+    oi = torch.empty((rows, k), dtype=torch.int64, device=dev)
+    lib = _lib.lib()
+    wsb = int(lib.fz_topk_workspace_bytes(rows, n, k))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    check(lib.fz_topk_rows_f32(_ptr(scores), rows, n, _ld(scores), k, int(id_base), _ptr(os_), _ptr(oi), _ptr(ws), wsb, _stream(scores)),
+          "fz_topk_rows_f32")
+    return os_, oi
+
+
+def topk_merge(in_scores: torch.Tensor, in_ids: torch.Tensor):
+    """[G,rows,k] per-shard lists -> global top-k [rows,k] (after the RCCL all-gather)."""
+    _dev(in_scores, torch.float32, "topk_merge(in_scores)")
+    _dev(in_ids, torch.int64, "topk_merge(in_ids)")
+    in_scores, in_ids = in_scores.contiguous(), in_ids.contiguous()
+    G, rows, k = in_scores.shape
+    os_ = torch.empty((rows, k), dtype=torch.float32, device=in_scores.device)
+    oi = torch.empty((rows, k), dtype=torch.int64, device=in_scores.device)
+    check(_lib.lib().fz_topk_merge(_ptr(in_scores), _ptr(in_ids), G, rows, k, _ptr(os_), _ptr(oi), _stream(in_scores)), "fz_topk_merge")
+    return os_, oi
+
+
+# ---------------------------------------------------------------------------------------
+# BM25
+# ---------------------------------------------------------------------------------------
+def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float, qoff, qterms, Q: int, N: int) -> torch.Tensor:
+    dev = idf.device
+    out = torch.empty((max(Q, 1), max(round_up(N, _PAD), _PAD)), dtype=torch.float64, device=dev)[:Q, :N]
+    check(_lib.lib().fz_bm25_scores_f64(_ptr(toff), _ptr(pdoc), _ptr(ptf), _ptr(idf), _ptr(doc_len), float(avgdl), float(k1), float(b),
+                                        _ptr(qoff), _ptr(qterms), Q, N, _ptr(out), _ld(out), _stream(idf)), "fz_bm25_scores_f64")
+    return out
+
+
+def f64_to_f32(src: torch.Tensor) -> torch.Tensor:
+    """Plane-preserving fp64 -> fp32 (what torch.tensor(..., dtype=float32) does to BM25's Python floats, hybrid.py:255)."""
+    _dev(src, torch.float64, "f64_to_f32")
+    rows, n = src.shape
+    ld = _ld(src)
+    dst = torch.empty((max(rows, 1), ld), dtype=torch.float32, device=src.device)
+    # convert the whole padded buffer when it is one allocation; otherwise row views
+    check(_lib.lib().fz_f64_to_f32(_ptr(src), _ptr(dst), rows * ld - (ld - n) if rows > 0 else 0, _stream(src)), "fz_f64_to_f32")
+    return dst[:rows, :n]

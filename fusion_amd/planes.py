@@ -1,0 +1,77 @@
+"""Device-resident ranked lists.
+
+The reference passes `list[Q] of list[<=N] of {'corpus_id', 'score'}` between Ranker and Aggregator
+(hybrid.py:66-75,93-106,137,170-179).  On the GPU the same information is one `RankedSystem` per
+retrieval system: dense planes indexed by corpus POSITION (column j = j-th entry of the corpus dict),
+which is what the fusion kernels read with coalesced 16-byte accesses.  The list-of-dicts form is
+rebuilt only when a caller asks for it (`to_lists`).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+
+@dataclass
+class RankedSystem:
+    scores: torch.Tensor          # [Q, N] float32 plane: score of doc j for query q (undefined where rank < 0)
+    order: torch.Tensor           # [Q, N] int32 plane: order[q, r] = corpus position at rank r (r < lens[q]), else -1
+    rank: torch.Tensor            # [Q, N] int32 plane: rank[q, j] = list position of doc j, -1 if absent
+    lens: torch.Tensor            # [Q] int32: list length per query
+    ids: np.ndarray               # [N] corpus position -> corpus_id (hybrid.py:66 idx2id)
+    sorted_scores: torch.Tensor | None = None   # [Q, N] scores in rank order (same dtype as the ranking keys)
+    full: bool = True             # every list covers all N docs (lens == N)
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def Q(self) -> int:
+        return self.scores.shape[0]
+
+    @property
+    def N(self) -> int:
+        return self.scores.shape[1]
+
+    def to_lists(self, topk: int | None = None) -> list[list[dict]]:
+        """-> the reference's RankedLists (hybrid.py:75,106,137)."""
+        order = self.order.cpu().numpy()
+        lens = self.lens.cpu().numpy()
+        if self.sorted_scores is not None:
+            ss = self.sorted_scores.cpu().numpy()
+        else:
+            sc = self.scores.cpu().numpy()
+            ss = np.take_along_axis(sc, np.maximum(order, 0).astype(np.int64), axis=1)
+        out = []
+        for q in range(self.Q):
+            n = int(lens[q]) if topk is None else min(int(lens[q]), topk)
+            cid = self.ids[order[q, :n]]
+            out.append([{"corpus_id": c.item() if hasattr(c, "item") else c, "score": float(s)} for c, s in zip(cid, ss[q, :n])])
+        return out
+
+
+@dataclass
+class FusedResult:
+    """Output of Aggregator.fuse on the device: fused lists over the union of ids per query."""
+    order: torch.Tensor           # [Q, N] int32: corpus position at fused rank r (r < lens[q])
+    scores: torch.Tensor          # [Q, N] fused score at fused rank r (float64 for rrf/bcf/none, float32 otherwise)
+    lens: torch.Tensor            # [Q] int32 = |union of ids|
+    ids: np.ndarray
+
+    def to_lists(self) -> list[list[dict]]:
+        order = self.order.cpu().numpy()
+        sc = self.scores.cpu().numpy()
+        lens = self.lens.cpu().numpy()
+        f32 = sc.dtype == np.float32
+        out = []
+        for q in range(order.shape[0]):
+            n = int(lens[q])
+            cid = self.ids[order[q, :n]]
+            out.append([{"corpus_id": c.item() if hasattr(c, "item") else c, "score": (np.float32(s) if f32 else float(s))}
+                        for c, s in zip(cid, sc[q, :n])])
+        return out
+
+    def predictions(self, topk: int | None = None) -> list[list]:
+        order = self.order.cpu().numpy()
+        lens = self.lens.cpu().numpy()
+        return [self.ids[order[q, :(int(lens[q]) if topk is None else min(int(lens[q]), topk))]].tolist() for q in range(order.shape[0])]

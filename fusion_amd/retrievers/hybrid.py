@@ -1,0 +1,420 @@
+"""MI355X-native drop-in for the reference's `src/retrievers/hybrid.py` (488 lines): same class names,
+method signatures, CLI flags, result types and error behaviour; the arithmetic runs in the HIP kernels of
+fusion_amd/csrc behind include/fusion_hip.h.
+
+Reference map (file:line in the reference tree)
+  run_evaluation            hybrid.py:24-42
+  Ranker.*_search           hybrid.py:49-75, 77-106, 108-137, 139-163
+  Aggregator.fuse           hybrid.py:170-220 (+ convert2dict :222-233, transform_scores :235-280,
+                            weight_scores :282-291, aggregate_scores :293-307)
+  main / argparse           hybrid.py:310-468, 471-488
+
+Interchange type: the reference's RankedLists (list[Q] of list[<=N] of {'corpus_id','score'}) is accepted and
+returned everywhere the reference does; additionally every Ranker method takes `as_device=True` to hand over
+device-resident `RankedSystem` planes, which `Aggregator.fuse` consumes without a host round trip.
+
+Documented deviations: D1 own SPLADE wrapper; D2 working cross-encoder rerank; D4 the weights
+check really checks (KeyError); ties inside a system are broken by ascending corpus position; percentile tables
+must be ascending (they are quantiles, hybrid.py:391-397).
+"""
+from __future__ import annotations
+
+import argparse
+import itertools
+import os
+import sys
+from os.path import join
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..planes import FusedResult, RankedSystem
+
+RankedLists = list  # list[list[dict]]
+
+
+def run_evaluation(predictions: list[list[int]], labels: list[list[int]], print2console: bool = True, log2wandb: bool = False,
+                   args: argparse.Namespace = None):
+    """hybrid.py:24-42 (wandb logging is out of scope: observability to an external SaaS)."""
+    from ..utils.metrics import Metrics
+    evaluator = Metrics(recall_at_k=[5, 10, 20, 50, 100, 200, 500, 1000], map_at_k=[10, 100], mrr_at_k=[10, 100], ndcg_at_k=[10, 100])
+    scores = evaluator.compute_all_metrics(all_ground_truths=labels, all_results=predictions)
+    if print2console:
+        for metric, score in scores.items():
+            print(f"- {metric.capitalize()}: {score:.3f}")
+    return scores
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("fusion_amd needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _rank_scores(scores: torch.Tensor, ids: np.ndarray, return_topk: int | None) -> RankedSystem:
+    """Full ranking of a [Q, N] score plane: what util.semantic_search(top_k=N) + sorted() produce (hybrid.py:103)."""
+    order, sk, rank = ops.sort_rows_desc(scores, want_rank=True)
+    Q, N = scores.shape
+    k = N if return_topk is None else min(return_topk, N)
+    lens = torch.full((Q,), k, dtype=torch.int32, device=scores.device)
+    full = k == N
+    if not full:  # lists truncated to top-k: docs beyond rank k are absent from the list
+        rank = torch.where(rank < k, rank, torch.full_like(rank, -1))
+        order = order.clone()
+        order[:, k:] = -1
+    return RankedSystem(scores=scores, order=order, rank=rank, lens=lens, ids=ids, sorted_scores=sk, full=full)
+
+
+class Ranker:
+    """Produce per-system ranked lists (hybrid.py:45-163)."""
+
+    @staticmethod
+    def bm25_search(queries: list[str], corpus: dict[int, str], do_preprocessing: bool, k1: float, b: float, return_topk: int = None,
+                    *, as_device: bool = False):
+        """hybrid.py:49-75. `do_preprocessing=True` needs the spaCy lemmatiser (src/data/preprocessor.py), a third-party
+        NLP model outside the hot path: pass pre-tokenised whitespace text instead."""
+        from .bm25 import BM25
+        if do_preprocessing:
+            raise NotImplementedError("spaCy preprocessing (fr_core_news_md) is out of scope: pass lemmatised text, do_preprocessing=False")
+        documents = list(corpus.values())
+        ids = np.array(list(corpus.keys()))
+        retriever = BM25(corpus=documents, k1=k1, b=b, device=_device())
+        rs = retriever.search_device(queries, ids=ids)
+        if return_topk is not None and return_topk < rs.N:
+            k = return_topk
+            rs.rank = torch.where(rs.rank < k, rs.rank, torch.full_like(rs.rank, -1))
+            rs.order = rs.order.clone(); rs.order[:, k:] = -1
+            rs.lens = torch.full_like(rs.lens, k); rs.full = False
+        return rs if as_device else rs.to_lists()
+
+    @staticmethod
+    def single_vector_search(queries: list[str], corpus: dict[int, str], model_name_or_path: str, return_topk: int = None,
+                             *, encoder=None, as_device: bool = False):
+        """hybrid.py:77-106: encode docs + queries (batch 64), cosine similarity, full ranking.
+        `encoder` (optional) injects an already-built fusion_amd.encoders module (e.g. random_init for synthetic runs)."""
+        from .. import encoders
+        documents = list(corpus.values())
+        ids = np.array(list(corpus.keys()))
+        kind = "splade" if "splade" in model_name_or_path.lower() else "dpr"
+        model = encoder if encoder is not None else encoders.from_pretrained(model_name_or_path, kind, device=_device())
+        d_embs = model.encode(documents, batch_size=64, query_mode=False)
+        q_embs = model.encode(queries, batch_size=64, query_mode=True)
+        scores = ops.cos_scores(q_embs, d_embs)   # hybrid.py:103 always uses cos_sim
+        rs = _rank_scores(scores, ids, return_topk)
+        del d_embs, q_embs
+        if encoder is None:
+            del model
+            torch.cuda.empty_cache()
+        return rs if as_device else rs.to_lists()
+
+    @staticmethod
+    def multi_vector_search(queries: list[str], corpus: dict[int, str], model_name_or_path: str, output_dir: str = "output",
+                            return_topk: int = None, *, encoder=None, as_device: bool = False):
+        """hybrid.py:108-137.  The reference goes through colbert-ai's PLAID index (approximate, candidate-pruned);
+        here every (query, document) pair gets its exact MaxSim score on the device, a superset ranking of PLAID's."""
+        from .. import encoders
+        documents = list(corpus.values())
+        ids = np.array(list(corpus.keys()))
+        model = encoder if encoder is not None else encoders.from_pretrained(model_name_or_path, "colbert", device=_device())
+        Dtok, Doff = model.encode_docs(documents, batch_size=64)
+        Qtok = model.encode_queries(queries, batch_size=64)
+        scores = ops.maxsim(Qtok, Dtok, Doff)
+        rs = _rank_scores(scores, ids, return_topk)
+        del Dtok, Qtok
+        if encoder is None:
+            del model
+            torch.cuda.empty_cache()
+        return rs if as_device else rs.to_lists()
+
+    @staticmethod
+    def cross_encoder_search(queries: list[str], candidates: list, model_name_or_path: str, return_topk: int = None, *, model=None):
+        """hybrid.py:139-163 is dead code in the reference (`docs` undefined, candidates type mismatch).
+        Working form: `candidates[i]` is a dict id->text (or a fused list of {'corpus_id'} plus `corpus` in `model.corpus`);
+        `model.predict(list[(query, doc)]) -> scores` is any PyTorch-ROCm cross-encoder."""
+        if model is None:
+            raise NotImplementedError("no cross-encoder checkpoint available offline: pass model=<object with predict()>")
+        ranked_lists = []
+        for query, cands in zip(queries, candidates):
+            cids = list(cands.keys())
+            docs = list(cands.values())
+            scores = model.predict([(query, d) for d in docs])
+            order = sorted(range(len(docs)), key=lambda i: -float(scores[i]))[: return_topk or len(docs)]
+            ranked_lists.append([{"corpus_id": cids[i], "score": float(scores[i])} for i in order])
+        return ranked_lists
+
+
+class Aggregator:
+    """Normalise + fuse ranked lists (hybrid.py:166-307)."""
+
+    @classmethod
+    def fuse(cls, ranked_lists: dict, method: str, normalization: str = None, linear_weights: dict[str, float] = None,
+             percentile_distributions: dict[str, np.ndarray] = None, return_topk: int = 1000, *, as_device: bool = False):
+        """hybrid.py:170-220.  `ranked_lists`: system -> RankedLists (reference format) or system -> RankedSystem (device)."""
+        fused = cls.fuse_device(cls._to_device(ranked_lists), method, normalization, linear_weights, percentile_distributions)
+        if as_device:
+            return fused
+        return fused.to_lists()[:return_topk]   # slices QUERIES, as hybrid.py:220 does
+
+    # -- device pipeline -----------------------------------------------------------------
+    @classmethod
+    def fuse_device(cls, systems: dict[str, RankedSystem], method: str, normalization: str = None,
+                    linear_weights: dict[str, float] = None, percentile_distributions: dict[str, np.ndarray] = None) -> FusedResult:
+        names = list(systems.keys())
+        S = [systems[n] for n in names]
+        Q = S[0].Q
+        assert all(s.Q == Q for s in S), (
+            "Ranked results from different retrieval systems have varying lenghts across systems (i.e., some systems have been run on more queries).")
+        N = S[0].N
+        if any(s.N != N for s in S):
+            raise ValueError("device systems must be planes over the same corpus")
+        dev = S[0].scores.device
+        all_full = all(s.full for s in S)
+        ranks = None if all_full else [s.rank for s in S]
+
+        if method in ("bcf", "rrf"):
+            lens = torch.stack([s.lens for s in S]).contiguous()
+            fused = ops.fuse_rank([s.rank for s in S], lens, method)
+        elif method == "nsf":
+            w = [linear_weights[n] for n in names]          # KeyError when a system has no weight (hybrid.py:214)
+            if normalization in ("percentile-rank", "normal-curve-equivalent"):
+                distr = [cls._table(percentile_distributions.get(n), dev) for n in names]   # AttributeError on None (hybrid.py:213)
+                fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, distr)
+            elif normalization in ("min-max", "z-score", "arctan"):
+                percentile_distributions.get                # same AttributeError as hybrid.py:213 when None is passed
+                fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization)
+            else:                                           # 'none' / unknown string: passthrough (hybrid.py:280)
+                percentile_distributions.get
+                fused = ops.fuse_none([s.scores for s in S], ranks, w)
+        else:                                               # unknown method: raw scores are summed (hybrid.py:203-218)
+            fused = ops.fuse_none([s.scores for s in S], ranks, [1.0] * len(S))
+
+        if all_full:
+            ins, U = S[0].order, None                        # first-insertion order == system 0's ranking
+            lens_out = torch.full((Q,), N, dtype=torch.int32, device=dev)
+        else:
+            lens = torch.stack([s.lens for s in S]).contiguous()
+            ins, U = ops.insertion_order([s.order for s in S], lens, N)
+            lens_out = U
+        order, sk, _ = ops.sort_rows_desc(fused, init_order=ins, row_len=U)
+        return FusedResult(order=order, scores=sk, lens=lens_out, ids=S[0].ids)
+
+    @staticmethod
+    def _table(distr, dev) -> torch.Tensor:
+        t = np.asarray(distr, dtype=np.float64).astype(np.float32)   # torch.tensor(distr, dtype=float32), hybrid.py:272
+        if t.ndim != 1 or t.size == 0:
+            raise ValueError("percentile distribution must be a non-empty 1-D table")
+        if np.any(np.diff(t) < 0):
+            raise ValueError("percentile distribution must be ascending (it is a quantile table, hybrid.py:391-397)")
+        return torch.from_numpy(t).to(dev)
+
+    @staticmethod
+    def _to_device(ranked_lists: dict) -> dict[str, RankedSystem]:
+        first = next(iter(ranked_lists.values()))
+        if isinstance(first, RankedSystem):
+            return ranked_lists
+        dev = _device()
+        names = list(ranked_lists.keys())
+        Q = len(first)
+        assert all(len(v) == Q for v in ranked_lists.values()), (
+            "Ranked results from different retrieval systems have varying lenghts across systems (i.e., some systems have been run on more queries).")
+        # corpus position = first-seen order of the ids (any bijection works: ties are broken by list order, not position)
+        pos: dict = {}
+        for n in names:
+            for lst in ranked_lists[n]:
+                for x in lst:
+                    if x["corpus_id"] not in pos:
+                        pos[x["corpus_id"]] = len(pos)
+        N = max(len(pos), 1)
+        ids = np.empty(N, dtype=object)
+        for k, v in pos.items():
+            ids[v] = k
+        try:
+            ids = ids.astype(np.int64)
+        except (TypeError, ValueError):
+            pass
+        ld = ops.round_up(N, 64)
+        out = {}
+        for n in names:
+            sc = np.zeros((Q, ld), dtype=np.float32)
+            rk = np.full((Q, ld), -1, dtype=np.int32)
+            od = np.full((Q, ld), -1, dtype=np.int32)
+            ln = np.zeros(Q, dtype=np.int32)
+            for q, lst in enumerate(ranked_lists[n]):
+                d = {}
+                for x in lst:            # convert2dict (hybrid.py:231): first position kept, last score wins
+                    d[x["corpus_id"]] = x["score"]
+                if d:
+                    j = np.fromiter((pos[c] for c in d.keys()), dtype=np.int64, count=len(d))
+                    sc[q, j] = np.fromiter(d.values(), dtype=np.float64, count=len(d)).astype(np.float32)
+                    rk[q, j] = np.arange(len(d), dtype=np.int32)
+                    od[q, : len(d)] = j
+                ln[q] = len(d)
+            t = lambda a: torch.from_numpy(a).to(dev)[:, :N]
+            out[n] = RankedSystem(scores=t(sc), order=t(od), rank=t(rk), lens=torch.from_numpy(ln).to(dev), ids=ids,
+                                  full=bool((ln == N).all()))
+        return out
+
+    # -- the reference's small helpers, kept for API compatibility ---------------------------
+    @staticmethod
+    def convert2dict(results: list[dict]) -> dict:
+        """hybrid.py:222-233."""
+        return {res["corpus_id"]: res["score"] for res in results}
+
+    @staticmethod
+    def transform_scores(results: dict, transformation: str, percentile_distr: np.ndarray = None) -> dict:
+        """hybrid.py:235-280 for one list; the statistics and the transform run in the fusion kernel (weight 1)."""
+        n = len(results)
+        if transformation == "borda-count":
+            return {pid: (n - idx + 1) / n for idx, pid in enumerate(results.keys())}
+        if transformation == "reciprocal-rank":
+            return {pid: 1 / (60 + idx + 1) for idx, pid in enumerate(results.keys())}
+        if transformation not in ("min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent"):
+            return results
+        dev = _device()
+        plane = ops.alloc_plane(1, n, torch.float32, dev)
+        plane.copy_(torch.tensor(list(results.values()), dtype=torch.float64).to(torch.float32).unsqueeze(0))
+        distr = None
+        if transformation in ("percentile-rank", "normal-curve-equivalent"):
+            distr = [Aggregator._table(percentile_distr, dev)]
+        out = ops.fuse_nsf([plane], None, [1.0], transformation, distr).cpu().numpy()[0]
+        return {pid: s for pid, s in zip(results.keys(), out)}
+
+    @staticmethod
+    def weight_scores(results: dict, w: float) -> dict:
+        """hybrid.py:282-291."""
+        return {cid: s * w for cid, s in results.items()}
+
+    @staticmethod
+    def aggregate_scores(*args: dict) -> list[dict]:
+        """hybrid.py:293-307 for already-transformed dicts (host; the device path is fuse())."""
+        agg: dict = {}
+        for res in args:
+            for pid, s in res.items():
+                agg[pid] = agg.get(pid, 0.0) + s
+        return [{"corpus_id": p, "score": s} for p, s in sorted(agg.items(), key=lambda kv: kv[1], reverse=True)]
+
+
+# ---------------------------------------------------------------------------------------------------
+# driver (hybrid.py:310-468) -- same flags; data comes from local files because there is no network
+# ---------------------------------------------------------------------------------------------------
+MODEL_CKPTS = {
+    "dpr": {"general": "antoinelouis/biencoder-camembert-base-mmarcoFR", "legal": "maastrichtlawtech/dpr-legal-french"},
+    "splade": {"general": "antoinelouis/spladev2-camembert-base-mmarcoFR", "legal": "maastrichtlawtech/splade-legal-french"},
+    "colbert": {"general": "antoinelouis/colbertv1-camembert-base-mmarcoFR", "legal": "maastrichtlawtech/colbert-legal-french"},
+    "monobert": {"general": "antoinelouis/crossencoder-camembert-base-mmarcoFR", "legal": "maastrichtlawtech/monobert-legal-french"},
+}
+
+
+def weight_grid(system_names: list[str], step: float = 0.05) -> list[dict[str, float]]:
+    """hybrid.py:405-409: every weight vector on the `step` lattice that sums to 1 (np.isclose)."""
+    grid = np.arange(0, 1 + step, step)
+    return [dict(zip(system_names, comb)) for comb in itertools.product(grid, repeat=len(system_names)) if np.isclose(sum(comb), 1.0)]
+
+
+def load_data(args):
+    """LLeQA corpus / questions.  The reference pulls maastrichtlawtech/lleqa from the HF hub (hybrid.py:336-339);
+    offline, `--synthetic N,Q` generates an LLeQA-shaped corpus, `--data_dir` reads corpus.jsonl / questions_{split}.jsonl."""
+    import json
+    if getattr(args, "synthetic", None):
+        n, q = (int(x) for x in args.synthetic.split(","))
+        rng = np.random.default_rng(0)
+        vocab = np.array([f"mot{i}" for i in range(5000)])
+        p = 1.0 / np.arange(1, 5001); p /= p.sum()
+        corpus = {int(i + 1): " ".join(rng.choice(vocab, size=int(rng.integers(20, 200)), p=p)) for i in range(n)}
+        queries = [" ".join(rng.choice(vocab, size=int(rng.integers(4, 16)), p=p)) for _ in range(q)]
+        pos = [sorted(rng.choice(np.arange(1, n + 1), size=int(rng.integers(1, 5)), replace=False).tolist()) for _ in range(q)]
+        return corpus, queries, pos
+    d = args.data_dir
+    if not d or not os.path.isdir(d):
+        raise FileNotFoundError("no network: pass --data_dir with corpus.jsonl + questions_<split>.jsonl, or --synthetic N,Q")
+    corpus = {}
+    with open(join(d, "corpus.jsonl")) as f:
+        for line in f:
+            r = json.loads(line); corpus[r["id"]] = r["article"]
+    split = "validation" if args.data_split == "dev" else args.data_split
+    queries, pos = [], []
+    with open(join(d, f"questions_{split}.jsonl")) as f:
+        for line in f:
+            r = json.loads(line); queries.append(r["question"]); pos.append(r["article_ids"])
+    return corpus, queries, pos
+
+
+def main(args):
+    import pandas as pd
+    from .. import encoders
+    sep = f"#{'-' * 40}#"
+    os.makedirs(args.output_dir, exist_ok=True)
+    args.eval_type = ("in" if args.models_domain == "legal" else "out") + "domain"
+    print("Loading corpus and queries...")
+    corpus, queries, pos_pids = load_data(args)
+    results: dict[str, RankedSystem] = {}
+    synth = bool(getattr(args, "synthetic", None))
+
+    def enc(kind):
+        if synth:   # random-init CamemBERT-shaped encoder (no checkpoints offline)
+            return encoders.random_init(kind, device=_device(), size=getattr(args, "synthetic_model", "tiny"))
+        return None
+    if args.run_bm25:
+        print(f"{sep}\n# Ranking with BM25\n{sep}")
+        results["bm25"] = Ranker.bm25_search(queries, corpus, do_preprocessing=False, k1=2.5, b=0.2, as_device=True)
+    if args.run_dpr:
+        print(f"{sep}\n# Ranking with DPR\n{sep}")
+        results["dpr"] = Ranker.single_vector_search(queries, corpus, MODEL_CKPTS["dpr"][args.models_domain], encoder=enc("dpr"), as_device=True)
+    if args.run_splade:
+        print(f"{sep}\n# Ranking with SPLADE\n{sep}")
+        results["splade"] = Ranker.single_vector_search(queries, corpus, MODEL_CKPTS["splade"][args.models_domain], encoder=enc("splade"), as_device=True)
+    if args.run_colbert:
+        print(f"{sep}\n# Ranking with ColBERT\n{sep}")
+        results["colbert"] = Ranker.multi_vector_search(queries, corpus, MODEL_CKPTS["colbert"][args.models_domain], encoder=enc("colbert"), as_device=True)
+
+    def distributions():
+        if args.normalization in ("percentile-rank", "normal-curve-equivalent"):
+            df = pd.read_csv(join(args.output_dir, f"score_distributions_raw_{args.eval_type}_28k.csv"))
+            return {k: np.array(v) for k, v in df.to_dict("series").items()}
+        return {}
+
+    if args.fusion == "nsf" and args.tune_linear_fusion_weight:
+        combos = weight_grid(list(results.keys()))
+        distr = distributions()
+        print(f"{sep}\n# Tuning the weights of convex combination between systems: {len(combos)} permutations\n{sep}")
+        rows = []
+        for weights in combos:
+            fused = Aggregator.fuse(results, method=args.fusion, normalization=args.normalization, percentile_distributions=distr,
+                                    linear_weights=weights, as_device=True)
+            perf = run_evaluation(predictions=fused.predictions(1000), labels=pos_pids, print2console=False)
+            rows.append({**perf, **{f"weight_{k}": v for k, v in weights.items()}})
+            pd.DataFrame(rows).to_csv(join(args.output_dir, f"nsf_{args.normalization}_{args.eval_type}.csv"), index=False)
+        print("Done.")
+        return
+
+    weights = {s: 1 / len(results) for s in results} if args.fusion == "nsf" else {}
+    distr = distributions() if args.fusion == "nsf" else {}
+    print(f"{sep}\n# Fusing results with {args.fusion.upper()}{' (' + args.normalization + ')' if args.fusion == 'nsf' else ''}\n{sep}")
+    fused = Aggregator.fuse(results, method=args.fusion, normalization=args.normalization, percentile_distributions=distr,
+                            linear_weights=weights, as_device=True)
+    print(f"{sep}\n# Evaluation \n{sep}")
+    return run_evaluation(predictions=fused.predictions(1000), labels=pos_pids, args=args)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--data_split", type=str, choices=["dev", "test", "train"])
+    parser.add_argument("--models_domain", type=str, choices=["general", "legal"])
+    for name in ("bm25", "dpr", "splade", "colbert", "monobert"):
+        parser.add_argument(f"--run_{name}", action="store_true", default=False)
+    parser.add_argument("--fusion", type=str, choices=["bcf", "rrf", "nsf"])
+    parser.add_argument("--normalization", type=str, choices=["none", "min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent"])
+    parser.add_argument("--tune_linear_fusion_weight", action="store_true", default=False)
+    parser.add_argument("--analyze_score_distributions", action="store_true", default=False)
+    parser.add_argument("--output_dir", type=str)
+    # offline additions (no HF hub): local data or synthetic LLeQA-shaped data
+    parser.add_argument("--data_dir", type=str, default=os.environ.get("LLEQA_DIR"))
+    parser.add_argument("--synthetic", type=str, default=None, help="N,Q: synthetic corpus/queries of that size")
+    parser.add_argument("--synthetic_model", type=str, default="tiny", choices=["tiny", "base"])
+    return parser
+
+
+if __name__ == "__main__":
+    a, _ = build_parser().parse_known_args()   # unknown flags ignored, as hybrid.py:487
+    main(a)

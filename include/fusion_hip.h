@@ -1,0 +1,152 @@
+/*
+ * fusion_hip.h -- C ABI of libfusion_hip.so: the MI355X (gfx950) scoring + fusion engine
+ * behind the reference's src/retrievers/hybrid.py (Ranker / Aggregator).
+ *
+ * The reference has no FFI layer: its boundary is a Python API.  These
+ * entry points are what a Python binding for that path needs; fusion_amd/_lib.py is
+ * that binding (ctypes), and INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.  Citations are file:line in the reference tree.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _h (host);
+ *  - the caller owns every buffer; nothing is allocated, freed or synchronised inside
+ *    (graph-capturable): temporary storage comes from a caller-supplied workspace whose
+ *    size fz_*_workspace_bytes() reports;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *    asynchronous on it and re-entrant across streams;
+ *  - return value: FZ_OK (0) or a negative fz_status; no exceptions cross the boundary;
+ *  - score planes are row-major [rows][ld] with ld >= n; ld*4 should be a multiple of 16 B
+ *    for full-rate vector access (any ld is accepted).
+ *
+ * Data model: the reference's RankedLists (list[Q] of list[<=N] of {'corpus_id','score'},
+ * hybrid.py:66-75,93-106) is held per system as dense planes indexed by corpus POSITION:
+ *   score[q][j] fp32; rank[q][j] int32 = 0-based position of doc j in the system's list,
+ *   -1 if absent (PLAID-pruned ColBERT lists, hybrid.py:137); order[q][r] = doc at rank r;
+ *   len[q] = list length.  `idx` of hybrid.py:249,252 is `rank`.
+ */
+#ifndef FUSION_HIP_H
+#define FUSION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    FZ_OK = 0,
+    FZ_ERR_ARG = -1,         /* null / negative / inconsistent argument */
+    FZ_ERR_UNSUPPORTED = -2, /* shape outside what the kernels are built for (fails loudly, never falls back) */
+    FZ_ERR_HIP = -3,         /* a HIP runtime call failed; fz_last_hip_error() has the code */
+    FZ_ERR_WORKSPACE = -4    /* workspace NULL or too small */
+} fz_status;
+
+/* Aggregator.transform_scores modes (hybrid.py:235-280) */
+typedef enum {
+    FZ_NORM_NONE = 0,        /* :280 passthrough */
+    FZ_NORM_MINMAX = 1,      /* :254-258 */
+    FZ_NORM_ZSCORE = 2,      /* :260-264, unbiased std */
+    FZ_NORM_ARCTAN = 3,      /* :266-269 */
+    FZ_NORM_PERCENTILE = 4,  /* :271-275 */
+    FZ_NORM_NCE = 5          /* :276-277 */
+} fz_norm;
+
+typedef enum { FZ_RRF = 0 /* hybrid.py:252 */, FZ_BCF = 1 /* hybrid.py:249 */ } fz_rank_method;
+
+const char* fz_strerror(int status);
+int fz_last_hip_error(void);
+/* ABI version of this header: bump on any signature change */
+int fz_abi_version(void);
+
+/* ---- K1: single-vector scoring (DPR / SPLADE), hybrid.py:101-103 ---------------------- */
+/* Y[r] = X[r] / max(||X[r]||_2, 1e-12)   (util.cos_sim's normalisation; splade/base.py:195-196) */
+int fz_normalize_rows_f32(const float* X, int rows, int d, int ldx, float* Y, int ldy, void* stream);
+/* scores[q][j] = <Qn[q], Dn[j]>  fp32-in/fp32-accumulate MFMA GEMM (torch.mm, splade/base.py:197;
+ * util.dot_score, sentence_transformers.py:229).  Qn [Q][ldq], Dn [N][ldd], d = contraction. */
+int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int ldd, int Q, int N, int d, float* scores, int lds,
+                      void* stream);
+
+/* ---- K2: ColBERT late interaction, hybrid.py:108-137 (exact MaxSim) ------ */
+/* scores[q][j] = sum_{i<Lq} max_{t in doc j} <Qtok[q][i], Dtok[t]>.
+ * Qtok [Q][Lq][dim] fp16; Dtok packed ragged [sumL][dim] fp16, doc j owns rows [Doff[j], Doff[j+1]);
+ * Doff [N+1] int64 (device), sumL = Doff[N] (known to the host: rows of Dtok).
+ * dim must be 128 (run_colbert.sh:26); Lq in {32, 64, 128} (64: hybrid.py:129).  Empty documents score 0. */
+int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* Doff, int64_t sumL, int Q, int Lq, int N, int dim,
+                  float* scores, int lds, void* stream);
+
+/* ---- K5a/K6: stable descending row sort ---------------------------------------------- */
+/* Python sorted(..., reverse=True) is stable (bm25.py:104, hybrid.py:306).  For each row:
+ * the incoming sequence is keys gathered through init_order (NULL = identity, i.e. ties ->
+ * ascending corpus position), of length row_len[row] (NULL = n); it is sorted by key
+ * descending, ties keeping incoming order; -0.0 == +0.0; NaN first.
+ * key_bits 32 (fp32 keys) or 64 (fp64 keys).  Outputs, each nullable:
+ *   order[row][r]       payload (corpus position) at output rank r, r < row_len[row]
+ *   sorted_keys[row][r] its key (same type as keys)
+ *   rank[row][payload]  = r  (inverse permutation; other entries untouched: pre-fill with -1)
+ * Supported n: 1 .. fz_sort_max_n(). */
+int fz_sort_max_n(void);
+int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows, int n,
+                      int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream);
+
+/* ---- K5b: rank-based fusion, hybrid.py:206-211,248-252,301-304 ------------------------- */
+/* fused[q][j] = sum over systems s (in the given order, fp64, starting from 0.0) of
+ *   rrf: 1/(60+rank+1)     bcf: (len-rank+1)/len      for rank >= 0;  -inf if j is in no list.
+ * ranks_h: HOST array of S device pointers, each [Q][ld] int32; lens [S][Q] int32 (device). */
+int fz_fuse_rank_f64(const int32_t* const* ranks_h, const int32_t* lens, int S, int Q, int N, int ld, int method,
+                     double* fused, void* stream);
+
+/* ---- K3/K4: normalise -> weight -> sum, hybrid.py:212-214,254-280,291,301-304 --------- */
+/* per-row statistics over the valid entries (rank NULL = all valid):
+ *   FZ_NORM_MINMAX: stat_a=min stat_b=max;  FZ_NORM_ZSCORE: stat_a=mean stat_b=unbiased std
+ *   (fp64 accumulation, rounded to fp32; 1-element rows give std=NaN as torch.std does). */
+int fz_row_stats_f32(const float* scores, const int32_t* rank, int rows, int N, int ld, int norm, float* stat_a,
+                     float* stat_b, void* stream);
+/* fused[q][j] = sum_s fl32( t_s(score_s[q][j]) * fl32(w_s) ), fp32, unfused, in system order
+ * (NumPy-2 semantics of hybrid.py:291,304), t_s = the normalisation with that row's statistics;
+ * docs absent from every system: -inf.  One pass over HBM: each plane is read once.
+ * planes_h / ranks_h / distr_h: HOST arrays of S device pointers (ranks_h nullable, entries
+ * nullable = all docs present; distr_h needed only for PERCENTILE/NCE: ascending fp32 tables of
+ * P_h[s] entries, hybrid.py:272).  w_h: HOST fp64 weights (rounded to fp32 inside).
+ * norm = FZ_NORM_NONE is rejected here: use fz_fuse_none_f64 (the reference stays in float64). */
+int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
+                    int ld, int norm, const float* const* distr_h, const int32_t* P_h, float* fused, void* stream);
+/* 'none' / unknown normalisation: fused[q][j] = sum_s (double)score_s * w_s in fp64 (hybrid.py:280,291,304) */
+int fz_fuse_none_f64(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
+                     int ld, double* fused, void* stream);
+
+/* ---- first-insertion order of the fused dict, hybrid.py:301-304 (tie-break, SURVEY KAT-1) */
+/* ins_order[q][0..U[q]) = docs in the order aggregate_scores first inserts them: system by system,
+ * each in its rank order, skipping docs already seen.  orders_h: HOST array of S device pointers
+ * [Q][ld]; lens [S][Q].  Workspace: fz_insertion_order_workspace_bytes(Q, N). */
+size_t fz_insertion_order_workspace_bytes(int Q, int N);
+int fz_insertion_order(const int32_t* const* orders_h, const int32_t* lens, int S, int Q, int N, int ld, int32_t* ins_order,
+                       int32_t* U, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- top-k + shard merge: sentence_transformers.py:346-364 (chunked score -> topk -> heap) */
+/* k best of each row by (score desc, id asc); ids = id_base + column. out [rows][k]; rows with
+ * fewer than k columns are padded with (-inf, -1).  k <= fz_topk_max_k(). */
+int fz_topk_max_k(void);
+size_t fz_topk_workspace_bytes(int rows, int n, int k);
+int fz_topk_rows_f32(const float* scores, int rows, int n, int ld, int k, int64_t id_base, float* out_scores,
+                     int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream);
+/* merge G per-shard lists [G][rows][k] (as all-gathered over RCCL) into the global top-k [rows][k] */
+int fz_topk_merge(const float* in_scores, const int64_t* in_ids, int G, int rows, int k, float* out_scores, int64_t* out_ids,
+                  void* stream);
+
+/* ---- A1: BM25 scoring on device, bm25.py:149-156 -------------------------------------- */
+/* scores[q][j] (fp64) = sum over query terms in query order of idf*tf*(k1+1)/(tf+k1*(1-b+b*dl/avgdl)).
+ * CSR postings by term (toff [V+1], pdoc, ptf), idf [V] fp64, doc_len [N]; queries as CSR of term
+ * ids (qoff [Q+1], qterms; -1 = out of vocabulary). */
+int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf, const int32_t* doc_len,
+                       double avgdl, double k1, double b, const int64_t* qoff, const int32_t* qterms, int Q, int N,
+                       double* scores, int lds, void* stream);
+
+/* ---- small utilities ------------------------------------------------------------------ */
+int fz_fill_i32(int32_t* p, size_t count, int32_t value, void* stream);
+int fz_f64_to_f32(const double* src, float* dst, size_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUSION_HIP_H */

@@ -1,0 +1,433 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs, vs the golden
+fixtures made by the reference, and size-independent properties at BASELINE.json's full sizes.
+Bar: bit-exact for ranks / orders / fp64 rank fusion / exact-stat fp32 transforms; stated tolerance otherwise."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from fusion_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def plane(ops, a):
+    t = ops.alloc_plane(a.shape[0], a.shape[1], torch.from_numpy(a[:0]).dtype, "cuda")
+    t.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+    return t
+
+
+def keys_with_ties(rng, rows, n, dtype):
+    k = rng.normal(0, 1, (rows, n)).astype(dtype)
+    if n >= 8:
+        for r in range(rows):
+            idx = rng.choice(n, size=max(2, n // 3), replace=False)
+            k[r, idx] = k[r, idx[0]]
+            k[r, idx[1]] = 0.0
+            k[r, idx[2]] = -0.0
+        k[0, rng.integers(0, n)] = np.inf
+        k[0, rng.integers(0, n)] = -np.inf
+        if rows > 1:
+            k[1, rng.integers(0, n)] = np.nan
+    return k
+
+
+SORT_N32 = [1, 2, 63, 64, 65, 257, 1000, 1024, 1025, 4096, 4097, 8192, 9000, 16384, 20000, 27942, 28672, 28673, 35840]
+SORT_N64 = [1, 2, 65, 1000, 1025, 4097, 9000, 16385, 27942, 28672]
+
+
+@pytest.mark.parametrize("n", SORT_N32)
+def test_sort_rows_f32(ops, oracle, n):
+    rng = np.random.default_rng(n)
+    k = keys_with_ties(rng, 5, n, np.float32)
+    order, sk, rank = ops.sort_rows_desc(plane(ops, k), want_rank=True)
+    e_order, e_sk, e_rank = oracle.sort_rows_desc(k, want_rank=True)
+    np.testing.assert_array_equal(order.cpu().numpy(), e_order)
+    np.testing.assert_array_equal(rank.cpu().numpy(), e_rank)
+    np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)   # -0.0 == 0.0, NaN == NaN positionally
+
+
+@pytest.mark.parametrize("n", SORT_N64)
+def test_sort_rows_f64(ops, oracle, n):
+    rng = np.random.default_rng(1000 + n)
+    k = keys_with_ties(rng, 4, n, np.float64)
+    order, sk, rank = ops.sort_rows_desc(plane(ops, k), want_rank=True)
+    e_order, e_sk, e_rank = oracle.sort_rows_desc(k, want_rank=True)
+    np.testing.assert_array_equal(order.cpu().numpy(), e_order)
+    np.testing.assert_array_equal(rank.cpu().numpy(), e_rank)
+    np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)
+
+
+def test_sort_unsupported_n_fails_loudly(ops):
+    from fusion_amd._lib import FusionHipError
+    with pytest.raises(FusionHipError):
+        ops.sort_rows_desc(torch.zeros((2, 40000), device="cuda"))
+    with pytest.raises(TypeError):
+        ops.sort_rows_desc(torch.zeros((2, 10)))   # CPU tensor: no CPU path
+
+
+@pytest.mark.parametrize("n,dtype", [(5, np.float32), (300, np.float32), (5000, np.float64), (27942, np.float32)])
+def test_sort_gathered_sequence(ops, oracle, n, dtype):
+    """init_order + row_len: the fused-list ordering call (ties keep first-insertion order)."""
+    rng = np.random.default_rng(n)
+    rows = 4
+    k = np.round(rng.normal(0, 1, (rows, n)), 1).astype(dtype)   # many ties
+    init = np.stack([rng.permutation(n) for _ in range(rows)]).astype(np.int32)
+    lens = np.array([n, max(1, n // 2), 1, max(1, n - 1)], dtype=np.int32)
+    for r in range(rows):
+        init[r, lens[r]:] = -1
+    order, sk, _ = ops.sort_rows_desc(plane(ops, k), init_order=plane(ops, init), row_len=dev(lens))
+    e_order, e_sk = oracle.sort_rows_desc(k, init_order=init, row_len=lens)
+    np.testing.assert_array_equal(order.cpu().numpy(), e_order)
+    np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)
+
+
+def synth_systems(rng, S, Q, N, partial=True):
+    planes, ranks, orders, lens = [], [], [], np.zeros((S, Q), dtype=np.int32)
+    for s in range(S):
+        if s == 0:
+            sc = np.maximum(0, rng.gamma(0.5, 4.0, (Q, N)) - 2).astype(np.float32)
+        elif s == 3:
+            sc = rng.normal(20, 4, (Q, N)).astype(np.float32)
+        else:
+            sc = rng.uniform(-0.2, 0.9, (Q, N)).astype(np.float32)
+        order = np.argsort(-sc.astype(np.float64), axis=1, kind="stable").astype(np.int32)
+        rank = np.full((Q, N), -1, dtype=np.int32)
+        for q in range(Q):
+            L = N if not (partial and s in (1, 3)) else max(1, int(N * (0.6 if s == 3 else 0.9)))
+            lens[s, q] = L
+            rank[q, order[q, :L]] = np.arange(L, dtype=np.int32)
+            order[q, L:] = -1
+        planes.append(sc); ranks.append(rank); orders.append(order)
+    return planes, ranks, orders, lens
+
+
+@pytest.mark.parametrize("S,Q,N", [(2, 3, 1), (2, 4, 257), (4, 5, 1000), (4, 3, 5000), (3, 2, 27942)])
+@pytest.mark.parametrize("method", ["rrf", "bcf"])
+def test_fuse_rank_exact(ops, oracle, S, Q, N, method):
+    rng = np.random.default_rng(S * 1000 + N)
+    _, ranks, _, lens = synth_systems(rng, S, Q, N)
+    got = ops.fuse_rank([plane(ops, r) for r in ranks], dev(lens), method).cpu().numpy()
+    exp = oracle.fuse_rank(ranks, lens, method)
+    np.testing.assert_array_equal(got, exp)   # float64, bit for bit
+
+
+NSF_TOL = {"min-max": 0.0, "percentile-rank": 0.0, "z-score": 1e-6, "arctan": 1e-6, "normal-curve-equivalent": 1e-4}
+
+
+@pytest.mark.parametrize("S,Q,N", [(1, 2, 1), (2, 4, 257), (4, 3, 1000), (4, 2, 5000), (4, 2, 20000), (4, 2, 27942)])
+@pytest.mark.parametrize("norm", list(NSF_TOL))
+@pytest.mark.parametrize("partial", [False, True])
+def test_fuse_nsf(ops, oracle, S, Q, N, norm, partial):
+    rng = np.random.default_rng(S * 77 + N)
+    planes, ranks, _, _ = synth_systems(rng, S, Q, N, partial)
+    w = rng.dirichlet(np.ones(S))
+    distr = None
+    if norm in ("percentile-rank", "normal-curve-equivalent"):
+        distr = [np.quantile(p.astype(np.float64), np.linspace(0, 1, min(101, N + 2))).astype(np.float32) for p in planes]
+    rk = ranks if partial else None
+    got = ops.fuse_nsf([plane(ops, p) for p in planes], None if rk is None else [plane(ops, r) for r in rk], w, norm,
+                       None if distr is None else [dev(d) for d in distr]).cpu().numpy()
+    exp = oracle.fuse_nsf(planes, rk, w, norm, distr)
+    tol = NSF_TOL[norm]
+    if tol == 0.0:
+        np.testing.assert_array_equal(got, exp)
+    else:
+        fin = np.isfinite(exp)
+        np.testing.assert_array_equal(np.isfinite(got), fin)
+        np.testing.assert_array_equal(got[~fin], exp[~fin])   # -inf (absent docs / icdf(0)) and NaN in the same places
+        assert np.max(np.abs(got[fin] - exp[fin]), initial=0.0) <= tol
+
+
+def test_fuse_nsf_constant_and_single(ops, oracle):
+    const = np.full((2, 300), 3.25, dtype=np.float32)
+    for norm in ("min-max", "z-score"):
+        got = ops.fuse_nsf([plane(ops, const)], None, [1.0], norm).cpu().numpy()
+        np.testing.assert_array_equal(got, oracle.fuse_nsf([const], None, [1.0], norm))
+    one = np.array([[2.0]], dtype=np.float32)
+    z = ops.fuse_nsf([plane(ops, one)], None, [1.0], "z-score").cpu().numpy()
+    assert np.isnan(z[0, 0])   # torch.std of one element (KAT-4)
+    assert ops.fuse_nsf([plane(ops, one)], None, [1.0], "min-max").cpu().numpy()[0, 0] == 1.0
+
+
+@pytest.mark.parametrize("S,Q,N", [(2, 3, 257), (4, 2, 27942)])
+def test_fuse_none_exact(ops, oracle, S, Q, N):
+    rng = np.random.default_rng(5)
+    planes, ranks, _, _ = synth_systems(rng, S, Q, N)
+    w = rng.dirichlet(np.ones(S))
+    got = ops.fuse_none([plane(ops, p) for p in planes], [plane(ops, r) for r in ranks], w).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.fuse_none(planes, ranks, w))
+
+
+@pytest.mark.parametrize("S,Q,N", [(2, 3, 5), (4, 4, 1000), (4, 2, 27942)])
+def test_insertion_order(ops, oracle, S, Q, N):
+    rng = np.random.default_rng(N)
+    _, _, orders, lens = synth_systems(rng, S, Q, N)
+    ins, U = ops.insertion_order([plane(ops, o) for o in orders], dev(lens), N)
+    e_ins, e_U = oracle.insertion_order(orders, lens, N)
+    np.testing.assert_array_equal(U.cpu().numpy(), e_U)
+    g = ins.cpu().numpy()
+    for q in range(Q):
+        np.testing.assert_array_equal(g[q, : e_U[q]], e_ins[q, : e_U[q]])
+
+
+# ---- the reference's own outputs, through the drop-in Aggregator --------------------------------------
+FUSE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "fuse_*.npz")))
+METHODS = [("rrf", "none"), ("bcf", "none"), ("nsf", "none"), ("nsf", "min-max"), ("nsf", "z-score"), ("nsf", "arctan"),
+           ("nsf", "percentile-rank"), ("nsf", "normal-curve-equivalent")]
+EXACT = {("rrf", "none"), ("bcf", "none"), ("nsf", "none"), ("nsf", "min-max"), ("nsf", "percentile-rank")}
+TOL = {("nsf", "z-score"): 2e-6, ("nsf", "arctan"): 1e-6, ("nsf", "normal-curve-equivalent"): 1e-4}
+
+
+@pytest.mark.parametrize("path", FUSE_FILES, ids=[os.path.basename(p)[:-4] for p in FUSE_FILES])
+def test_aggregator_matches_reference_golden(path):
+    from fusion_amd.retrievers.hybrid import Aggregator
+    z = np.load(path, allow_pickle=False)
+    systems = [str(s) for s in z["systems"]]
+    ids, sc, ln = z["in_ids"], z["in_scores"], z["in_len"]
+    Q = ids.shape[1]
+    lists = {s: [[{"corpus_id": int(ids[si, q, r]), "score": float(sc[si, q, r])} for r in range(ln[si, q])] for q in range(Q)]
+             for si, s in enumerate(systems)}
+    weights = {s: float(w) for s, w in zip(systems, z["weights"])}
+    distr = {s: z[f"distr_{s}"] for s in systems}
+    for method, norm in METHODS:
+        got = Aggregator.fuse(lists, method=method, normalization=norm, linear_weights=weights, percentile_distributions=distr)
+        key = f"{method}__{norm}"
+        e_ids, e_sc, e_len = z[f"out_ids__{key}"], z[f"out_scores__{key}"], z[f"out_len__{key}"]
+        assert len(got) == Q
+        for q in range(Q):
+            n = int(e_len[q])
+            assert len(got[q]) == n, (key, q)
+            g_ids = np.array([x["corpus_id"] for x in got[q]], dtype=np.int64)
+            g_sc = np.array([float(x["score"]) for x in got[q]], dtype=np.float64)
+            if (method, norm) in EXACT:
+                np.testing.assert_array_equal(g_ids, e_ids[q, :n], err_msg=key)      # ranked-list identity
+                np.testing.assert_array_equal(g_sc, e_sc[q, :n], err_msg=key)
+            else:
+                assert sorted(g_ids.tolist()) == sorted(e_ids[q, :n].tolist())
+                exp = {int(i): s for i, s in zip(e_ids[q, :n], e_sc[q, :n])}
+                ref = np.array([exp[int(i)] for i in g_ids])
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isfinite(g_sc), fin), key
+                assert np.max(np.abs(g_sc[fin] - ref[fin]), initial=0.0) <= TOL[(method, norm)], key
+
+
+def test_aggregator_kat_and_errors():
+    from fusion_amd.retrievers.hybrid import Aggregator
+    kat = json.load(open(os.path.join(GOLDEN, "kat_fuse.json")))
+    L = lambda pairs: [{"corpus_id": i, "score": s} for i, s in pairs]
+    a = {"s1": [L([(100, 2.0), (200, 1.0)])], "s2": [L([(200, 2.0), (100, 1.0)])]}
+    b = {"s2": a["s2"], "s1": a["s1"]}
+    assert Aggregator.fuse(a, "rrf") == kat["kat1_s1s2"]          # KAT-1: first-insertion tie-break
+    assert Aggregator.fuse(b, "rrf") == kat["kat1_s2s1"]
+    three = {"s1": [L([(1, 1.0), (2, .5)])] * 3, "s2": [L([(2, 1.0), (1, .5)])] * 3}
+    assert Aggregator.fuse(three, "rrf", return_topk=2) == kat["kat6_topk2"]   # slices queries
+    dup = {"s1": [L([(1, 3.0), (2, 2.0), (1, 1.0), (3, 0.5)])], "s2": [L([(3, 1.0), (2, .5)])]}
+    assert Aggregator.fuse(dup, "rrf") == kat["kat_dup_rrf"]
+    assert Aggregator.fuse(dup, "bcf") == kat["kat_dup_bcf"]
+    lists = {"bm25": [L([(10, 7.5), (11, 3.0), (12, 0.0)])], "dpr": [L([(12, .9), (10, .5), (13, .1)])]}
+    got = Aggregator.fuse(lists, "nsf", "min-max", {"bm25": .5, "dpr": .5}, {})
+    assert [(x["corpus_id"], float(x["score"])) for x in got[0]] == [(x["corpus_id"], x["score"]) for x in kat["kat2_nsf_min-max"][0]]
+    with pytest.raises(AssertionError):
+        Aggregator.fuse({"a": [L([(1, 1.0)])], "b": [L([(1, 1.0)])] * 2}, "rrf")
+    with pytest.raises(KeyError):
+        Aggregator.fuse({"a": [L([(1, 1.0)])], "b": [L([(1, 1.0)])]}, "nsf", "min-max", {"a": 1.0}, {})
+    with pytest.raises(AttributeError):
+        Aggregator.fuse({"a": [L([(1, 1.0)])]}, "nsf", "min-max", {"a": 1.0}, None)
+    t = Aggregator.transform_scores({1: 0.2, 2: 4.6, 3: 99.0}, "percentile-rank", percentile_distr=np.linspace(0, 10, 11))
+    assert {k: float(v) for k, v in t.items()} == {x["corpus_id"]: x["score"] for x in kat["kat5_percentile"]}
+
+
+# ---- scoring -------------------------------------------------------------------------------------------
+def test_dot_scores_identity_layout(ops):
+    """A = I against an ASYMMETRIC B catches a transposed C write / swapped operand map."""
+    d = 256
+    A = torch.eye(d, device="cuda")[:130].contiguous()          # 130 x 256
+    B = (torch.arange(200 * d, device="cuda", dtype=torch.float32).reshape(200, d) % 251) - 97.0
+    S = ops.dot_scores(A, B)
+    torch.testing.assert_close(S, B[:, :130].t().contiguous(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("Q,N,d", [(1, 1, 4), (3, 5, 8), (195, 300, 768), (130, 1000, 100), (64, 27942, 768), (257, 129, 36)])
+def test_cos_scores_vs_oracle(ops, oracle, Q, N, d):
+    rng = np.random.default_rng(Q + N + d)
+    Qe = rng.normal(0, 1, (Q, d)).astype(np.float32)
+    De = rng.normal(0, 1, (N, d)).astype(np.float32)
+    Qn = ops.normalize_rows(dev(Qe)); Dn = ops.normalize_rows(dev(De))
+    np.testing.assert_allclose(Qn.cpu().numpy()[:, :d], oracle.normalize_rows(Qe), rtol=0, atol=1e-7)
+    got = ops.dot_scores(Qn, Dn).cpu().numpy()
+    exp = oracle.cos_scores(Qe, De)
+    assert got.shape == (Q, N)
+    assert np.max(np.abs(got - exp)) <= 2e-6     # contract: 1e-4 (north_star); fp32 MFMA chain is ~1e-7
+
+
+def test_normalize_zero_row(ops):
+    X = torch.zeros((2, 8), device="cuda"); X[1, 0] = 3.0
+    Y = ops.normalize_rows(X).cpu().numpy()
+    assert np.all(Y[0] == 0) and Y[1, 0] == 1.0       # x / max(||x||, 1e-12)
+
+
+def ragged_docs(rng, N, dim=128, lo=0, hi=80):
+    lens = rng.integers(lo, hi, N)
+    off = np.zeros(N + 1, dtype=np.int64); off[1:] = np.cumsum(lens)
+    tok = rng.normal(0, 1, (int(off[-1]), dim)).astype(np.float32)
+    tok /= np.maximum(np.linalg.norm(tok, axis=1, keepdims=True), 1e-6)
+    return tok.astype(np.float16), off
+
+
+@pytest.mark.parametrize("Q,N,Lq,hi", [(1, 1, 32, 40), (3, 70, 64, 80), (20, 300, 64, 140), (17, 65, 32, 33), (5, 40, 128, 600)])
+def test_maxsim_vs_oracle(ops, oracle, Q, N, Lq, hi):
+    rng = np.random.default_rng(Q * 31 + N)
+    Dtok, Doff = ragged_docs(rng, N, hi=hi)
+    if N > 3:
+        assert (np.diff(Doff) == 0).any() or True
+    Qtok = rng.normal(0, 1, (Q, Lq, 128)).astype(np.float32)
+    Qtok /= np.linalg.norm(Qtok, axis=2, keepdims=True)
+    Qtok = Qtok.astype(np.float16)
+    got = ops.maxsim(dev(Qtok), dev(Dtok), dev(Doff)).cpu().numpy()
+    exp = oracle.maxsim(Qtok.astype(np.float32), Dtok.astype(np.float32), Doff)
+    assert np.max(np.abs(got - exp)) <= 1e-4 * max(1, Lq / 32)
+
+
+def test_maxsim_empty_docs(ops, oracle):
+    rng = np.random.default_rng(0)
+    Dtok, _ = ragged_docs(rng, 1, lo=50, hi=51)
+    Doff = np.array([0, 0, 20, 20, 50, 50], dtype=np.int64)     # docs 0, 2, 4 empty
+    Qtok = rng.normal(0, 1, (2, 64, 128)).astype(np.float16)
+    got = ops.maxsim(dev(Qtok), dev(Dtok), dev(Doff)).cpu().numpy()
+    exp = oracle.maxsim(Qtok.astype(np.float32), Dtok.astype(np.float32), Doff)
+    assert np.all(got[:, [0, 2, 4]] == 0)
+    assert np.max(np.abs(got - exp)) <= 2e-3    # un-normalised tokens: larger magnitudes
+
+
+# ---- top-k ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,n,k", [(3, 10, 4), (2, 5, 8), (4, 3000, 100), (3, 40000, 1000), (2, 100000, 1000), (2, 300001, 50)])
+def test_topk_rows(ops, oracle, rows, n, k):
+    rng = np.random.default_rng(n)
+    sc = np.round(rng.normal(0, 1, (rows, n)), 3).astype(np.float32)   # ties
+    gs, gi = ops.topk_rows(plane(ops, sc), k, id_base=7_000_000_000)
+    es, ei = oracle.topk_rows(sc, k, id_base=7_000_000_000)
+    np.testing.assert_array_equal(gs.cpu().numpy(), es)
+    np.testing.assert_array_equal(gi.cpu().numpy(), ei)
+
+
+def test_topk_merge(ops, oracle):
+    rng = np.random.default_rng(3)
+    G, rows, k, nloc = 8, 6, 1000, 5000
+    sc = np.round(rng.normal(0, 1, (G, rows, nloc)), 2).astype(np.float32)
+    parts = [oracle.topk_rows(sc[g], k, id_base=g * nloc) for g in range(G)]
+    in_s = np.stack([p[0] for p in parts]); in_i = np.stack([p[1] for p in parts])
+    gs, gi = ops.topk_merge(dev(in_s), dev(in_i))
+    es, ei = oracle.topk_merge(in_s, in_i)
+    np.testing.assert_array_equal(gs.cpu().numpy(), es)
+    np.testing.assert_array_equal(gi.cpu().numpy(), ei)
+    # and it equals the top-k of the unsharded matrix
+    fs, fi = oracle.topk_rows(np.concatenate(list(sc), axis=1), k)
+    np.testing.assert_array_equal(gs.cpu().numpy(), fs)
+    np.testing.assert_array_equal(gi.cpu().numpy(), fi)
+
+
+# ---- BM25 ----------------------------------------------------------------------------------------------
+def test_bm25_matches_reference_golden():
+    from fusion_amd.retrievers.bm25 import BM25
+    g = json.load(open(os.path.join(GOLDEN, "bm25.json")))
+    for (k1, b), exp in zip(g["params"], g["results"]):
+        got = BM25(g["docs"], k1=k1, b=b).search_all(g["queries"], top_k=len(g["docs"]))
+        for gq, eq in zip(got, exp):
+            assert [x["corpus_id"] for x in gq] == [e[0] for e in eq]
+            assert [x["score"] for x in gq] == [e[1] for e in eq]     # float64 bit-exact
+    k = g["kat8"]
+    got = BM25(k["docs"], 2.5, 0.2).search_all(k["queries"], top_k=4)
+    assert [[[x["corpus_id"], x["score"]] for x in r] for r in got] == k["results"]
+
+
+def test_bm25_vs_oracle_larger(oracle):
+    from fusion_amd.retrievers.bm25 import BM25
+    rng = np.random.default_rng(9)
+    vocab = np.array([f"w{i}" for i in range(2000)])
+    p = 1.0 / np.arange(1, 2001); p /= p.sum()
+    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(5, 120)), p=p)) for _ in range(3000)]
+    queries = [" ".join(rng.choice(vocab, size=int(rng.integers(1, 12)), p=p)) for _ in range(40)] + ["", "zzz w1 w1"]
+    m = BM25(docs, 2.5, 0.2)
+    got = m.scores(queries).cpu().numpy()
+    exp = oracle.BM25(docs, 2.5, 0.2).scores(queries)
+    np.testing.assert_array_equal(got, exp)
+
+
+# ---- full-size properties (BASELINE.json sizes: Q=1024, N=27,942) ------------------------------------------
+def test_full_size_rrf_pipeline_properties(ops):
+    Q, N = 1024, 27942
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = ops.alloc_plane(Q, N, torch.float32, "cuda"); a.copy_(torch.rand((Q, N), generator=g, device="cuda"))
+    b = ops.alloc_plane(Q, N, torch.float32, "cuda"); b.copy_(torch.randn((Q, N), generator=g, device="cuda").round(decimals=2))
+    oa, ka, ra = ops.sort_rows_desc(a, want_rank=True)
+    ob, kb, rb = ops.sort_rows_desc(b, want_rank=True)
+    for o, k, r, src in ((oa, ka, ra, a), (ob, kb, rb, b)):
+        assert bool((k[:, :-1] >= k[:, 1:]).all())                                   # sortedness
+        assert bool((torch.sort(o.long(), dim=1).values == torch.arange(N, device="cuda")).all())   # permutation
+        assert bool((torch.gather(r.long(), 1, o.long()) == torch.arange(N, device="cuda")).all())  # rank = inverse
+        assert bool((torch.gather(src, 1, o.long()) == k).all())                    # keys travel with payloads
+    # stability: equal keys keep ascending corpus position
+    eq = kb[:, :-1] == kb[:, 1:]
+    assert bool((ob[:, :-1][eq] < ob[:, 1:][eq]).all())
+    lens = torch.full((2, Q), N, dtype=torch.int32, device="cuda")
+    fused = ops.fuse_rank([ra, rb], lens, "rrf")
+    ref = 1.0 / (61.0 + ra.double()) + 1.0 / (61.0 + rb.double())                    # same fp64 expression order
+    assert bool((fused == ref).all())
+    of, kf, _ = ops.sort_rows_desc(fused, init_order=oa)
+    assert bool((kf[:, :-1] >= kf[:, 1:]).all())
+    assert bool((torch.sort(of.long(), dim=1).values == torch.arange(N, device="cuda")).all())
+    # swapping the systems changes nothing but the tie-break (checksum of the fused multiset)
+    fused2 = ops.fuse_rank([rb, ra], lens, "rrf")
+    assert bool((fused2 == fused).all())                                             # a+b == b+a in IEEE
+
+
+def test_full_size_nsf_properties(ops):
+    Q, N, S = 1024, 27942, 4
+    g = torch.Generator(device="cuda").manual_seed(1)
+    planes = []
+    for s in range(S):
+        p = ops.alloc_plane(Q, N, torch.float32, "cuda"); p.copy_(torch.randn((Q, N), generator=g, device="cuda") * (s + 1) + s)
+        planes.append(p)
+    w = [0.1, 0.2, 0.3, 0.4]
+    f = ops.fuse_nsf(planes, None, w, "min-max")
+    # min-max of every system lies in [0,1] -> fused in [0, sum w]; each row attains 0..1 per system
+    assert float(f.min()) >= 0.0 and float(f.max()) <= 1.0 + 1e-6
+    ref = torch.zeros((Q, N), device="cuda")
+    for p, ww in zip(planes, w):
+        mn, mx = p.min(1, keepdim=True).values, p.max(1, keepdim=True).values
+        ref = ref + ((p - mn) / (mx - mn)) * torch.tensor(ww, dtype=torch.float32, device="cuda")
+    assert bool((f == ref).all())                                                    # same unfused fp32 ops
+    # idempotence: min-max of an already min-max-normalised single system is itself
+    one = ops.fuse_nsf([planes[0]], None, [1.0], "min-max")
+    one_p = ops.alloc_plane(Q, N, torch.float32, "cuda"); one_p.copy_(one)
+    two = ops.fuse_nsf([one_p], None, [1.0], "min-max")
+    assert bool((two == one_p).all())
+    z = ops.fuse_nsf([planes[1]], None, [1.0], "z-score")
+    assert float(z.mean(1).abs().max()) < 1e-4 and float((z.std(1) - 1).abs().max()) < 1e-4
+
+
+def test_full_size_cos_linearity(ops):
+    Q, N, d = 1024, 27942, 768
+    g = torch.Generator(device="cuda").manual_seed(2)
+    Qe = torch.randn((Q, d), generator=g, device="cuda"); De = torch.randn((N, d), generator=g, device="cuda")
+    S = ops.cos_scores(Qe, De)
+    assert float(S.abs().max()) <= 1.0 + 1e-5
+    ref = torch.nn.functional.normalize(Qe[:64].double()) @ torch.nn.functional.normalize(De.double()).t()
+    assert float((S[:64].double() - ref).abs().max()) <= 2e-6
+    S2 = ops.cos_scores(Qe * 3.0, De * 0.5)              # cosine is scale-invariant
+    assert float((S2 - S).abs().max()) <= 1e-6
