@@ -1,0 +1,124 @@
+"""Corpus-sharded dense retrieval with ONE collective (BASELINE.json configs[4]: mMARCO-fr, 8.8 M passages).
+
+Reference spec: InformationRetrievalEvaluatorCustom.compute_metrices (src/utils/sentence_transformers.py:314-393):
+corpus in chunks, per chunk score -> torch.topk -> heap merge keeping max_k = 1000 per query.  The reference does
+this on one GPU, one query at a time (1.2 M launches for mMARCO).  Here:
+
+  * the corpus-embedding matrix is row-sharded over the ranks (one process per GPU, 288 GB HBM each);
+  * every rank scores ALL queries against its shard in document chunks: fp32-MFMA GEMM -> per-row top-k
+    (csrc/sort.hip) -> merge into the running top-k -- no host round trip;
+  * ONE all-gather of the per-shard [Q, k] (score fp32, id int64) lists over RCCL/xGMI (8.2 MB + 8.2 MB per rank at
+    Q = 1024, k = 1000: < 1 % of the GEMM time) and an identical local G-way merge on every rank.
+Ties are broken by ascending global document id everywhere, so the result does not depend on the number of shards.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+
+def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous, balanced row shards: the first n % world shards get one extra row."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def allgather_topk(local_scores: torch.Tensor, local_ids: torch.Tensor, group=None, merge_fn=None):
+    """local [Q, k] lists (each sorted by score desc, id asc; padding = (-inf, -1)) -> global [Q, k] on every rank.
+    merge_fn([G,Q,k] scores, [G,Q,k] ids) -> ([Q,k], [Q,k]); defaults to the HIP merge."""
+    import torch.distributed as dist
+    if merge_fn is None:
+        from . import ops
+        merge_fn = ops.topk_merge
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return merge_fn(local_scores.unsqueeze(0).contiguous(), local_ids.unsqueeze(0).contiguous())
+    Q, k = local_scores.shape
+    gs = torch.empty((world, Q, k), dtype=local_scores.dtype, device=local_scores.device)
+    gi = torch.empty((world, Q, k), dtype=local_ids.dtype, device=local_ids.device)
+    # concatenated-along-dim-0 output form: accepted by RCCL and gloo alike
+    dist.all_gather_into_tensor(gs.view(world * Q, k), local_scores.contiguous(), group=group)
+    dist.all_gather_into_tensor(gi.view(world * Q, k), local_ids.contiguous(), group=group)
+    return merge_fn(gs, gi)
+
+
+class ShardedDenseIndex:
+    """One rank's shard of the L2-normalised corpus embeddings + the chunked score -> top-k loop."""
+
+    CHUNK = 8 * 28672   # documents per GEMM launch: 8 sort-kernel rows per query
+
+    def __init__(self, Dn_local: torch.Tensor, id_base: int, group=None):
+        self.Dn, self.id_base, self.group = Dn_local, int(id_base), group
+
+    def local_topk(self, Qn: torch.Tensor, k: int):
+        from . import ops
+        n = self.Dn.shape[0]
+        best_s = best_i = None
+        for c0 in range(0, max(n, 1), self.CHUNK):
+            c1 = min(n, c0 + self.CHUNK)
+            S = ops.dot_scores(Qn, self.Dn[c0:c1])
+            s, i = ops.topk_rows(S, k, id_base=self.id_base + c0)
+            if best_s is None:
+                best_s, best_i = s, i
+            else:   # running top-k: merge two id-ascending lists (chunks arrive in id order)
+                best_s, best_i = ops.topk_merge(torch.stack([best_s, s]), torch.stack([best_i, i]))
+        return best_s, best_i
+
+    def search(self, Qn: torch.Tensor, k: int = 1000):
+        s, i = self.local_topk(Qn, k)
+        return allgather_topk(s, i, self.group)
+
+
+def bench_sharded(args, dev, rank, world, dist):
+    """bench.py --workload mmarco: encode + sharded score + top-k + all-gather, queries/s (strong scaling: the corpus is fixed)."""
+    from . import encoders, ops
+    N, d, Q, k = args.mmarco_docs, args.dim, args.queries, args.topk
+    lo, hi = shard_bounds(N, world, rank)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    Dn = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
+    for c0 in range(0, hi - lo, 1 << 20):   # generated on the device, shard by shard: 27 GB never cross PCIe
+        c1 = min(hi - lo, c0 + (1 << 20))
+        Dn[c0:c1] = ops.normalize_rows(torch.randn((c1 - c0, d), generator=g, device=dev))
+    index = ShardedDenseIndex(Dn, lo, None)
+    rng = np.random.default_rng(5)
+    if not args.no_encode:
+        enc = encoders.random_init("dpr", device=dev, size=args.encoder_size, seed=0)
+        L = 64
+        qlen = rng.integers(8, L + 1, Q)
+        ids = rng.integers(7, enc.backbone.config.vocab_size - 1, (Q, L))
+        mask = (np.arange(L)[None, :] < qlen[:, None]).astype(np.int64)
+        ids_t = torch.from_numpy(np.where(mask == 1, ids, 1)).to(dev)
+        mask_t = torch.from_numpy(mask).to(dev)
+    else:
+        q_emb = torch.from_numpy(rng.normal(0, 1, (Q, d)).astype(np.float32)).to(dev)
+
+    def step():
+        e = enc.encode_ids(ids_t, mask_t) if not args.no_encode else q_emb
+        return index.search(ops.normalize_rows(e), k)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist: dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    el = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    flops = 2.0 * Q * (hi - lo) * d
+    return {"metric": "queries/sec end-to-end (encode+score+fuse), mMARCO-fr-shaped sharded DPR", "value": Q * args.steps / el,
+            "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"mMARCO-fr-shaped DPR: N={N} passages sharded x{world}, d={d}, Q={Q}, top-{k}, RCCL all-gather of per-shard top-k",
+                       "encode_in_step": not args.no_encode},
+            "shard_gemm_tflop": flops / 1e12}
