@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--no-encode", action="store_true", help="skip the transformer forward (score+fuse only; not the headline metric)")
     p.add_argument("--encoder-size", default="base", choices=["base", "tiny"])
+    p.add_argument("--encode-buckets", type=int, default=8, help="length buckets for the query encoder (1 = pad everything to the batch maximum)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--mmarco-docs", type=int, default=8841823)
     p.add_argument("--topk", type=int, default=1000)
@@ -94,6 +95,7 @@ def build_lleqa(args, dev, rank):
         mask = (np.arange(L)[None, :] < qlen[:, None]).astype(np.int64)
         ids = np.where(mask == 1, ids, enc.backbone.config.pad_token_id)
         st["enc"], st["ids"], st["mask"] = enc, torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+        st["qlen"] = qlen   # host token counts (a tokenizer returns them): drives length-bucketed batching
     else:
         st["q_emb"] = torch.from_numpy(rng.normal(0, 1, (Q, d)).astype(np.float32)).to(dev)
     # corpus embeddings: encoded + normalised once (static corpus), resident in HBM
@@ -118,6 +120,7 @@ def build_lleqa(args, dev, rank):
                       qoff=torch.from_numpy(qoff).to(dev), qterms=torch.from_numpy(qterms).to(dev))
     st["lens2"] = torch.full((2, Q), N, dtype=torch.int32, device=dev)
     st["Q"], st["N"], st["d"] = Q, N, d
+    st["buckets"] = args.encode_buckets
     st["host"] = dict(idf=idf, toff=toff, pd=pd, tf=tf, lens=lens, qoff=qoff, qterms=qterms)
     return st
 
@@ -127,7 +130,7 @@ def step_lleqa(st, ev=None):
     Q, N = st["Q"], st["N"]
     b = st["bm25"]
     if ev: ev.mark("start")
-    q_emb = st["enc"].encode_ids(st["ids"], st["mask"]) if "enc" in st else st["q_emb"]
+    q_emb = st["enc"].encode_ids_bucketed(st["ids"], st["mask"], st["qlen"], st["buckets"]) if "enc" in st else st["q_emb"]
     if ev: ev.mark("encode")
     Qn = ops.normalize_rows(q_emb)
     S = ops.dot_scores(Qn, st["Dn"])
@@ -140,7 +143,7 @@ def step_lleqa(st, ev=None):
     if ev: ev.mark("bm25_rank")
     fused = ops.fuse_rank([r_b, r_d], st["lens2"], "rrf")
     if ev: ev.mark("fuse_rrf")
-    order, scores, _ = ops.sort_rows_desc(fused, init_order=o_b)
+    order, scores, _ = ops.sort_rows_desc(fused, init_rank=r_b)   # ties keep BM25's (system 0) order
     if ev: ev.mark("final_order")
     return order, scores, (S, B)
 

@@ -21,7 +21,9 @@ namespace fz {
 
 struct SortArgs {
     const void* keys;            // fp32 or fp64
-    const int32_t* init_order;   // nullable [rows][key_row_stride]
+    const int32_t* init_order;   // nullable [rows][key_row_stride]: column at sequence position r (gather)
+    const int32_t* init_rank;    // nullable [rows][key_row_stride]: sequence position of column j, -1 = not in the sequence
+                                 //   (same information as init_order, but loaded coalesced and placed through LDS)
     const int32_t* row_len;      // nullable [rows]
     int n_total;                 // elements per row (before chunking)
     long key_row_stride;         // elements between consecutive rows
@@ -90,6 +92,53 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     if (threadIdx.x < 4) misc[8 + threadIdx.x] = (threadIdx.x & 1) ? 0xffffffffu : 0u;  // [8]=or0 [9]=and0 [10]=or1 [11]=and1
     __syncthreads();
     uint32_t or0 = 0, and0 = 0xffffffffu, or1 = 0, and1 = 0xffffffffu;
+    if (a.init_rank) {
+        // placed sequence: column j sits at sequence position init_rank[j].  Keys and positions are read coalesced
+        // by column; each key word is scattered to exch[position] and read back in striped order (one LDS round
+        // per word) -- the random walk happens in LDS instead of as 27,942 uncoalesced 4/8-byte HBM reads per row.
+        const int32_t* __restrict__ irow = a.init_rank + krow;
+        uint32_t pos[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int j = w * E * 64 + i * 64 + lane;
+            const bool in = j < a.n_total;
+            const int r = in ? irow[j] : -1;
+            const bool ok = in && (unsigned)r < (unsigned)m;
+            pos[i] = ok ? (uint32_t)r : 0xffffffffu;
+            if (KW == 1) {
+                k0[i] = desc_key_f32(kf[in ? j : 0]);
+            } else {
+                const uint64_t kk = desc_key_f64(kd[in ? j : 0]);
+                k0[i] = (uint32_t)kk;
+                k1[KW == 2 ? i : 0] = (uint32_t)(kk >> 32);
+            }
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        auto place = [&](uint32_t (&reg)[E], uint32_t fill) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) exch[w * E * 64 + i * 64 + lane] = fill;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < E; ++i)
+                if (pos[i] != 0xffffffffu) exch[pos[i]] = reg[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < E; ++i) reg[i] = exch[w * E * 64 + i * 64 + lane];
+            __syncthreads();
+        };
+        place(k0, SENT);
+        if constexpr (KW == 2) place(k1, SENT);
+#pragma unroll
+        for (int i = 0; i < E; ++i) meta[i] = (uint32_t)(w * E * 64 + i * 64 + lane);   // payload = own column (< 65535)
+        place(meta, 0xffffu);
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            if (meta[i] != 0xffffu) {   // a real element landed in this slot
+                or0 |= k0[i]; and0 &= k0[i];
+                if (KW == 2) { or1 |= k1[KW == 2 ? i : 0]; and1 &= k1[KW == 2 ? i : 0]; }
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         // branch-free: out-of-range lanes load a safe element (column c0 exists because m > 0) and discard it
@@ -113,6 +162,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         meta[i] = ok ? (uint32_t)(init_row ? col : col - c0) & 0xffffu : 0xffffu;
         if ((i & (KW == 2 ? 1 : 3)) == (KW == 2 ? 1 : 3)) __builtin_amdgcn_sched_barrier(0);  // few items in flight
     }
+    }
     // which digits vary over the row?
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -127,6 +177,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     const uint32_t diff0 = misc[8] ^ misc[9];
     const uint32_t diff1 = (KW == 2) ? (misc[10] ^ misc[11]) : 0u;
 
+#ifndef FZ_ABL_NOPASS  // FZ_ABL_*: diagnostic ablation builds (tools/ablate); never defined in the product build
     for (int pass = 0; pass < 4 * KW; ++pass) {
         const int shift = (pass & 3) * 8;
         const bool hi = (KW == 2) && pass >= 4;
@@ -140,20 +191,22 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         for (int i = 0; i < E; ++i) {
             const uint32_t kw = hi ? k1[KW == 2 ? i : 0] : k0[i];
             const uint32_t d = (kw >> shift) & 0xffu;
+            // wave64 match-any on the 8 digit bits, 4 VALU per bit: sign-extended bit (0 / -1), ballot, and
+            // mask &= ~(ballot ^ sext) as one v_bitop3 per 32-lane half
             uint32_t mlo = 0xffffffffu, mhi = 0xffffffffu;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const unsigned long long bal = __ballot(bit);
-                const uint32_t neg = bit ? 0u : 0xffffffffu;
-                mlo &= ((uint32_t)bal) ^ neg;
-                mhi &= ((uint32_t)(bal >> 32)) ^ neg;
+                const uint32_t sx = (uint32_t)__builtin_amdgcn_sbfe((int)kw, (unsigned)(shift + b), 1u);
+                const unsigned long long bal = __ballot(sx != 0u);
+                mlo &= ~(((uint32_t)bal) ^ sx);
+                mhi &= ~(((uint32_t)(bal >> 32)) ^ sx);
             }
             const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
             const uint32_t npeer = __popc(mlo) + __popc(mhi);
             const uint32_t old = my[d];
             if (below == 0) my[d] = old + npeer;
-            meta[i] = (meta[i] & 0xffffu) | ((old + below) << 16);
+            // bytes {3,2} <- (old+below), bytes {1,0} <- payload : one v_perm_b32
+            meta[i] = __builtin_amdgcn_perm(old + below, meta[i], 0x05040100u);
             // opaque to the optimiser: otherwise hipcc keeps old, below, payload and &my[d] in four separate
             // registers per item across the barrier (6.6 VGPRs/item -> scratch spills at E = 28)
             asm volatile("" : "+v"(meta[i]));
@@ -181,6 +234,9 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             for (int ww = 0; ww < NW; ++ww) cnt[ww * 256 + threadIdx.x] += base;
         }
         __syncthreads();
+#ifdef FZ_ABL_RANKONLY
+        continue;
+#endif
         // ---- 3. destination, exchange --------------------------------------------------
         // (sched_barrier every 4 items: without it hipcc hoists all E LDS addresses/values and spills)
 #pragma unroll
@@ -189,7 +245,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             asm volatile("" : "+v"(kw));  // recompute the digit here instead of keeping &my[d] alive per item
             const uint32_t d = (kw >> shift) & 0xffu;
             const uint32_t dst = my[d] + (meta[i] >> 16);
-            meta[i] = (meta[i] & 0xffffu) | (dst << 16);
+            meta[i] = __builtin_amdgcn_perm(dst, meta[i], 0x05040100u);
             asm volatile("" : "+v"(meta[i]));
             exch[dst] = k0[i];
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -228,6 +284,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         }
         __syncthreads();
     }
+#endif  // FZ_ABL_NOPASS
 
     // ---- output (coalesced: consecutive lanes = consecutive ranks) -------------------------
     const int lim = m < a.out_limit ? m : a.out_limit;
@@ -239,12 +296,21 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     int32_t* __restrict__ o_rank = a.rank ? a.rank + (size_t)row * a.out_row_stride : nullptr;
     const int32_t* __restrict__ cmap = a.colmap ? a.colmap + (size_t)row * a.colmap_row_stride : nullptr;
     const int64_t* __restrict__ imap = a.idmap ? a.idmap + krow : nullptr;
+    // rank = inverse permutation.  Scattering it straight to HBM costs as much as the four radix passes
+    // (27,942 random 4-byte writes per row); it is inverted in LDS instead and stored coalesced.
+    const bool rank_via_lds = o_rank && !cmap && a.chunks == 1;   // block-uniform
+    const bool full_row = (m == a.n_total) && !init_row && !a.init_rank;   // a gathered/placed sequence may skip columns
+    if (rank_via_lds && !full_row) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) exch[w * E * 64 + i * 64 + lane] = 0xffffffffu;   // columns outside the sequence
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         const int p = w * E * 64 + i * 64 + lane;
         if (p < lim) {
             int col = (int)(meta[i] & 0xffffu);
-            if (!init_row) col += c0;
+            if (!init_row && !a.init_rank) col += c0;
             const int oc = cmap ? cmap[col] : col;  // -1 = padding candidate of a short top-k chunk
             if (o_order) o_order[p] = oc;
             if (o_ids) o_ids[p] = imap ? imap[elem(col)] : (oc < 0 ? (int64_t)-1 : a.id_base + (int64_t)oc);
@@ -252,9 +318,23 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
                 if (KW == 1) o_kf[p] = desc_key_f32_inv(k0[i]);
                 else o_kd[p] = desc_key_f64_inv(((uint64_t)k1[KW == 2 ? i : 0] << 32) | (uint64_t)k0[i]);
             }
-            if (o_rank && oc >= 0) o_rank[oc] = p;
+#ifndef FZ_ABL_NORANKSCATTER
+            if (rank_via_lds) exch[col] = (uint32_t)p;          // col < n_total <= T*E
+            else if (o_rank && oc >= 0) o_rank[oc] = p;
+#endif
         }
         if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (rank_via_lds) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int j = w * E * 64 + i * 64 + lane;
+            if (j < a.n_total) {
+                const uint32_t r = exch[j];
+                if (full_row || r != 0xffffffffu) o_rank[j] = (int32_t)r;
+            }
+        }
     }
 }
 
@@ -318,6 +398,20 @@ extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* 
     if (n > (key_bits == 32 ? 35840 : 28672)) return FZ_ERR_UNSUPPORTED;
     SortArgs a{};
     a.keys = keys; a.init_order = init_order; a.row_len = row_len;
+    a.n_total = n; a.key_row_stride = ld; a.seg_len = n; a.seg_stride = 0;
+    a.chunks = 1; a.chunk_len = n;
+    a.order = order; a.sorted_keys = sorted_keys; a.rank = rank;
+    a.out_row_stride = ld; a.out_chunk_stride = 0; a.out_limit = n;
+    return launch_sort(a, key_bits / 32, rows, n, as_stream(stream));
+}
+
+extern "C" int fz_sort_rows_desc_placed(const void* keys, int key_bits, const int32_t* init_rank, const int32_t* row_len, int rows,
+                                        int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream) {
+    if (!keys || !init_rank || (key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
+    if (rows == 0 || n == 0) return FZ_OK;
+    if (n > (key_bits == 32 ? 35840 : 28672)) return FZ_ERR_UNSUPPORTED;
+    SortArgs a{};
+    a.keys = keys; a.init_rank = init_rank; a.row_len = row_len;
     a.n_total = n; a.key_row_stride = ld; a.seg_len = n; a.seg_stride = 0;
     a.chunks = 1; a.chunk_len = n;
     a.order = order; a.sorted_keys = sorted_keys; a.rank = rank;

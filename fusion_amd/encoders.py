@@ -88,6 +88,26 @@ class DenseEncoder(_Base):
         return (h * m).sum(1) / m.sum(1).clamp_min(1e-9)   # sentence-transformers Pooling(mean)
 
     @torch.no_grad()
+    def encode_ids_bucketed(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, lengths, n_buckets: int = 8) -> torch.Tensor:
+        """Same result as encode_ids, without paying for padding: sequences are sorted by length (as
+        SentenceTransformer.encode does, hybrid.py:101-102) and run in `n_buckets` sub-batches, each trimmed to its own
+        longest sequence.  `lengths` is the HOST array of token counts (known from tokenisation: no device sync)."""
+        import numpy as np
+        lengths = np.asarray(lengths)
+        n = len(lengths)
+        order = np.argsort(-lengths, kind="stable")
+        out = torch.empty((n, self.dim), dtype=torch.float32, device=self._device)
+        per = -(-n // max(1, n_buckets))
+        for s in range(0, n, per):
+            idx = order[s: s + per]
+            L = int(lengths[idx[0]])
+            sel = torch.from_numpy(idx).to(self._device, non_blocking=True)
+            ids = input_ids.index_select(0, sel)[:, :L]
+            mask = attention_mask.index_select(0, sel)[:, :L]
+            out.index_copy_(0, sel, self.encode_ids(ids, mask).float())
+        return out
+
+    @torch.no_grad()
     def encode(self, sentences: list[str], batch_size: int = 64, query_mode: bool = True, **_) -> torch.Tensor:
         out = torch.empty((len(sentences), self.dim), dtype=torch.float32, device=self._device)
         for idx, ids, mask in self._batches(sentences, batch_size, 512):

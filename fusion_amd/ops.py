@@ -152,8 +152,10 @@ def sort_max_n(dtype=torch.float32) -> int:
 
 
 def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, row_len: torch.Tensor | None = None,
-                   want_order=True, want_keys=True, want_rank=False):
+                   want_order=True, want_keys=True, want_rank=False, init_rank: torch.Tensor | None = None):
     """Stable descending row sort (Python sorted(reverse=True): bm25.py:104, hybrid.py:306).
+    Incoming sequence: identity (default), `init_order` (column at each sequence position) or `init_rank`
+    (sequence position of each column: a rank plane; read coalesced, the fast form).
     Returns (order|None, sorted_keys|None, rank|None); order/sorted_keys entries beyond row_len are -1 / -inf,
     rank entries of elements outside the sequence are -1."""
     _dev(keys, None, "sort_rows_desc(keys)")
@@ -164,7 +166,9 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
     ld = _ld(keys)
     dev = keys.device
 
-    partial = row_len is not None or init_order is not None  # some slots may stay unwritten: pre-fill them
+    if init_order is not None and init_rank is not None:
+        raise ValueError("pass init_order or init_rank, not both")
+    partial = row_len is not None or init_order is not None or init_rank is not None  # some slots may stay unwritten: pre-fill them
 
     def mk(dtype, fill):
         shape = (max(rows, 1), ld)
@@ -182,8 +186,18 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
     if row_len is not None:
         _dev(row_len, torch.int32, "row_len")
         row_len = row_len.contiguous()
-    check(_lib.lib().fz_sort_rows_desc(_ptr(keys), 32 if keys.dtype == torch.float32 else 64, _ptr(init_order), _ptr(row_len),
-                                       rows, n, ld, _ptr(order), _ptr(sk), _ptr(rank), _stream(keys)), "fz_sort_rows_desc")
+    bits = 32 if keys.dtype == torch.float32 else 64
+    if init_rank is not None:
+        _dev(init_rank, torch.int32, "init_rank")
+        if _ld(init_rank) != ld and rows > 1:
+            t = mk(torch.int32, -1)
+            t.copy_(init_rank)
+            init_rank = t
+        check(_lib.lib().fz_sort_rows_desc_placed(_ptr(keys), bits, _ptr(init_rank), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk),
+                                                  _ptr(rank), _stream(keys)), "fz_sort_rows_desc_placed")
+    else:
+        check(_lib.lib().fz_sort_rows_desc(_ptr(keys), bits, _ptr(init_order), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk),
+                                           _ptr(rank), _stream(keys)), "fz_sort_rows_desc")
     return order, sk, rank
 
 

@@ -190,13 +190,14 @@ class Aggregator:
             fused = ops.fuse_none([s.scores for s in S], ranks, [1.0] * len(S))
 
         if all_full:
-            ins, U = S[0].order, None                        # first-insertion order == system 0's ranking
+            # first-insertion order == system 0's ranking: its rank plane places every doc (coalesced, no gather)
             lens_out = torch.full((Q,), N, dtype=torch.int32, device=dev)
+            order, sk, _ = ops.sort_rows_desc(fused, init_rank=S[0].rank)
         else:
             lens = torch.stack([s.lens for s in S]).contiguous()
             ins, U = ops.insertion_order([s.order for s in S], lens, N)
             lens_out = U
-        order, sk, _ = ops.sort_rows_desc(fused, init_order=ins, row_len=U)
+            order, sk, _ = ops.sort_rows_desc(fused, init_order=ins, row_len=U)
         return FusedResult(order=order, scores=sk, lens=lens_out, ids=S[0].ids)
 
     @staticmethod

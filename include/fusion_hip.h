@@ -89,6 +89,13 @@ int fz_sort_max_n(void);
 int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows, int n,
                       int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream);
 
+/* Same sort, incoming sequence given the other way round: init_rank[row][j] = position of column j in the incoming
+ * sequence (-1 = not in it); restricted to the columns in the sequence it is a bijection onto [0, row_len[row]).
+ * This is what a rank plane IS, so the fused-list ordering (ties keep system 0's order) needs no gather:
+ * keys and positions are read coalesced and placed through LDS. */
+int fz_sort_rows_desc_placed(const void* keys, int key_bits, const int32_t* init_rank, const int32_t* row_len, int rows, int n,
+                             int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream);
+
 /* ---- K5b: rank-based fusion, hybrid.py:206-211,248-252,301-304 ------------------------- */
 /* fused[q][j] = sum over systems s (in the given order, fp64, starting from 0.0) of
  *   rrf: 1/(60+rank+1)     bcf: (len-rank+1)/len      for rank >= 0;  -inf if j is in no list.

@@ -96,6 +96,25 @@ def test_sort_gathered_sequence(ops, oracle, n, dtype):
     np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)
 
 
+@pytest.mark.parametrize("n,dtype", [(1, np.float32), (300, np.float32), (5000, np.float64), (27942, np.float32), (27942, np.float64)])
+def test_sort_placed_sequence(ops, oracle, n, dtype):
+    """init_rank form (coalesced, placed through LDS) == init_order form == oracle."""
+    rng = np.random.default_rng(n + 1)
+    rows = 4
+    k = np.round(rng.normal(0, 1, (rows, n)), 1).astype(dtype)
+    init = np.stack([rng.permutation(n) for _ in range(rows)]).astype(np.int32)
+    lens = np.array([n, max(1, n // 2), 1, max(1, n - 1)], dtype=np.int32)
+    irank = np.full((rows, n), -1, dtype=np.int32)
+    for r in range(rows):
+        init[r, lens[r]:] = -1
+        irank[r, init[r, :lens[r]]] = np.arange(lens[r], dtype=np.int32)
+    order, sk, rank = ops.sort_rows_desc(plane(ops, k), init_rank=plane(ops, irank), row_len=dev(lens), want_rank=True)
+    e_order, e_sk, e_rank = oracle.sort_rows_desc(k, init_order=init, row_len=lens, want_rank=True)
+    np.testing.assert_array_equal(order.cpu().numpy(), e_order)
+    np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)
+    np.testing.assert_array_equal(rank.cpu().numpy(), e_rank)
+
+
 def synth_systems(rng, S, Q, N, partial=True):
     planes, ranks, orders, lens = [], [], [], np.zeros((S, Q), dtype=np.int32)
     for s in range(S):
@@ -388,7 +407,9 @@ def test_full_size_rrf_pipeline_properties(ops):
     fused = ops.fuse_rank([ra, rb], lens, "rrf")
     ref = 1.0 / (61.0 + ra.double()) + 1.0 / (61.0 + rb.double())                    # same fp64 expression order
     assert bool((fused == ref).all())
-    of, kf, _ = ops.sort_rows_desc(fused, init_order=oa)
+    of, kf, _ = ops.sort_rows_desc(fused, init_rank=ra)
+    of2, kf2, _ = ops.sort_rows_desc(fused, init_order=oa)
+    assert bool((of == of2).all()) and bool((kf == kf2).all())                       # placed == gathered
     assert bool((kf[:, :-1] >= kf[:, 1:]).all())
     assert bool((torch.sort(of.long(), dim=1).values == torch.arange(N, device="cuda")).all())
     # swapping the systems changes nothing but the tie-break (checksum of the fused multiset)

@@ -176,3 +176,17 @@ def test_allgather_topk_gloo_world2():
     for p in ps: p.join(30)
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] and r[2] for r in res), res      # sharded top-k == unsharded top-k, on every rank
+
+
+def test_bucketed_encode_equals_padded_encode():
+    from fusion_amd import encoders
+    enc = encoders.random_init("dpr", device="cpu", size="tiny")
+    rng = np.random.default_rng(0)
+    n, L = 37, 24
+    lens = rng.integers(3, L + 1, n)
+    ids = rng.integers(7, 500, (n, L))
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    ids = np.where(mask == 1, ids, 1)
+    a = enc.encode_ids(torch.from_numpy(ids), torch.from_numpy(mask))
+    b = enc.encode_ids_bucketed(torch.from_numpy(ids), torch.from_numpy(mask), lens, n_buckets=5)
+    assert torch.allclose(a, b, atol=2e-6)     # padding never attends: trimming it changes nothing but rounding
