@@ -157,89 +157,187 @@ struct NsfArgs {
     int S, N, ld;
 };
 
-template <int NORM, int E4 /* float4 per thread */, bool VEC>
-__global__ __launch_bounds__(1024) void fuse_nsf_row_kernel(NsfArgs a, float* __restrict__ fused) {
-    constexpr int T = 1024;
-    __shared__ double red_d[T / 64];
-    __shared__ float red_f[2 * T / 64];
+// Combined block reduction of up to 3 doubles (one barrier pair for all statistics of a row).
+template <int THREADS, int NV>
+__device__ __forceinline__ void block_sum_n(double (&v)[NV], double* red /* NV*THREADS/64 */) {
+    constexpr int NW = THREADS / 64;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_reduce_sum(v[k]);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[k * NW + w] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) s += red[k * NW + i];  // fixed order: deterministic
+        v[k] = s;
+    }
+}
+
+// Barrier that does NOT drain pending LDS-DMA (a __syncthreads() would: hipcc emits vmcnt(0) in front of it while a
+// global_load_lds is in flight, which would serialise the prefetch below).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int THREADS>
+__device__ __forceinline__ void block_minmax_nan(float& mn, float& mx, float& nanflag, float* red /* 3*THREADS/64 */) {
+    constexpr int NW = THREADS / 64;
+    mn = wave_reduce_min(mn); mx = wave_reduce_max(mx); nanflag = wave_reduce_max(nanflag);
+    const int w = threadIdx.x >> 6;
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) { red[w] = mn; red[NW + w] = mx; red[2 * NW + w] = nanflag; }
+    lds_barrier();
+    mn = red[0]; mx = red[NW]; nanflag = red[2 * NW];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) { mn = fminf(mn, red[i]); mx = fmaxf(mx, red[NW + i]); nanflag = fmaxf(nanflag, red[2 * NW + i]); }
+}
+template <int THREADS, int NV>
+__device__ __forceinline__ void block_sum_n_nodrain(double (&v)[NV], double* red /* NV*THREADS/64 */) {
+    constexpr int NW = THREADS / 64;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_reduce_sum(v[k]);
+    const int w = threadIdx.x >> 6;
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[k * NW + w] = v[k];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) s += red[k * NW + i];  // fixed order: deterministic
+        v[k] = s;
+    }
+}
+
+// K4.  One workgroup of T threads per query; thread t owns columns {4*(t + T*i) .. +3}, i < E4.
+//   * the accumulator and the CURRENT system's row live in registers (2*4*E4 VGPRs);
+//   * DMA = true: the NEXT system's row streams HBM -> LDS by global_load_lds (no VGPRs, asynchronous) while the
+//     current one is reduced across the workgroup and transformed; each wave later reads back exactly the 1-KiB
+//     pieces it issued itself, so the only synchronisation is that wave's own vmcnt;
+//   * every plane is read from HBM once: (S+1)*N*4 bytes per query.
+// VALID = rank planes carry validity (partial lists); needs VEC-style planes: ld % 4 == 0, 16-B aligned bases,
+// so a float4 starting below N never leaves the padded row.
+template <int NORM, int T /* threads */, int E4 /* float4 per thread */, bool VEC, bool VALID, bool DMA>
+__global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __restrict__ fused) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* rowbuf = reinterpret_cast<float*>(smem_raw);                                 // DMA: [T*E4*4] floats
+    double* red_d = reinterpret_cast<double*>(smem_raw + (DMA ? (size_t)T * E4 * 16 : 0)); // [3*T/64]
+    float* red_f = reinterpret_cast<float*>(red_d + 3 * T / 64);                        // [3*T/64]
     const int q = blockIdx.x;
     const int N = a.N;
     const size_t rowoff = (size_t)q * a.ld;
+    const int lane = threadIdx.x & 63;
 
     float acc[E4][4];
-    bool present[E4][4];
+    uint64_t present = 0ull;   // VALID only: some system lists the column (bit 4*i+c)
 #pragma unroll
     for (int i = 0; i < E4; ++i)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { acc[i][c] = 0.0f; present[i][c] = false; }
+        for (int c = 0; c < 4; ++c) acc[i][c] = 0.0f;
 
-    for (int s = 0; s < a.S; ++s) {
+    float v[E4][4];
+    uint64_t ok = 0ull;        // column inside the row (and listed by the system when VALID)
+
+    auto dma_row = [&](int s) {   // HBM -> LDS, one 1-KiB piece per wave-instruction; lanes past the row end stay off
         const float* __restrict__ x = a.planes[s] + rowoff;
-        const int32_t* __restrict__ rk = a.ranks[s] ? a.ranks[s] + rowoff : nullptr;
-        float v[E4][4];
-        bool ok[E4][4];
 #pragma unroll
         for (int i = 0; i < E4; ++i) {
             const int j0 = 4 * (threadIdx.x + T * i);
+            if (j0 < N) {
+                // LDS destination = wave-uniform base + lane*16: pass the address of lane 0's slot
+                __builtin_amdgcn_global_load_lds(x + j0, (__attribute__((address_space(3))) void*)(rowbuf + 4 * (threadIdx.x - lane + T * i)), 16, 0, 0);
+            }
+        }
+    };
+    auto take_row = [&](int s) {   // current row -> registers (+ validity mask)
+        const float* __restrict__ x = a.planes[s] + rowoff;
+        const int32_t* __restrict__ rk = (VALID && a.ranks[s]) ? a.ranks[s] + rowoff : nullptr;
+        ok = 0ull;
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own pieces have landed
+#pragma unroll
+        for (int i = 0; i < E4; ++i) {
+            const int j0 = 4 * (threadIdx.x + T * i);
+            uint32_t m = 0u;
             if (VEC) {
-                if (j0 + 3 < N) {
-                    float4 f = *reinterpret_cast<const float4*>(x + j0);
+                if (j0 < N) {
+                    const float4 f = DMA ? *reinterpret_cast<const float4*>(rowbuf + 4 * (threadIdx.x + T * i))
+                                         : *reinterpret_cast<const float4*>(x + j0);
                     v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
-                    ok[i][0] = ok[i][1] = ok[i][2] = ok[i][3] = true;
-                    if (rk) {
-                        int4 r = *reinterpret_cast<const int4*>(rk + j0);
-                        ok[i][0] = r.x >= 0; ok[i][1] = r.y >= 0; ok[i][2] = r.z >= 0; ok[i][3] = r.w >= 0;
+                    const int rem = N - j0;
+                    m = rem >= 4 ? 0xfu : ((1u << rem) - 1u);
+                    if (VALID && rk) {
+                        const int4 r = *reinterpret_cast<const int4*>(rk + j0);
+                        m &= (r.x >= 0 ? 1u : 0u) | (r.y >= 0 ? 2u : 0u) | (r.z >= 0 ? 4u : 0u) | (r.w >= 0 ? 8u : 0u);
                     }
                 } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        bool in = j0 + c < N;
-                        v[i][c] = in ? x[j0 + c] : 0.0f;
-                        ok[i][c] = in && (!rk || rk[j0 + c] >= 0);
-                    }
+                    v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    bool in = j0 + c < N;
+                    const bool in = j0 + c < N;
                     v[i][c] = in ? x[j0 + c] : 0.0f;
-                    ok[i][c] = in && (!rk || rk[j0 + c] >= 0);
+                    if (in && (!(VALID && rk) || rk[j0 + c] >= 0)) m |= 1u << c;
                 }
             }
+            ok |= (uint64_t)m << (4 * i);
+        }
+    };
+
+    if (DMA) dma_row(0);
+    for (int s = 0; s < a.S; ++s) {
+        take_row(s);
+        if (DMA && s + 1 < a.S) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // our ds_reads of row s are done before the DMA overwrites the slots
+            dma_row(s + 1);                                       // in flight during the reduction + transform below
         }
         float sa = 0.f, sb = 0.f;
         if (NORM == FZ_NORM_MINMAX) {
-            float mn = INFINITY, mx = -INFINITY;
-            bool nan = false;
+            float mn = INFINITY, mx = -INFINITY, nanf_ = 0.f;
 #pragma unroll
             for (int i = 0; i < E4; ++i)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (ok[i][c]) { nan |= (v[i][c] != v[i][c]); mn = fminf(mn, v[i][c]); mx = fmaxf(mx, v[i][c]); }
-            block_minmax<T>(mn, mx, red_f);
-            int anynan = __syncthreads_or(nan ? 1 : 0);
-            sa = anynan ? __uint_as_float(0x7fc00000u) : mn;
-            sb = anynan ? __uint_as_float(0x7fc00000u) : mx;
+                {   // branch-free: unlisted / padding columns contribute the identity
+                    const bool in = (ok >> (4 * i + c)) & 1ull;
+                    const float x = v[i][c];
+                    mn = fminf(mn, in ? x : INFINITY);
+                    mx = fmaxf(mx, in ? x : -INFINITY);
+                    nanf_ = (in && x != x) ? 1.f : nanf_;
+                }
+            block_minmax_nan<T>(mn, mx, nanf_, red_f);
+            sa = nanf_ > 0.f ? __uint_as_float(0x7fc00000u) : mn;   // torch.min/max propagate NaN
+            sb = nanf_ > 0.f ? __uint_as_float(0x7fc00000u) : mx;
         } else if (NORM == FZ_NORM_ZSCORE) {
-            double sum = 0.0, cnt = 0.0;
+            // one pass, shifted by x0 = the row's column-0 score (any finite sample of the row makes the one-pass
+            // variance stable; a uniform scalar load, no reduction):
+            //   d = x - x0;  mean = x0 + sum(d)/n;  var = (sum(d^2) - sum(d)^2/n)/(n-1)       (all fp64)
+            float x0c = a.planes[s][rowoff];
+            if (!(x0c == x0c) || fabsf(x0c) == INFINITY) x0c = 0.f;
+            const double x0 = (double)x0c;
+            double st[3] = {0.0, 0.0, 0.0};   // sum d, sum d^2, count
 #pragma unroll
             for (int i = 0; i < E4; ++i)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (ok[i][c]) { sum += (double)v[i][c]; cnt += 1.0; }
-            sum = block_sum<T>(sum, red_d);
-            cnt = block_sum<T>(cnt, red_d);
-            double mean = cnt > 0.0 ? sum / cnt : (double)NAN;
-            double ss = 0.0;
-#pragma unroll
-            for (int i = 0; i < E4; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (ok[i][c]) { double d = (double)v[i][c] - mean; ss += d * d; }
-            ss = block_sum<T>(ss, red_d);
-            double var = cnt > 1.0 ? ss / (cnt - 1.0) : (double)NAN;
+                {
+                    const bool in = (ok >> (4 * i + c)) & 1ull;
+                    const double d = in ? (double)v[i][c] - x0 : 0.0;
+                    st[0] += d; st[1] += d * d; st[2] += in ? 1.0 : 0.0;
+                }
+            block_sum_n_nodrain<T, 3>(st, red_d);
+            const double n = st[2];
+            const double mean = n > 0.0 ? x0 + st[0] / n : (double)NAN;
+            const double var = n > 1.0 ? (st[1] - st[0] * st[0] / n) / (n - 1.0) : (double)NAN;
             sa = (float)mean;
-            sb = (float)sqrt(var);
+            sb = (float)sqrt(var < 0.0 ? 0.0 : var);
         }
         const float w = a.w[s];
         const float* __restrict__ distr = a.distr[s];
@@ -248,12 +346,23 @@ __global__ __launch_bounds__(1024) void fuse_nsf_row_kernel(NsfArgs a, float* __
         for (int i = 0; i < E4; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (ok[i][c]) {
-                    float t = transform<NORM>(v[i][c], sa, sb, distr, P);
-                    float prod = t * w;           // fl32(t * fl32(w))      hybrid.py:291 under NumPy 2
-                    acc[i][c] = acc[i][c] + prod; // fl32(acc + prod)        hybrid.py:304
-                    present[i][c] = true;
+            {
+                // percentile modes walk a table: keep them predicated; the arithmetic modes are branch-free
+                // (!VALID: padding columns compute garbage that is never stored)
+                const bool in = !VALID || ((ok >> (4 * i + c)) & 1ull);
+                if (NORM == FZ_NORM_PERCENTILE || NORM == FZ_NORM_NCE) {
+                    if (in) {
+                        const float t = transform<NORM>(v[i][c], sa, sb, distr, P);
+                        const float prod = t * w;
+                        acc[i][c] = acc[i][c] + prod;
+                    }
+                } else {
+                    const float t = transform<NORM>(v[i][c], sa, sb, distr, P);
+                    const float prod = t * w;                       // fl32(t * fl32(w))      hybrid.py:291 under NumPy 2
+                    acc[i][c] = in ? acc[i][c] + prod : acc[i][c];  // fl32(acc + prod)        hybrid.py:304
                 }
+            }
+        if (VALID) present |= ok;
     }
     float* __restrict__ out = fused + rowoff;
 #pragma unroll
@@ -261,9 +370,10 @@ __global__ __launch_bounds__(1024) void fuse_nsf_row_kernel(NsfArgs a, float* __
         const int j0 = 4 * (threadIdx.x + T * i);
         float o[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) o[c] = present[i][c] ? acc[i][c] : -INFINITY;
-        if (VEC && j0 + 3 < N) *reinterpret_cast<float4*>(out + j0) = make_float4(o[0], o[1], o[2], o[3]);
-        else {
+        for (int c = 0; c < 4; ++c) o[c] = (!VALID || ((present >> (4 * i + c)) & 1ull)) ? acc[i][c] : -INFINITY;
+        if (VEC) {
+            if (j0 < N) *reinterpret_cast<float4*>(out + j0) = make_float4(o[0], o[1], o[2], o[3]);   // may touch padding columns [N, ld)
+        } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (j0 + c < N) out[j0 + c] = o[c];
@@ -442,19 +552,33 @@ extern "C" int fz_row_stats_f32(const float* scores, const int32_t* rank, int ro
     return FZ_OK;
 }
 
+template <int NORM, int TT, int E4, bool VEC, bool VALID, bool DMA>
+static int launch_nsf_cfg(const NsfArgs& a, int Q, float* fused, hipStream_t st) {
+    constexpr size_t lds = (DMA ? (size_t)TT * E4 * 16 : 0) + 3 * (TT / 64) * (sizeof(double) + sizeof(float)) + 64;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        FZ_HIP_TRY(hipFuncSetAttribute((const void*)fuse_nsf_row_kernel<NORM, TT, E4, VEC, VALID, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    fuse_nsf_row_kernel<NORM, TT, E4, VEC, VALID, DMA><<<Q, TT, lds, st>>>(a, fused);
+    return 0;
+}
+
 template <int NORM>
 static int launch_nsf(const NsfArgs& a, int Q, float* fused, hipStream_t st) {
-    const bool vec = (a.ld % 4 == 0) && ((uintptr_t)fused % 16 == 0);
-    bool al = vec;
-    for (int s = 0; s < a.S; ++s) al = al && ((uintptr_t)a.planes[s] % 16 == 0) && (!a.ranks[s] || (uintptr_t)a.ranks[s] % 16 == 0);
-    const int need4 = (a.N + 4095) / 4096;  // float4 per thread at 1024 threads
-#define FZ_NSF_CASE(E4)                                                                   \
-    if (need4 <= E4) {                                                                    \
-        if (al) fuse_nsf_row_kernel<NORM, E4, true><<<Q, 1024, 0, st>>>(a, fused);        \
-        else fuse_nsf_row_kernel<NORM, E4, false><<<Q, 1024, 0, st>>>(a, fused);          \
-        return 0;                                                                         \
+    bool al = (a.ld % 4 == 0) && ((uintptr_t)fused % 16 == 0);
+    bool valid = false;
+    for (int s = 0; s < a.S; ++s) {
+        al = al && ((uintptr_t)a.planes[s] % 16 == 0) && (!a.ranks[s] || (uintptr_t)a.ranks[s] % 16 == 0);
+        valid = valid || a.ranks[s];
     }
-    FZ_NSF_CASE(1) FZ_NSF_CASE(2) FZ_NSF_CASE(4) FZ_NSF_CASE(7) FZ_NSF_CASE(8)
+#define FZ_NSF_CASE(TT, E4)                                                                           \
+    if (a.N <= TT * E4 * 4) {                                                                         \
+        if (al && !valid) return launch_nsf_cfg<NORM, TT, E4, true, false, true>(a, Q, fused, st);    \
+        if (al) return launch_nsf_cfg<NORM, TT, E4, true, true, false>(a, Q, fused, st);              \
+        return launch_nsf_cfg<NORM, TT, E4, false, true, false>(a, Q, fused, st);                     \
+    }
+    FZ_NSF_CASE(256, 1) FZ_NSF_CASE(256, 4) FZ_NSF_CASE(512, 4) FZ_NSF_CASE(1024, 4) FZ_NSF_CASE(1024, 7) FZ_NSF_CASE(1024, 8)
 #undef FZ_NSF_CASE
     return 1;  // row too long for the register-resident kernel
 }

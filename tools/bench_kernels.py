@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Per-kernel timings at BASELINE.json sizes (one JSON line per kernel). Usage: python tools/bench_kernels.py [names...]"""
+import json, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fusion_amd import ops
+
+HBM, F32, F16 = 8000e9, 157.3e12, 2500e12
+
+
+def timeit(f, n=10, warm=3):
+    for _ in range(warm): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def emit(name, ms, work, peak, unit, **kw):
+    ach = work / (ms * 1e-3)
+    print(json.dumps(dict(kernel=name, ms=round(ms, 4), achieved=round(ach / (1e12 if unit == "TFLOP/s" else 1e9), 2), unit=unit,
+                          frac=round(ach / peak, 4), **kw)), flush=True)
+
+
+def rand_plane(Q, N, g, scale=1.0, shift=0.0):
+    p = ops.alloc_plane(Q, N, torch.float32, "cuda")
+    p.copy_(torch.randn((Q, N), generator=g, device="cuda") * scale + shift)
+    return p
+
+
+def bench_nsf(Q=1024, N=27942, S=4):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    planes = [rand_plane(Q, N, g, s + 1, s) for s in range(S)]
+    out = ops.alloc_plane(Q, N, torch.float32, "cuda")
+    w = [0.25] * S
+    for norm in ("min-max", "z-score", "arctan"):
+        ms = timeit(lambda: ops.fuse_nsf(planes, None, w, norm, out=out))
+        emit(f"fuse_nsf_row_kernel<{norm}> S={S}", ms, (S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
+    ranks = [ops.sort_rows_desc(p, want_order=False, want_keys=False, want_rank=True)[2] for p in planes]
+    ms = timeit(lambda: ops.fuse_nsf(planes, ranks, w, "min-max", out=out))
+    emit(f"fuse_nsf_row_kernel<min-max,+validity> S={S}", ms, (2 * S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
+    lens = torch.full((S, Q), N, dtype=torch.int32, device="cuda")
+    for m in ("rrf", "bcf"):
+        ms = timeit(lambda: ops.fuse_rank(ranks, lens, m))
+        emit(f"fuse_rank_kernel<{m}> S={S}", ms, (S * 4 + 8) * Q * N, HBM, "GB/s", Q=Q, N=N)
+    ms = timeit(lambda: ops.fuse_none(planes, None, w))
+    emit(f"fuse_none_kernel S={S}", ms, (S * 4 + 8) * Q * N, HBM, "GB/s", Q=Q, N=N)
+    ms = timeit(lambda: ops.row_stats(planes[0], None, "z-score"))
+    emit("row_stats_kernel<z-score>", ms, Q * N * 4, HBM, "GB/s", Q=Q, N=N)
+
+
+def bench_gemm(Q=1024, N=27942, d=768):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    Qn = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
+    Dn = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
+    out = ops.alloc_plane(Q, N, torch.float32, "cuda")
+    ms = timeit(lambda: ops.dot_scores(Qn, Dn, out=out), n=20)
+    emit("dot_scores_kernel", ms, 2.0 * Q * N * d, F32, "TFLOP/s", Q=Q, N=N, d=d)
+    for q in (195,):
+        Qs = Qn[:q].contiguous()
+        ms = timeit(lambda: ops.dot_scores(Qs, Dn), n=20)
+        emit("dot_scores_kernel", ms, 2.0 * q * N * d, F32, "TFLOP/s", Q=q, N=N, d=d)
+    ms = timeit(lambda: ops.normalize_rows(Dn))
+    emit("normalize_rows_kernel", ms, 2 * N * d * 4, HBM, "GB/s", rows=N, d=d)
+
+
+def bench_maxsim(N=27942, Qs=(195, 1024)):
+    rng = np.random.default_rng(0)
+    lens = np.clip(rng.normal(300, 120, N), 16, 512).astype(np.int64)
+    off = np.zeros(N + 1, dtype=np.int64); off[1:] = np.cumsum(lens)
+    sumL = int(off[-1])
+    g = torch.Generator(device="cuda").manual_seed(2)
+    Dtok = torch.nn.functional.normalize(torch.randn((sumL, 128), generator=g, device="cuda"), dim=-1).half()
+    Doff = torch.from_numpy(off).cuda()
+    for Q in Qs:
+        Qtok = torch.nn.functional.normalize(torch.randn((Q, 64, 128), generator=g, device="cuda"), dim=-1).half()
+        out = ops.alloc_plane(Q, N, torch.float32, "cuda")
+        ms = timeit(lambda: ops.maxsim(Qtok, Dtok, Doff, out=out), n=3, warm=1)
+        emit("maxsim_kernel", ms, 2.0 * Q * 64 * sumL * 128, F16, "TFLOP/s", Q=Q, N=N, sumL=sumL)
+
+
+def bench_topk(Q=1024, n=8 * 28672, k=1000):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    S = ops.alloc_plane(Q, n, torch.float32, "cuda"); S.copy_(torch.rand((Q, n), generator=g, device="cuda"))
+    ms = timeit(lambda: ops.topk_rows(S, k), n=5)
+    emit("topk_rows (chunk-sort-truncate)", ms, Q * n * 4, HBM, "GB/s", Q=Q, n=n, k=k)
+
+
+def bench_mmarco(Q=1024, N=8841823 // 8, d=768, k=1000):
+    """One 1/8 shard of mMARCO (what each GPU does at G=8), without the all-gather."""
+    from fusion_amd.distributed import ShardedDenseIndex
+    g = torch.Generator(device="cuda").manual_seed(4)
+    Dn = torch.empty((N, d), dtype=torch.float32, device="cuda")
+    for c0 in range(0, N, 1 << 19):
+        c1 = min(N, c0 + (1 << 19))
+        Dn[c0:c1] = ops.normalize_rows(torch.randn((c1 - c0, d), generator=g, device="cuda"))
+    Qn = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
+    idx = ShardedDenseIndex(Dn, 0)
+    ms = timeit(lambda: idx.local_topk(Qn, k), n=2, warm=1)
+    emit("mmarco shard: GEMM+topk chunks", ms, 2.0 * Q * N * d, F32, "TFLOP/s", Q=Q, N=N, k=k)
+
+
+ALL = dict(nsf=bench_nsf, gemm=bench_gemm, maxsim=bench_maxsim, topk=bench_topk, mmarco=bench_mmarco)
+if __name__ == "__main__":
+    for n in (sys.argv[1:] or list(ALL)):
+        ALL[n]()
