@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 // ---- fp32 MFMA GEMM --------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;  // LDS row = 36 floats = 144 B
+constexpr int BM = 128, BK = 32, LDT = BK + 4;  // LDS row = 36 floats = 144 B; BN (128 or 64) is a template parameter
 
 struct GemmArgs {
     const float* A; int lda;   // queries  [Q][lda]
@@ -62,9 +62,13 @@ struct GemmArgs {
     int Q, N, d, QB, TN;
 };
 
+template <int BN>
 __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
+    constexpr int NI = BN / 64;          // MFMA tiles per wave along N (wave tile = 64 x BN/2)
+    constexpr int BROWS = BN / 32;       // staging float4 per thread for the corpus tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // [buf][A|B][128][LDT]
+    // [buf][A: 128 rows | B: BN rows][LDT]
+    constexpr int BUF = (BM + BN) * LDT;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
 
@@ -76,34 +80,35 @@ __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
 
     // staging: thread -> (row = tid/8 + 32*i, k4 = tid%8)
     const int srow = tid >> 3, sk = (tid & 7) * 4;
-    float4 ra[4], rb[4];
+    float4 ra[4], rb[BROWS];
     auto gload = [&](int kt) {
         const int k = kt * BK + sk;
         const bool kin = k < g.d;  // d % 4 == 0: a float4 is entirely inside or outside
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = srow + 32 * i;
-            const int qa = row0 + r, nb = col0 + r;
+            const int qa = row0 + srow + 32 * i;
             ra[i] = (kin && qa < g.Q) ? *reinterpret_cast<const float4*>(g.A + (size_t)qa * g.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            const int nb = col0 + srow + 32 * i;
             rb[i] = (kin && nb < g.N) ? *reinterpret_cast<const float4*>(g.B + (size_t)nb * g.ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto sstore = [&](int buf) {
-        float* As = lds + buf * (2 * BM * LDT);
+        float* As = lds + buf * BUF;
         float* Bs = As + BM * LDT;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = srow + 32 * i;
-            *reinterpret_cast<float4*>(As + r * LDT + sk) = ra[i];
-            *reinterpret_cast<float4*>(Bs + r * LDT + sk) = rb[i];
-        }
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDT + sk) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDT + sk) = rb[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NI];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
@@ -115,21 +120,21 @@ __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < KT) gload(kt + 1);
-        const float* As = lds + buf * (2 * BM * LDT) + (wr * 64 + fr) * LDT + fh;
-        const float* Bs = lds + buf * (2 * BM * LDT) + BM * LDT + (wc * 64 + fr) * LDT + fh;
+        const float* As = lds + buf * BUF + (wr * 64 + fr) * LDT + fh;
+        const float* Bs = lds + buf * BUF + BM * LDT + (wc * (BN / 2) + fr) * LDT + fh;
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
-            float4 a[2], b[2];
+            float4 a[2], b[NI];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const float4*>(As + mi * 32 * LDT + kg * 8);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const float4*>(Bs + ni * 32 * LDT + kg * 8);
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const float4*>(Bs + ni * 32 * LDT + kg * 8);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
+                    for (int ni = 0; ni < NI; ++ni) {
                         const float av = kk == 0 ? a[mi].x : kk == 1 ? a[mi].y : kk == 2 ? a[mi].z : a[mi].w;
                         const float bv = kk == 0 ? b[ni].x : kk == 1 ? b[ni].y : kk == 2 ? b[ni].z : b[ni].w;
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
@@ -143,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int c = col0 + wc * 64 + ni * 32 + (lane & 31);
+        for (int ni = 0; ni < NI; ++ni) {
+            const int c = col0 + wc * (BN / 2) + ni * 32 + (lane & 31);
             if (c < g.N) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -178,16 +183,23 @@ extern "C" int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int 
     g.A = Qn; g.lda = ldq; g.B = Dn; g.ldb = ldd; g.C = scores; g.ldc = lds;
     g.Q = Q; g.N = N; g.d = d;
     g.QB = (Q + BM - 1) / BM;
-    g.TN = (N + BN - 1) / BN;
+    // tile width: 128x128 tiles have the best MFMA:LDS ratio, 128x64 tiles halve the quantisation of the last
+    // round (two workgroups are resident per CU: 512 slots).  Pick the smaller modelled time (64-wide measured ~15 % dearer per flop).
+    const long slots = 512;
+    const long t128 = (long)g.QB * ((N + 127) / 128), t64 = (long)g.QB * ((N + 63) / 64);
+    const double c128 = (double)((t128 + slots - 1) / slots), c64 = 0.6 * (double)((t64 + slots - 1) / slots);
+    const int bn = (c64 < c128) ? 64 : 128;
+    g.TN = (N + bn - 1) / bn;
     const long nblk = 8L * g.QB * ((g.TN + 7) / 8);
     if (nblk > 0x7fffffffL) return FZ_ERR_UNSUPPORTED;
-    constexpr size_t lds_bytes = 2 * 2 * BM * LDT * sizeof(float);  // 73,728
     static bool attr_set = false;
     if (!attr_set) {
-        FZ_HIP_TRY(hipFuncSetAttribute((const void*)dot_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        FZ_HIP_TRY(hipFuncSetAttribute((const void*)dot_scores_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (BM + 128) * LDT * sizeof(float))));
+        FZ_HIP_TRY(hipFuncSetAttribute((const void*)dot_scores_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (BM + 64) * LDT * sizeof(float))));
         attr_set = true;
     }
-    dot_scores_kernel<<<(unsigned)nblk, 256, lds_bytes, as_stream(stream)>>>(g);
+    if (bn == 128) dot_scores_kernel<128><<<(unsigned)nblk, 256, 2 * (BM + 128) * LDT * sizeof(float), as_stream(stream)>>>(g);
+    else dot_scores_kernel<64><<<(unsigned)nblk, 256, 2 * (BM + 64) * LDT * sizeof(float), as_stream(stream)>>>(g);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }
