@@ -59,6 +59,8 @@ _PROTOS = {
     "fz_topk_rows_f32": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "fz_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "fz_bm25_scores_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "fz_tune_max_gold": (_i, []),
+    "fz_gold_ranks_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fz_fill_i32": (_i, [_vp, _sz, C.c_int32, _vp]),
     "fz_f64_to_f32": (_i, [_vp, _vp, _sz, _vp]),
 }

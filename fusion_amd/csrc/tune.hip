@@ -1,0 +1,124 @@
+// tune.hip -- N1: the linear-fusion weight sweep of hybrid.py:404-426 without re-fusing or sorting.
+//
+// Reference: for each of W weight vectors (21 / 231 / 1771 for S = 2 / 3 / 4, hybrid.py:405-409) it deep-copies all
+// ranked lists, re-normalises them, fuses, sorts and evaluates (hybrid.py:418-425): ~60 h of Python for LLeQA test.
+// Every metric of run_evaluation (metrics.py:40-136) is a function of the fused RANKS of the gold documents only, and
+//     rank(g) = #{ j : fused_j > fused_g  or  (fused_j == fused_g and pos_j < pos_g) }
+// (pos = first-insertion position: the stable-sort tie-break, hybrid.py:301-306).  So the normalised planes T_s are
+// computed ONCE (fz_fuse_nsf_f32 with weight 1) and this kernel only counts.  fused_j is evaluated with exactly the
+// arithmetic of the fusion kernel (fl32(t*w), sequential fl32 adds, unfused), so the ranks are identical to those
+// of the materialise-and-sort path.
+//
+// Mapping: grid (column chunks of 4096, queries); 256 threads x 16 columns; the chunk's S x 16 normalised scores and
+// 16 positions stay in registers for the whole sweep; per weight vector: S unfused mul+add per column, G compares,
+// wave reduction, one atomicAdd per wave and gold.
+#include "common.h"
+
+namespace fz {
+
+constexpr int TUNE_G = 8;        // gold documents per query handled per launch
+constexpr int TUNE_COLS = 16;    // columns per thread
+
+struct TuneArgs {
+    const float* T[FZ_MAX_SYSTEMS];   // normalised planes [Q][ld]; entries of docs a system does not list must be 0
+    const int32_t* pos;               // [Q][ld] first-insertion position, -1 = doc in no list
+    const float* weights;             // [W][S] fp32 (already rounded from the Python floats)
+    const int32_t* gold;              // [Q][TUNE_G] corpus positions, -1 = padding
+    int32_t* out;                     // [W][Q][TUNE_G] ranks (zero-initialised by the caller)
+    int S, W, Q, N, ld;
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void gold_ranks_kernel(TuneArgs a) {
+    const int q = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const size_t rowoff = (size_t)q * a.ld;
+    const int c0 = blockIdx.x * (256 * TUNE_COLS);
+
+    // this thread's columns: strided by 256 inside the chunk (coalesced 4-byte loads)
+    float t[S][TUNE_COLS];
+    int pj[TUNE_COLS];
+#pragma unroll
+    for (int i = 0; i < TUNE_COLS; ++i) {
+        const int j = c0 + i * 256 + threadIdx.x;
+        const bool in = j < a.N;
+        pj[i] = in ? a.pos[rowoff + j] : -1;
+#pragma unroll
+        for (int s = 0; s < S; ++s) t[s][i] = in ? a.T[s][rowoff + j] : 0.f;
+    }
+    // the query's gold documents (block-uniform)
+    float tg[S][TUNE_G];
+    int pg[TUNE_G];
+#pragma unroll
+    for (int g = 0; g < TUNE_G; ++g) {
+        const int col = a.gold[q * TUNE_G + g];
+        const bool ok = col >= 0 && col < a.N;
+        pg[g] = ok ? a.pos[rowoff + col] : -1;   // -1: padding or a gold doc no system retrieved (never ranked)
+#pragma unroll
+        for (int s = 0; s < S; ++s) tg[s][g] = ok ? a.T[s][rowoff + col] : 0.f;
+    }
+
+    for (int w = 0; w < a.W; ++w) {
+        float wv[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) wv[s] = a.weights[w * S + s];
+        float fg[TUNE_G];
+#pragma unroll
+        for (int g = 0; g < TUNE_G; ++g) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { const float prod = tg[s][g] * wv[s]; acc = acc + prod; }
+            fg[g] = acc;
+        }
+        int cnt[TUNE_G];
+#pragma unroll
+        for (int g = 0; g < TUNE_G; ++g) cnt[g] = 0;
+#pragma unroll
+        for (int i = 0; i < TUNE_COLS; ++i) {
+            float f = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { const float prod = t[s][i] * wv[s]; f = f + prod; }   // hybrid.py:291,304 (NumPy 2: fp32)
+            const bool listed = pj[i] >= 0;
+#pragma unroll
+            for (int g = 0; g < TUNE_G; ++g) {
+                // NaN fused scores sort first in this build: a NaN beats every number
+                const bool fn = f != f, gn = fg[g] != fg[g];
+                const bool beats = (fn && !gn) || (!fn && !gn && f > fg[g]) || (((fn && gn) || f == fg[g]) && pj[i] < pg[g]);
+                cnt[g] += (listed && beats) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < TUNE_G; ++g) {
+            int c = cnt[g];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            if (lane == 0 && c != 0 && pg[g] >= 0) atomicAdd(&a.out[((size_t)w * a.Q + q) * TUNE_G + g], c);
+        }
+    }
+}
+
+}  // namespace fz
+
+using namespace fz;
+
+extern "C" int fz_tune_max_gold(void) { return TUNE_G; }
+
+extern "C" int fz_gold_ranks_f32(const float* const* T_h, const int32_t* pos, const float* weights, const int32_t* gold, int S, int W,
+                                 int Q, int N, int ld, int32_t* out_ranks, void* stream) {
+    if (!T_h || !pos || !weights || !gold || !out_ranks || S <= 0 || S > FZ_MAX_SYSTEMS || W < 0 || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (W == 0 || Q == 0 || N == 0) return FZ_OK;
+    TuneArgs a{};
+    for (int s = 0; s < S; ++s) { if (!T_h[s]) return FZ_ERR_ARG; a.T[s] = T_h[s]; }
+    a.pos = pos; a.weights = weights; a.gold = gold; a.out = out_ranks; a.S = S; a.W = W; a.Q = Q; a.N = N; a.ld = ld;
+    dim3 grid((unsigned)((N + 256 * TUNE_COLS - 1) / (256 * TUNE_COLS)), (unsigned)Q);
+    hipStream_t st = as_stream(stream);
+    switch (S) {
+        case 1: gold_ranks_kernel<1><<<grid, 256, 0, st>>>(a); break;
+        case 2: gold_ranks_kernel<2><<<grid, 256, 0, st>>>(a); break;
+        case 3: gold_ranks_kernel<3><<<grid, 256, 0, st>>>(a); break;
+        case 4: gold_ranks_kernel<4><<<grid, 256, 0, st>>>(a); break;
+        default: return FZ_ERR_UNSUPPORTED;   // the reference sweeps at most 4 systems (run_hybrid.sh:21-33)
+    }
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}

@@ -81,6 +81,27 @@ def _same_ld(*ts):
     return lds.pop() if lds else max(_ld(t) for t in ts if t is not None)
 
 
+def harmonise(ts: list):
+    """One C-ABI call takes ONE row stride for all its planes: copy the odd ones out (None entries pass through)."""
+    real = [t for t in ts if t is not None]
+    if not real:
+        return ts
+    rows, n = real[0].shape
+    want = max(round_up(n, _PAD), _PAD)
+    lds = {_ld(t) for t in real} if rows > 1 else {want}
+    if len(lds) == 1 and all(t.data_ptr() % 16 == 0 and t.stride(1) == 1 for t in real):
+        return ts
+    out = []
+    for t in ts:
+        if t is None or (rows > 1 and _ld(t) == want and t.data_ptr() % 16 == 0 and t.stride(1) == 1):
+            out.append(t)
+        else:
+            p = alloc_plane(rows, n, t.dtype, t.device)
+            p.copy_(t)
+            out.append(p)
+    return out
+
+
 # ---------------------------------------------------------------------------------------
 # K1 scoring
 # ---------------------------------------------------------------------------------------
@@ -208,6 +229,7 @@ def fuse_rank(ranks: list[torch.Tensor], lens: torch.Tensor, method: str) -> tor
     """rrf / bcf in float64 (hybrid.py:248-252,301-304). ranks[s] [Q,N] int32 planes, lens [S,Q] int32."""
     for r in ranks:
         _dev(r, torch.int32, "fuse_rank(ranks)")
+    ranks = harmonise(list(ranks))
     _dev(lens, torch.int32, "fuse_rank(lens)")
     lens = lens.contiguous()
     Q, N = ranks[0].shape
@@ -237,6 +259,8 @@ def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None
     for p in planes:
         _dev(p, torch.float32, "fuse_nsf(planes)")
     S = len(planes)
+    both = harmonise(list(planes) + (list(ranks) if ranks else []))
+    planes, ranks = both[:S], (both[S:] if ranks else None)
     Q, N = planes[0].shape
     ld = _same_ld(*planes, *([r for r in ranks if r is not None] if ranks else []))
     dev = planes[0].device
@@ -272,6 +296,8 @@ def fuse_none(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | Non
     for p in planes:
         _dev(p, torch.float32, "fuse_none(planes)")
     S = len(planes)
+    both = harmonise(list(planes) + (list(ranks) if ranks else []))
+    planes, ranks = both[:S], (both[S:] if ranks else None)
     Q, N = planes[0].shape
     ld = _same_ld(*planes, *([r for r in ranks if r is not None] if ranks else []))
     fused = torch.empty((max(Q, 1), ld), dtype=torch.float64, device=planes[0].device)[:Q, :N]
@@ -285,6 +311,7 @@ def insertion_order(orders: list[torch.Tensor], lens: torch.Tensor, N: int):
     """First-insertion order of the fused dict (hybrid.py:301-304). Returns (ins_order [Q,N] int32, U [Q] int32)."""
     for o in orders:
         _dev(o, torch.int32, "insertion_order(orders)")
+    orders = harmonise(list(orders))
     _dev(lens, torch.int32, "insertion_order(lens)")
     lens = lens.contiguous()
     Q = orders[0].shape[0]
@@ -295,6 +322,30 @@ def insertion_order(orders: list[torch.Tensor], lens: torch.Tensor, N: int):
     check(_lib.lib().fz_insertion_order(_ptr_array(orders), _ptr(lens), len(orders), Q, N, ld, _ptr(ins), _ptr(U), None, 0,
                                         _stream(orders[0])), "fz_insertion_order")
     return ins, U
+
+
+def gold_ranks(T: list[torch.Tensor], pos: torch.Tensor, weights: torch.Tensor, gold: torch.Tensor) -> torch.Tensor:
+    """Fused ranks of the gold documents for every weight vector (N1, hybrid.py:404-426).
+    T[s] [Q,N] normalised planes, pos [Q,N] int32 insertion positions (-1 absent), weights [W,S] fp32,
+    gold [Q,G] int32 corpus positions (-1 pad) -> ranks [W,Q,G] int32 (0 where gold is padding / unlisted: check pos)."""
+    for t in T:
+        _dev(t, torch.float32, "gold_ranks(T)")
+    _dev(pos, torch.int32, "gold_ranks(pos)")
+    _dev(weights, torch.float32, "gold_ranks(weights)")
+    _dev(gold, torch.int32, "gold_ranks(gold)")
+    lib = _lib.lib()
+    G = int(lib.fz_tune_max_gold())
+    both = harmonise(list(T) + [pos])
+    T, pos = both[:-1], both[-1]
+    Q, N = T[0].shape
+    W, S = weights.shape
+    if S != len(T) or gold.shape != (Q, G):
+        raise ValueError(f"weights must be [W,{len(T)}] and gold [Q,{G}]")
+    ld = _same_ld(*T, pos)
+    out = torch.zeros((W, Q, G), dtype=torch.int32, device=T[0].device)
+    check(lib.fz_gold_ranks_f32(_ptr_array(T), _ptr(pos), _ptr(weights.contiguous()), _ptr(gold.contiguous()), S, W, Q, N, ld, _ptr(out),
+                                _stream(T[0])), "fz_gold_ranks_f32")
+    return out
 
 
 # ---------------------------------------------------------------------------------------

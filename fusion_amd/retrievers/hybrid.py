@@ -200,6 +200,75 @@ class Aggregator:
             order, sk, _ = ops.sort_rows_desc(fused, init_order=ins, row_len=U)
         return FusedResult(order=order, scores=sk, lens=lens_out, ids=S[0].ids)
 
+    # -- N1: the whole weight grid in one pass (hybrid.py:404-426) ----------------------------------
+    @classmethod
+    def tune(cls, ranked_lists: dict, normalization: str, weight_combinations: list[dict[str, float]], labels: list[list],
+             percentile_distributions: dict[str, np.ndarray] = None) -> list[dict]:
+        """For every weight vector: the metrics run_evaluation() would report on Aggregator.fuse(method='nsf', ...).
+        The reference re-normalises, re-fuses, re-sorts and re-evaluates per weight vector (hybrid.py:416-425); here the
+        systems are normalised once and one counting kernel yields the fused ranks of the gold documents for all weight
+        vectors (csrc/tune.hip) -- every metric is a function of those ranks."""
+        from ..utils.metrics import metrics_from_gold_ranks
+        systems = cls._to_device(ranked_lists)
+        names = list(systems.keys())
+        S = [systems[n] for n in names]
+        if normalization not in ("min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent") or len(S) > 4:
+            return cls._tune_by_fusing(systems, normalization, weight_combinations, labels, percentile_distributions)
+        Q, N = S[0].Q, S[0].N
+        dev = S[0].scores.device
+        all_full = all(s.full for s in S)
+        T = []
+        for n, s in zip(names, S):
+            distr = None
+            if normalization in ("percentile-rank", "normal-curve-equivalent"):
+                distr = [cls._table(percentile_distributions.get(n), dev)]
+            t = ops.fuse_nsf([s.scores], None if s.full else [s.rank], [1.0], normalization, distr)   # fl32(t*1) + 0 = t, exactly
+            if not s.full:
+                t = torch.where(s.rank >= 0, t, torch.zeros_like(t))   # a system adds nothing for docs it does not list
+                t = ops.as_plane(t)
+            T.append(t)
+        if all_full:
+            pos = S[0].rank
+        else:
+            lens = torch.stack([s.lens for s in S]).contiguous()
+            ins, U = ops.insertion_order([s.order for s in S], lens, N)
+            pos = ops.alloc_plane(Q, N, torch.int32, dev, fill=-1)
+            r = torch.arange(N, device=dev, dtype=torch.int32).unsqueeze(0).expand(Q, N)
+            valid = r < U.unsqueeze(1)
+            rows = torch.arange(Q, device=dev).unsqueeze(1).expand(Q, N)
+            pos[rows[valid], ins.long()[valid]] = r[valid]
+        weights = torch.tensor([[np.float32(w[n]) for n in names] for w in weight_combinations], dtype=torch.float32, device=dev)  # KeyError as hybrid.py:214
+        id2pos = {cid: j for j, cid in enumerate(S[0].ids.tolist())}
+        gold_pos = [[id2pos.get(g, -1) for g in dict.fromkeys(gl)] for gl in labels]   # unique, order kept
+        G = int(ops._lib.lib().fz_tune_max_gold())
+        Gmax = max((len(g) for g in gold_pos), default=0)
+        W = len(weight_combinations)
+        ranks = np.full((W, Q, max(Gmax, 1)), np.iinfo(np.int64).max, dtype=np.int64)
+        pos_host = None
+        for g0 in range(0, Gmax, G):
+            gold = np.full((Q, G), -1, dtype=np.int32)
+            for q, gl in enumerate(gold_pos):
+                chunk = gl[g0:g0 + G]
+                gold[q, :len(chunk)] = chunk
+            out = ops.gold_ranks(T, pos, weights, torch.from_numpy(gold).to(dev)).cpu().numpy().astype(np.int64)
+            if pos_host is None:
+                pos_host = pos.cpu().numpy()
+            listed = (gold >= 0) & (np.take_along_axis(pos_host, np.maximum(gold, 0).astype(np.int64), axis=1) >= 0)
+            blk = np.where(listed[None, :, :], out, np.iinfo(np.int64).max)   # never retrieved -> rank = infinity
+            ranks[:, :, g0:g0 + G] = blk[:, :, : ranks.shape[2] - g0]
+        n_gold = np.array([len(gl) for gl in labels], dtype=np.int64)          # the reference divides by len(ground_truths)
+        list_len = (pos_host >= 0).sum(1) if pos_host is not None else np.zeros(Q, dtype=np.int64)
+        return metrics_from_gold_ranks(ranks, n_gold, list_len)
+
+    @classmethod
+    def _tune_by_fusing(cls, systems, normalization, weight_combinations, labels, percentile_distributions):
+        """Generic path (float64 'none' arithmetic, > 4 systems): one device fusion + evaluation per weight vector."""
+        out = []
+        for w in weight_combinations:
+            fused = cls.fuse_device(systems, "nsf", normalization, w, percentile_distributions)
+            out.append(run_evaluation(fused.predictions(1000), labels, print2console=False))
+        return out
+
     @staticmethod
     def _table(distr, dev) -> torch.Tensor:
         t = np.asarray(distr, dtype=np.float64).astype(np.float32)   # torch.tensor(distr, dtype=float32), hybrid.py:272
@@ -379,15 +448,11 @@ def main(args):
         combos = weight_grid(list(results.keys()))
         distr = distributions()
         print(f"{sep}\n# Tuning the weights of convex combination between systems: {len(combos)} permutations\n{sep}")
-        rows = []
-        for weights in combos:
-            fused = Aggregator.fuse(results, method=args.fusion, normalization=args.normalization, percentile_distributions=distr,
-                                    linear_weights=weights, as_device=True)
-            perf = run_evaluation(predictions=fused.predictions(1000), labels=pos_pids, print2console=False)
-            rows.append({**perf, **{f"weight_{k}": v for k, v in weights.items()}})
-            pd.DataFrame(rows).to_csv(join(args.output_dir, f"nsf_{args.normalization}_{args.eval_type}.csv"), index=False)
+        perfs = Aggregator.tune(results, args.normalization, combos, pos_pids, distr)
+        rows = [{**perf, **{f"weight_{k}": v for k, v in weights.items()}} for perf, weights in zip(perfs, combos)]
+        pd.DataFrame(rows).to_csv(join(args.output_dir, f"nsf_{args.normalization}_{args.eval_type}.csv"), index=False)   # schema of hybrid.py:420-425
         print("Done.")
-        return
+        return rows
 
     weights = {s: 1 / len(results) for s in results} if args.fusion == "nsf" else {}
     distr = distributions() if args.fusion == "nsf" else {}

@@ -68,3 +68,46 @@ class Metrics:
     def fscore(self, ground_truths, results, k: int = None):
         p, r = self.precision(ground_truths, results, k), self.recall(ground_truths, results, k)
         return (2 * p * r) / (p + r) if (p != 0.0 or r != 0.0) else 0.0
+
+
+RECALL_KS, MAP_KS, MRR_KS, NDCG_KS = [5, 10, 20, 50, 100, 200, 500, 1000], [10, 100], [10, 100], [10, 100]   # hybrid.py:28
+
+
+def metrics_from_gold_ranks(ranks: np.ndarray, n_gold: np.ndarray, list_len: np.ndarray) -> list[dict]:
+    """All metrics of run_evaluation (hybrid.py:24-42) from the 0-based ranks of the gold documents.
+    ranks [W, Q, G] int64 (np.iinfo(int64).max = never retrieved), n_gold [Q] = len(ground_truths) as the reference
+    divides by it, list_len [Q] = length of the fused list.  Same per-query formulas and summation order as
+    metrics.py:72-136; means over queries use an exactly rounded sum (statistics.mean differs by <= 1 ulp)."""
+    import math
+    W, Q, G = ranks.shape
+    INF = np.iinfo(np.int64).max
+    r = np.sort(ranks, axis=2)                                   # ascending gold ranks per (w, q)
+    have = r < INF
+    ng = np.maximum(n_gold, 1).astype(np.float64)[None, :]
+    disc = np.where(r == 0, 1.0, 1.0 / np.log2(np.where(have & (r >= 1), r, 1).astype(np.float64) + 1.0))   # metrics.py:108
+    idcg = np.array([1 + sum(1 / np.log2(i + 1) for i in range(1, int(n))) if n > 0 else 1.0 for n in n_gold], dtype=np.float64)[None, :]
+    per_query: dict[str, np.ndarray] = {}
+    for k in RECALL_KS:
+        per_query[f"recall@{k}"] = (have & (r < k)).sum(2) / ng
+    for k in MAP_KS:
+        ap = np.zeros((W, Q))
+        for i in range(G):                                       # i-th gold hit sits at rank r[..., i]: precision = (i+1)/(rank+1)
+            ok = have[:, :, i] & (r[:, :, i] < k)
+            ap = ap + np.where(ok, (i + 1) / (np.where(ok, r[:, :, i], 0).astype(np.float64) + 1.0), 0.0)
+        per_query[f"map@{k}"] = ap / ng
+    for k in MRR_KS:
+        first = r[:, :, 0]
+        ok = have[:, :, 0] & (first < k)
+        per_query[f"mrr@{k}"] = np.where(ok, 1.0 / (np.where(ok, first, 0).astype(np.float64) + 1.0), 0.0)
+    for k in NDCG_KS:
+        head = np.where(have & (r == 0), 1.0, 0.0).sum(2)         # relevances[0]
+        tail = np.zeros((W, Q))
+        for i in range(G):                                       # sum(...) for positions >= 1, in rank order
+            ok = have[:, :, i] & (r[:, :, i] >= 1) & (r[:, :, i] < k)
+            tail = tail + np.where(ok, disc[:, :, i], 0.0)
+        per_query[f"ndcg@{k}"] = (head + tail) / idcg
+    per_query["r-precision"] = (have & (r < n_gold[None, :, None])).sum(2) / ng
+    out = []
+    for w in range(W):
+        out.append({name: math.fsum(v[w].tolist()) / Q for name, v in per_query.items()})
+    return out

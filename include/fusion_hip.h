@@ -149,6 +149,18 @@ int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* 
                        double avgdl, double k1, double b, const int64_t* qoff, const int32_t* qterms, int Q, int N,
                        double* scores, int lds, void* stream);
 
+/* ---- N1: weight-grid sweep of the linear fusion, hybrid.py:404-426 ------------------------ */
+/* Fused ranks of the gold documents for W weight vectors at once, without fusing or sorting:
+ * out_ranks[w][q][g] = #{docs that precede gold g in the list Aggregator.fuse(method='nsf') would return with
+ * weights[w]} (fused score desc, ties by first-insertion position).  Every metric of run_evaluation is a
+ * function of these ranks.  T_h: HOST array of S device planes [Q][ld] holding the NORMALISED scores
+ * (fz_fuse_nsf_f32 of one system with weight 1; entries of docs the system does not list = 0); pos [Q][ld] =
+ * first-insertion position (-1 = in no list); weights [W][S] fp32; gold [Q][fz_tune_max_gold()] corpus positions
+ * (-1 = padding); out_ranks must be zeroed by the caller.  S <= 4. */
+int fz_tune_max_gold(void);
+int fz_gold_ranks_f32(const float* const* T_h, const int32_t* pos, const float* weights, const int32_t* gold, int S, int W,
+                      int Q, int N, int ld, int32_t* out_ranks, void* stream);
+
 /* ---- small utilities ------------------------------------------------------------------ */
 int fz_fill_i32(int32_t* p, size_t count, int32_t value, void* stream);
 int fz_f64_to_f32(const double* src, float* dst, size_t count, void* stream);

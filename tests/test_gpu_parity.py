@@ -271,6 +271,44 @@ def test_aggregator_kat_and_errors():
     assert {k: float(v) for k, v in t.items()} == {x["corpus_id"]: x["score"] for x in kat["kat5_percentile"]}
 
 
+# ---- N1: weight-grid sweep --------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,norm,partial", [(2, "min-max", False), (3, "z-score", False), (4, "min-max", True), (4, "z-score", True), (2, "arctan", False)])
+def test_tune_equals_fuse_per_weight(ops, S, norm, partial):
+    """Aggregator.tune (one counting kernel for the whole grid) == fuse + sort + Metrics per weight vector."""
+    from fusion_amd.planes import RankedSystem
+    from fusion_amd.retrievers.hybrid import Aggregator, run_evaluation, weight_grid
+    rng = np.random.default_rng(S * 5 + len(norm))
+    Q, N = 9, 700
+    planes, ranks, orders, lens = synth_systems(rng, S, Q, N, partial)
+    for p in planes:                      # plant ties so that the insertion-order tie-break matters
+        p[:, ::7] = np.round(p[:, ::7], 1)
+    ids = np.arange(5000, 5000 + N)
+    names = ["bm25", "dpr", "splade", "colbert"][:S]
+    systems = {}
+    for n, p, r, o, l in zip(names, planes, ranks, orders, lens):
+        # re-rank the (modified) planes on the device so ranks are consistent with the scores
+        pl = plane(ops, p)
+        od, _, rk = ops.sort_rows_desc(pl, want_rank=True)
+        L = torch.from_numpy(l).cuda()
+        full = bool((l == N).all())
+        if not full:
+            keep = torch.arange(N, device="cuda").unsqueeze(0) < L.unsqueeze(1)
+            rk = torch.where(rk < L.unsqueeze(1), rk, torch.full_like(rk, -1))
+            od = torch.where(keep, od, torch.full_like(od, -1))
+        systems[n] = RankedSystem(scores=pl, order=od, rank=rk, lens=L, ids=ids, full=full)
+    labels = [rng.choice(ids, size=int(rng.integers(1, 12)), replace=False).tolist() for _ in range(Q)]
+    labels[0] = labels[0] + [123456789]          # a gold id that is not in the corpus
+    grid = weight_grid(names)
+    grid = grid[:: max(1, len(grid) // 25)]       # a spread of ~25 weight vectors incl. zeros
+    got = Aggregator.tune(systems, norm, grid, labels, {})
+    for w, g in zip(grid, got):
+        fused = Aggregator.fuse(systems, "nsf", norm, w, {}, as_device=True)
+        exp = run_evaluation(fused.predictions(1000), labels, print2console=False)
+        assert list(g) == list(exp)
+        for k in exp:
+            assert g[k] == pytest.approx(float(exp[k]), rel=0, abs=1e-12), (w, k)
+
+
 # ---- scoring -------------------------------------------------------------------------------------------
 def test_dot_scores_identity_layout(ops):
     """A = I against an ASYMMETRIC B catches a transposed C write / swapped operand map."""

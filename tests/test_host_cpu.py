@@ -190,3 +190,24 @@ def test_bucketed_encode_equals_padded_encode():
     a = enc.encode_ids(torch.from_numpy(ids), torch.from_numpy(mask))
     b = enc.encode_ids_bucketed(torch.from_numpy(ids), torch.from_numpy(mask), lens, n_buckets=5)
     assert torch.allclose(a, b, atol=2e-6)     # padding never attends: trimming it changes nothing but rounding
+
+
+def test_metrics_from_gold_ranks_equals_metrics_class():
+    """The rank-based formulas of the tuning sweep == Metrics on explicit ranked lists."""
+    from fusion_amd.utils.metrics import Metrics, metrics_from_gold_ranks
+    rng = np.random.default_rng(4)
+    Q, N = 23, 1500
+    gold = [sorted(rng.choice(N, size=int(rng.integers(1, 7)), replace=False).tolist()) for _ in range(Q)]
+    pred = [rng.permutation(N).tolist() for _ in range(Q)]
+    ev = Metrics(recall_at_k=[5, 10, 20, 50, 100, 200, 500, 1000], map_at_k=[10, 100], mrr_at_k=[10, 100], ndcg_at_k=[10, 100])
+    exp = ev.compute_all_metrics(gold, pred)
+    G = max(len(g) for g in gold)
+    ranks = np.full((1, Q, G), np.iinfo(np.int64).max, dtype=np.int64)
+    for q in range(Q):
+        inv = {d: i for i, d in enumerate(pred[q])}
+        for i, g in enumerate(gold[q]):
+            ranks[0, q, i] = inv[g]
+    got = metrics_from_gold_ranks(ranks, np.array([len(g) for g in gold]), np.full(Q, N))[0]
+    assert list(got) == list(exp)
+    for k in exp:
+        assert got[k] == pytest.approx(float(exp[k]), rel=0, abs=1e-14), k
