@@ -64,6 +64,12 @@ class _Base(nn.Module):
         self.tokenizer = tokenizer
         self._device = torch.device(device)
 
+    def _clamp_lengths(self, config):
+        """Never tokenise past the model's position table (RoBERTa-style positions start at padding_idx + 1)."""
+        limit = int(getattr(config, "max_position_embeddings", 514)) - 2
+        self.max_query_length = min(self.max_query_length, limit)
+        self.max_doc_length = min(self.max_doc_length, limit)
+
     def _batches(self, sentences, batch_size, max_len, pad_to_max=False):
         # sort by length as SentenceTransformer.encode does, restore order afterwards
         order = sorted(range(len(sentences)), key=lambda i: -len(sentences[i]))
@@ -80,6 +86,7 @@ class DenseEncoder(_Base):
         super().__init__(tokenizer, device)
         self.backbone = backbone.to(self._device).eval()
         self.dim = backbone.config.hidden_size
+        self._clamp_lengths(backbone.config)
 
     @torch.no_grad()
     def encode_ids(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
@@ -110,7 +117,7 @@ class DenseEncoder(_Base):
     @torch.no_grad()
     def encode(self, sentences: list[str], batch_size: int = 64, query_mode: bool = True, **_) -> torch.Tensor:
         out = torch.empty((len(sentences), self.dim), dtype=torch.float32, device=self._device)
-        for idx, ids, mask in self._batches(sentences, batch_size, 512):
+        for idx, ids, mask in self._batches(sentences, batch_size, self.max_doc_length):   # max_seq_length = 512 (hybrid.py:99)
             out[torch.tensor(idx, device=self._device)] = self.encode_ids(ids, mask).float()
         return out
 
@@ -122,6 +129,7 @@ class SpladeEncoder(_Base):
         super().__init__(tokenizer, device)
         self.mlm = mlm.to(self._device).eval()
         self.dim = mlm.config.vocab_size
+        self._clamp_lengths(mlm.config)
 
     @torch.no_grad()
     def encode_ids(self, input_ids, attention_mask) -> torch.Tensor:
@@ -145,6 +153,7 @@ class ColbertEncoder(_Base):
         super().__init__(tokenizer, device)
         self.backbone = backbone.to(self._device).eval()
         self.linear = nn.Linear(backbone.config.hidden_size, self.dim, bias=False).to(self._device)
+        self._clamp_lengths(backbone.config)
         self.punct_ids = torch.tensor(list(punct_ids), dtype=torch.long, device=self._device)
 
     @torch.no_grad()

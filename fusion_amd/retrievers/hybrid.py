@@ -438,6 +438,10 @@ def main(args):
         print(f"{sep}\n# Ranking with ColBERT\n{sep}")
         results["colbert"] = Ranker.multi_vector_search(queries, corpus, MODEL_CKPTS["colbert"][args.models_domain], encoder=enc("colbert"), as_device=True)
 
+    if args.analyze_score_distributions:
+        print(f"{sep}\n# Analyzing the score distributions per system\n{sep}")
+        return analyze_score_distributions(args, results, corpus, pos_pids)
+
     def distributions():
         if args.normalization in ("percentile-rank", "normal-curve-equivalent"):
             df = pd.read_csv(join(args.output_dir, f"score_distributions_raw_{args.eval_type}_28k.csv"))
@@ -461,6 +465,61 @@ def main(args):
                             linear_weights=weights, as_device=True)
     print(f"{sep}\n# Evaluation \n{sep}")
     return run_evaluation(predictions=fused.predictions(1000), labels=pos_pids, args=args)
+
+
+def analyze_score_distributions(args, results: dict[str, RankedSystem], corpus: dict, pos_pids: list[list]):
+    """hybrid.py:363-402: per-system transformed scores of every (query, document), quantile tables of 1k / 10k / 100k /
+    |corpus| points (the input of the percentile-rank / NCE normalisations, hybrid.py:412,451) and the scores of the
+    positives vs as many random negatives.  The transform runs once per system on the device (one fusion-kernel pass
+    with weight 1) instead of once per (query, system) with a host round trip (hybrid.py:378)."""
+    import random
+    import pandas as pd
+    names = list(results.keys())
+    dev = results[names[0]].scores.device
+    distr = {}
+    if args.normalization in ("percentile-rank", "normal-curve-equivalent"):
+        df = pd.read_csv(join(args.output_dir, f"score_distributions_raw_{args.eval_type}_10k.csv"))   # hybrid.py:374
+        distr = {k: np.array(v) for k, v in df.to_dict("series").items()}
+    random.seed(42)
+    max_pid = max(corpus.keys())
+    neg_pids = [random.sample(list(set(range(1, max_pid + 1)) - set(x)), k=len(x)) for x in pos_pids]   # hybrid.py:368
+    transformed = {}
+    for n in names:
+        rs = results[n]
+        if args.normalization in ("min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent"):
+            d = [Aggregator._table(distr.get(n), dev)] if n in distr else None
+            t = ops.fuse_nsf([rs.scores], None if rs.full else [rs.rank], [1.0], args.normalization, d)
+        else:
+            t = rs.scores                                                        # 'none': raw scores (hybrid.py:280)
+        t = t.cpu().numpy().astype(np.float64)
+        listed = np.ones_like(t, dtype=bool) if rs.full else (rs.rank.cpu().numpy() >= 0)
+        transformed[n] = (t, listed)
+    ids = results[names[0]].ids
+    id2pos = {c: j for j, c in enumerate(ids.tolist())}
+    # scores_{norm}_{eval}_{split}.csv: one row per (system, query, listed document)   (hybrid.py:379,387)
+    frames = [pd.DataFrame({"system": n, "score": t[l]}) for n, (t, l) in transformed.items()]
+    all_scores_df = pd.concat(frames, ignore_index=True)
+    all_scores_df.to_csv(join(args.output_dir, f"scores_{args.normalization}_{args.eval_type}_{args.data_split}.csv"), index=False)
+    # quantile tables (hybrid.py:390-397): drop zeros and each system's two smallest distinct scores, then N+1 quantiles
+    for N in [1000, 10000, 100000, len(corpus)]:
+        cols = {}
+        for n, (t, l) in transformed.items():
+            v = t[l]
+            two = np.unique(v)[:2]
+            v = v[(v != 0.0) & ~np.isin(v, two)]
+            cols[n] = np.quantile(v, np.linspace(0, 1, N + 1)) if v.size else np.full(N + 1, np.nan)
+        pd.DataFrame(cols).to_csv(join(args.output_dir, f"score_distributions_{args.normalization}_{args.eval_type}_{round(N / 1e3)}k.csv"), index=False)
+    # labelled scores of positives / sampled negatives, 0 when a system does not list the document (hybrid.py:381-383,400)
+    rows = []
+    for q, (pos, neg) in enumerate(zip(pos_pids, neg_pids)):
+        for label, pids in (("positive", pos), ("negative", neg)):
+            for pid in pids:
+                j = id2pos.get(pid)
+                rows.append({"label": label, **{n: (float(t[q, j]) if j is not None and l[q, j] else 0) for n, (t, l) in transformed.items()}})
+    pd.DataFrame(rows, columns=["label"] + names).to_csv(
+        join(args.output_dir, f"labeled_scores_{args.normalization}_{args.eval_type}_{args.data_split}.csv"), index=False)
+    print("Done.")
+    return all_scores_df
 
 
 def build_parser():

@@ -490,3 +490,30 @@ def test_full_size_cos_linearity(ops):
     assert float((S[:64].double() - ref).abs().max()) <= 2e-6
     S2 = ops.cos_scores(Qe * 3.0, De * 0.5)              # cosine is scale-invariant
     assert float((S2 - S).abs().max()) <= 1e-6
+
+
+# ---- the CLI path end to end (synthetic LLeQA-shaped data, tiny random-init encoders) ---------------------------
+def test_cli_main_end_to_end(tmp_path):
+    import pandas as pd
+    from fusion_amd.retrievers.hybrid import build_parser, main
+    out = str(tmp_path)
+    base = f"--data_split test --models_domain legal --synthetic 600,6 --output_dir {out}".split()
+    a, _ = build_parser().parse_known_args(base + "--run_bm25 --run_dpr --run_splade --run_colbert --fusion rrf --normalization none".split())
+    sc = main(a)
+    assert set(sc) >= {"recall@500", "map@10", "r-precision"} and 0.0 <= sc["recall@500"] <= 1.0
+    a, _ = build_parser().parse_known_args(base + "--run_bm25 --run_dpr --fusion nsf --normalization z-score".split())
+    assert 0.0 <= main(a)["recall@1000"] <= 1.0
+    # score-distribution analysis (writes the quantile tables) ...
+    a, _ = build_parser().parse_known_args(base + "--run_bm25 --run_dpr --fusion nsf --normalization none --analyze_score_distributions".split())
+    main(a)
+    t = pd.read_csv(os.path.join(out, "score_distributions_none_indomain_1k.csv"))
+    # N in [1000, 10000, 100000, len(corpus)=600]: round(N/1e3) names both the first and the last table "1k" (hybrid.py:396)
+    assert list(t.columns) == ["bm25", "dpr"] and len(t) == 601 and (np.diff(t["dpr"].values) >= 0).all()
+    os.rename(os.path.join(out, "score_distributions_none_indomain_1k.csv"), os.path.join(out, "score_distributions_raw_indomain_28k.csv"))
+    # ... which percentile-rank fusion then consumes (hybrid.py:451), and the weight sweep writes the reference's CSV schema
+    a, _ = build_parser().parse_known_args(base + "--run_bm25 --run_dpr --fusion nsf --normalization percentile-rank".split())
+    assert 0.0 <= main(a)["recall@1000"] <= 1.0
+    a, _ = build_parser().parse_known_args(base + "--run_bm25 --run_dpr --fusion nsf --normalization min-max --tune_linear_fusion_weight".split())
+    rows = main(a)
+    df = pd.read_csv(os.path.join(out, "nsf_min-max_indomain.csv"))
+    assert len(rows) == len(df) == 21 and list(df.columns)[-2:] == ["weight_bm25", "weight_dpr"] and "recall@10" in df.columns
