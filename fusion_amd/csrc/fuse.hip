@@ -183,35 +183,37 @@ __device__ __forceinline__ void block_sum_n(double (&v)[NV], double* red /* NV*T
 // global_load_lds is in flight, which would serialise the prefetch below).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Single-barrier block reductions: the partial slots are double-buffered by `parity` (the caller alternates it per
+// use), so the write of round r+1 cannot overtake the reads of round r -- one s_barrier per reduction instead of two.
 template <int THREADS>
-__device__ __forceinline__ void block_minmax_nan(float& mn, float& mx, float& nanflag, float* red /* 3*THREADS/64 */) {
+__device__ __forceinline__ void block_minmax_nan(float& mn, float& mx, float& nanflag, float* red /* 2 x 3*THREADS/64 */, int parity) {
     constexpr int NW = THREADS / 64;
+    float* r = red + parity * 3 * NW;
     mn = wave_reduce_min(mn); mx = wave_reduce_max(mx); nanflag = wave_reduce_max(nanflag);
     const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { r[w] = mn; r[NW + w] = mx; r[2 * NW + w] = nanflag; }
     lds_barrier();
-    if ((threadIdx.x & 63) == 0) { red[w] = mn; red[NW + w] = mx; red[2 * NW + w] = nanflag; }
-    lds_barrier();
-    mn = red[0]; mx = red[NW]; nanflag = red[2 * NW];
+    mn = r[0]; mx = r[NW]; nanflag = r[2 * NW];
 #pragma unroll
-    for (int i = 1; i < NW; ++i) { mn = fminf(mn, red[i]); mx = fmaxf(mx, red[NW + i]); nanflag = fmaxf(nanflag, red[2 * NW + i]); }
+    for (int i = 1; i < NW; ++i) { mn = fminf(mn, r[i]); mx = fmaxf(mx, r[NW + i]); nanflag = fmaxf(nanflag, r[2 * NW + i]); }
 }
 template <int THREADS, int NV>
-__device__ __forceinline__ void block_sum_n_nodrain(double (&v)[NV], double* red /* NV*THREADS/64 */) {
+__device__ __forceinline__ void block_sum_n_nodrain(double (&v)[NV], double* red /* 2 x NV*THREADS/64 */, int parity) {
     constexpr int NW = THREADS / 64;
+    double* r = red + parity * NV * NW;
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = wave_reduce_sum(v[k]);
     const int w = threadIdx.x >> 6;
-    lds_barrier();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) red[k * NW + w] = v[k];
+        for (int k = 0; k < NV; ++k) r[k * NW + w] = v[k];
     }
     lds_barrier();
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         double s = 0.0;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) s += red[k * NW + i];  // fixed order: deterministic
+        for (int i = 0; i < NW; ++i) s += r[k * NW + i];  // fixed order: deterministic
         v[k] = s;
     }
 }
@@ -228,8 +230,8 @@ template <int NORM, int T /* threads */, int E4 /* float4 per thread */, bool VE
 __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __restrict__ fused) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* rowbuf = reinterpret_cast<float*>(smem_raw);                                 // DMA: [T*E4*4] floats
-    double* red_d = reinterpret_cast<double*>(smem_raw + (DMA ? (size_t)T * E4 * 16 : 0)); // [3*T/64]
-    float* red_f = reinterpret_cast<float*>(red_d + 3 * T / 64);                        // [3*T/64]
+    double* red_d = reinterpret_cast<double*>(smem_raw + (DMA ? (size_t)T * E4 * 16 : 0)); // [2][3*T/64]
+    float* red_f = reinterpret_cast<float*>(red_d + 2 * 3 * T / 64);                    // [2][3*T/64]
     const int q = blockIdx.x;
     const int N = a.N;
     const size_t rowoff = (size_t)q * a.ld;
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
                     mx = fmaxf(mx, in ? x : -INFINITY);
                     nanf_ = (in && x != x) ? 1.f : nanf_;
                 }
-            block_minmax_nan<T>(mn, mx, nanf_, red_f);
+            block_minmax_nan<T>(mn, mx, nanf_, red_f, s & 1);
             sa = nanf_ > 0.f ? __uint_as_float(0x7fc00000u) : mn;   // torch.min/max propagate NaN
             sb = nanf_ > 0.f ? __uint_as_float(0x7fc00000u) : mx;
         } else if (NORM == FZ_NORM_ZSCORE) {
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
                     const double d = in ? (double)v[i][c] - x0 : 0.0;
                     st[0] += d; st[1] += d * d; st[2] += in ? 1.0 : 0.0;
                 }
-            block_sum_n_nodrain<T, 3>(st, red_d);
+            block_sum_n_nodrain<T, 3>(st, red_d, s & 1);
             const double n = st[2];
             const double mean = n > 0.0 ? x0 + st[0] / n : (double)NAN;
             const double var = n > 1.0 ? (st[1] - st[0] * st[0] / n) / (n - 1.0) : (double)NAN;
@@ -554,7 +556,7 @@ extern "C" int fz_row_stats_f32(const float* scores, const int32_t* rank, int ro
 
 template <int NORM, int TT, int E4, bool VEC, bool VALID, bool DMA>
 static int launch_nsf_cfg(const NsfArgs& a, int Q, float* fused, hipStream_t st) {
-    constexpr size_t lds = (DMA ? (size_t)TT * E4 * 16 : 0) + 3 * (TT / 64) * (sizeof(double) + sizeof(float)) + 64;
+    constexpr size_t lds = (DMA ? (size_t)TT * E4 * 16 : 0) + 2 * 3 * (TT / 64) * (sizeof(double) + sizeof(float)) + 64;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         FZ_HIP_TRY(hipFuncSetAttribute((const void*)fuse_nsf_row_kernel<NORM, TT, E4, VEC, VALID, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
