@@ -15,6 +15,8 @@
 // operands, so the sum is unchanged.  Workgroup -> tile mapping is XCD-aware: the QB query blocks of one
 // corpus tile run back-to-back on one XCD (blockIdx % 8), so a corpus tile is fetched from HBM once and hit
 // in that XCD's L2 afterwards.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace fz {
@@ -60,23 +62,17 @@ struct GemmArgs {
     const float* B; int ldb;   // corpus   [N][ldb]
     float* C; int ldc;         // scores   [Q][ldc]
     int Q, N, d, QB, TN;
+    int full;                  // block ids < full run whole 128x128 tiles, the others 128x64 halves
 };
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
+template <int BN, bool DB /* double-buffered LDS (2 workgroups/CU) vs single buffer (3/CU) */>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int row0, const int col0, float* lds) {
     constexpr int NI = BN / 64;          // MFMA tiles per wave along N (wave tile = 64 x BN/2)
     constexpr int BROWS = BN / 32;       // staging float4 per thread for the corpus tile
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     // [buf][A: 128 rows | B: BN rows][LDT]
     constexpr int BUF = (BM + BN) * LDT;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
-
-    const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int qb = idx % g.QB;
-    const int dt = (idx / g.QB) * 8 + x;
-    if (dt >= g.TN) return;
-    const int row0 = qb * BM, col0 = dt * BN;
 
     // staging: thread -> (row = tid/8 + 32*i, k4 = tid%8)
     const int srow = tid >> 3, sk = (tid & 7) * 4;
@@ -118,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
     __syncthreads();
     const int fr = lane & 31, fh = (lane >> 5) * 4;
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
+        const int buf = DB ? (kt & 1) : 0;
         if (kt + 1 < KT) gload(kt + 1);
         const float* As = lds + buf * BUF + (wr * 64 + fr) * LDT + fh;
         const float* Bs = lds + buf * BUF + BM * LDT + (wc * (BN / 2) + fr) * LDT + fh;
@@ -140,8 +136,14 @@ __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
                     }
         }
-        if (kt + 1 < KT) sstore(buf ^ 1);
-        __syncthreads();
+        if (DB) {
+            if (kt + 1 < KT) sstore(buf ^ 1);
+            __syncthreads();
+        } else {
+            __syncthreads();                       // every wave is done reading the tile
+            if (kt + 1 < KT) sstore(0);
+            __syncthreads();
+        }
     }
 
     // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -158,6 +160,24 @@ __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
                 }
             }
         }
+}
+
+// Workgroup -> tile map.  XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch), so the QB query blocks of
+// one corpus tile are consecutive block ids on one XCD and the corpus tile is fetched from HBM once.  Blocks are
+// dispatched in id order; the first `g.full` ids run 128x128 tiles, the rest are the LAST partial round of tiles
+// cut into 128x64 halves, so that the tail occupies every CU for half a tile time instead of half the CUs for a
+// whole one (1792 equal tiles on 512 resident slots otherwise cost 4 rounds for 3.5 rounds of work).
+template <bool DB>
+__global__ __launch_bounds__(256, DB ? 2 : 3) void dot_scores_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int b = blockIdx.x, half = -1;
+    if (b >= g.full) { const int h = b - g.full; b = g.full + (h >> 1); half = h & 1; }
+    const int x = b & 7, idx = b >> 3;
+    const int qb = idx % g.QB;
+    const int dt = (idx / g.QB) * 8 + x;     // 128-wide corpus tile
+    if (dt >= g.TN) return;
+    if (half < 0) gemm_tile<128, DB>(g, qb * BM, dt * 128, lds);
+    else gemm_tile<64, DB>(g, qb * BM, dt * 128 + half * 64, lds);
 }
 
 }  // namespace fz
@@ -183,23 +203,24 @@ extern "C" int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int 
     g.A = Qn; g.lda = ldq; g.B = Dn; g.ldb = ldd; g.C = scores; g.ldc = lds;
     g.Q = Q; g.N = N; g.d = d;
     g.QB = (Q + BM - 1) / BM;
-    // tile width: 128x128 tiles have the best MFMA:LDS ratio, 128x64 tiles halve the quantisation of the last
-    // round (two workgroups are resident per CU: 512 slots).  Pick the smaller modelled time (64-wide measured ~15 % dearer per flop).
-    const long slots = 512;
-    const long t128 = (long)g.QB * ((N + 127) / 128), t64 = (long)g.QB * ((N + 63) / 64);
-    const double c128 = (double)((t128 + slots - 1) / slots), c64 = 0.6 * (double)((t64 + slots - 1) / slots);
-    const int bn = (c64 < c128) ? 64 : 128;
-    g.TN = (N + bn - 1) / bn;
-    const long nblk = 8L * g.QB * ((g.TN + 7) / 8);
+    g.TN = (N + 127) / 128;
+    const long B = 8L * g.QB * ((g.TN + 7) / 8);        // block ids of whole tiles (incl. the XCD padding, which exits at once)
+    static int single = -1;
+    if (single < 0) { const char* e = getenv("FZ_GEMM_SINGLE_BUFFER"); single = (e && e[0] == '1') ? 1 : 0; }
+    const long slots = single ? 768 : 512;               // resident workgroups on 256 CUs
+    long R = B % slots;                                  // the partial last round ...
+    if (R > slots / 2 || B < slots) R = 0;               // ... is only worth halving when it is at most half full
+    g.full = (int)(B - R);
+    const long nblk = (B - R) + 2 * R;
     if (nblk > 0x7fffffffL) return FZ_ERR_UNSUPPORTED;
+    constexpr size_t lds_db = 2 * (BM + 128) * LDT * sizeof(float), lds_sb = (BM + 128) * LDT * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        FZ_HIP_TRY(hipFuncSetAttribute((const void*)dot_scores_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (BM + 128) * LDT * sizeof(float))));
-        FZ_HIP_TRY(hipFuncSetAttribute((const void*)dot_scores_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (BM + 64) * LDT * sizeof(float))));
+        FZ_HIP_TRY(hipFuncSetAttribute((const void*)dot_scores_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_db));
         attr_set = true;
     }
-    if (bn == 128) dot_scores_kernel<128><<<(unsigned)nblk, 256, 2 * (BM + 128) * LDT * sizeof(float), as_stream(stream)>>>(g);
-    else dot_scores_kernel<64><<<(unsigned)nblk, 256, 2 * (BM + 64) * LDT * sizeof(float), as_stream(stream)>>>(g);
+    if (single) dot_scores_kernel<false><<<(unsigned)nblk, 256, lds_sb, as_stream(stream)>>>(g);
+    else dot_scores_kernel<true><<<(unsigned)nblk, 256, lds_db, as_stream(stream)>>>(g);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }
