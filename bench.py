@@ -118,6 +118,7 @@ def build_lleqa(args, dev, rank):
                       ptf=torch.from_numpy(tf.astype(np.int32)).to(dev), idf=torch.from_numpy(idf).to(dev),
                       doc_len=torch.from_numpy(lens.astype(np.int32)).to(dev), avgdl=float(lens.mean()),
                       qoff=torch.from_numpy(qoff).to(dev), qterms=torch.from_numpy(qterms).to(dev))
+    st["bm25"]["doc_norm"] = ops.bm25_doc_norms(st["bm25"]["doc_len"], st["bm25"]["avgdl"], 2.5, 0.2)   # per index, like the idf table
     st["lens2"] = torch.full((2, Q), N, dtype=torch.int32, device=dev)
     st["Q"], st["N"], st["d"] = Q, N, d
     st["buckets"] = args.encode_buckets
@@ -137,7 +138,7 @@ def step_lleqa(st, ev=None):
     if ev: ev.mark("dpr_score")
     o_d, _, r_d = ops.sort_rows_desc(S, want_keys=False, want_rank=True)
     if ev: ev.mark("dpr_rank")
-    B = ops.bm25_scores(b["toff"], b["pdoc"], b["ptf"], b["idf"], b["doc_len"], b["avgdl"], 2.5, 0.2, b["qoff"], b["qterms"], Q, N)
+    B = ops.bm25_scores(b["toff"], b["pdoc"], b["ptf"], b["idf"], b["doc_len"], b["avgdl"], 2.5, 0.2, b["qoff"], b["qterms"], Q, N, doc_norm=b["doc_norm"])
     if ev: ev.mark("bm25_score")
     o_b, _, r_b = ops.sort_rows_desc(B, want_keys=False, want_rank=True)
     if ev: ev.mark("bm25_rank")

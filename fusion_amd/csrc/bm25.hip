@@ -3,52 +3,130 @@
 //   score(q,d) = sum over query terms, IN QUERY ORDER, of idf*tf*(k1+1) / (tf + k1*(1 - b + b*|d|/avgdl))
 // in float64, exactly the reference's expression order (no FMA contraction: -ffp-contract=off), so the
 // scores and therefore the ranks are bit-identical to the Python loop.  Documents that lack a term add
-// +-0.0 in the reference, i.e. nothing.  One workgroup per query: the postings of one term touch distinct
-// documents (parallel, no atomics); terms are applied one after the other (barrier) to keep the sum order.
+// +-0.0 in the reference, i.e. nothing.  The postings of one term touch distinct documents (parallel, no
+// atomics); terms are applied one after the other (barrier) to keep the reference's sum order.
 #include "common.h"
 
 namespace fz {
 
 struct Bm25Args {
     const int64_t* toff; const int32_t* pdoc; const int32_t* ptf; const double* idf; const int32_t* doc_len;
+    const double* doc_norm;   // nullable: k1*(1-b+b*|d|/avgdl) per document (fz_bm25_doc_norms_f64), same bits as inline
     double avgdl, k1, b;
     const int64_t* qoff; const int32_t* qterms;
     int N; double* scores; int lds;
 };
 
-__global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
-    const int q = blockIdx.x;
-    double* __restrict__ row = a.scores + (size_t)q * a.lds;
-    for (int j = threadIdx.x; j < a.N; j += blockDim.x) row[j] = 0.0;
-    __syncthreads();
-    const int64_t p0 = a.qoff[q], p1 = a.qoff[q + 1];
-    for (int64_t p = p0; p < p1; ++p) {
-        const int t = a.qterms[p];
-        if (t < 0) continue;  // out of vocabulary: idf 0 (block-uniform)
-        const double w = a.idf[t];
-        const int64_t e0 = a.toff[t], e1 = a.toff[t + 1];
-        for (int64_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-            const int dj = a.pdoc[e];
-            const double tf = (double)a.ptf[e];
-            const double num = w * (tf * (a.k1 + 1.0));
-            const double den = tf + a.k1 * (1.0 - a.b + a.b * (double)a.doc_len[dj] / a.avgdl);
-            row[dj] = row[dj] + num / den;
-        }
-        __syncthreads();  // next term may touch the same documents: keep the reference's addition order
+// LDS-resident accumulators: one workgroup = (query, slice of BM25_SLICE documents).  The random read-modify-writes of
+// the posting walk hit LDS (ds_read_b64 / ds_write_b64) instead of HBM/L2; the slice is written out once, coalesced.
+// Postings of a term are sorted by document, so the slice's sub-range is found by two block-uniform binary searches.
+constexpr int BM25_SLICE = 14336;   // 14336 fp64 accumulators = 112 KiB of the CU's 160 KiB LDS
+
+__device__ __forceinline__ int64_t lower_bound_doc(const int32_t* __restrict__ pdoc, int64_t lo, int64_t hi, int doc) {
+    while (lo < hi) {   // first e in [lo, hi) with pdoc[e] >= doc  (uniform: scalar loads)
+        const int64_t mid = (lo + hi) >> 1;
+        if (pdoc[mid] < doc) lo = mid + 1; else hi = mid;
     }
+    return lo;
+}
+
+constexpr int BM25_TERMS = 256;     // query terms whose posting ranges are resolved per batch
+
+__global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
+    extern __shared__ __attribute__((aligned(16))) double acc[];          // [BM25_SLICE] accumulators
+    __shared__ int64_t s_e0[BM25_TERMS], s_e1[BM25_TERMS];
+    __shared__ double s_w[BM25_TERMS];
+    const int q = blockIdx.y;
+    const int d0 = blockIdx.x * BM25_SLICE;
+    const int d1 = (d0 + BM25_SLICE < a.N) ? d0 + BM25_SLICE : a.N;
+    const int n = d1 - d0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) acc[j] = 0.0;
+    const int64_t p0 = a.qoff[q], p1 = a.qoff[q + 1];
+    for (int64_t pb = p0; pb < p1; pb += BM25_TERMS) {
+        const int nt = (int)((p1 - pb < BM25_TERMS) ? p1 - pb : BM25_TERMS);
+        __syncthreads();   // acc zeroed / previous batch's table no longer read
+        // all posting sub-ranges of this slice at once: one thread per term walks its own binary searches
+        // (~30 dependent loads each -- done one term after the other they were the whole kernel time)
+        if ((int)threadIdx.x < nt) {
+            const int t = a.qterms[pb + threadIdx.x];
+            int64_t e0 = 0, e1 = 0; double w = 0.0;
+            if (t >= 0) {     // out of vocabulary: idf 0, contributes nothing
+                w = a.idf[t];
+                e0 = lower_bound_doc(a.pdoc, a.toff[t], a.toff[t + 1], d0);
+                e1 = lower_bound_doc(a.pdoc, e0, a.toff[t + 1], d1);
+            }
+            s_e0[threadIdx.x] = e0; s_e1[threadIdx.x] = e1; s_w[threadIdx.x] = w;
+        }
+        __syncthreads();
+        for (int k = 0; k < nt; ++k) {          // terms in QUERY ORDER: the reference's addition order
+            const int64_t e0 = s_e0[k], e1 = s_e1[k];
+            const double w = s_w[k];
+            if (e1 <= e0) continue;             // block-uniform
+            // the walk is latency-bound (posting -> per-document gather -> accumulate): U postings per lane in flight
+            constexpr int U = 4;
+            for (int64_t eb = e0; eb < e1; eb += (int64_t)blockDim.x * U) {
+                int doc[U]; double tf[U], kd[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t e = eb + (int64_t)u * blockDim.x + threadIdx.x;
+                    const bool ok = e < e1;
+                    doc[u] = ok ? a.pdoc[e] : -1;
+                    tf[u] = ok ? (double)a.ptf[e] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int dj = doc[u] < 0 ? d0 : doc[u];
+                    kd[u] = a.doc_norm ? a.doc_norm[dj] : a.k1 * (1.0 - a.b + a.b * (double)a.doc_len[dj] / a.avgdl);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (doc[u] >= 0) {
+                        const double num = w * (tf[u] * (a.k1 + 1.0));
+                        const double den = tf[u] + kd[u];
+                        acc[doc[u] - d0] = acc[doc[u] - d0] + num / den;   // postings of one term hit distinct documents: no race
+                    }
+                }
+            }
+            __syncthreads();  // the next term may touch the same documents
+        }
+    }
+    __syncthreads();
+    double* __restrict__ row = a.scores + (size_t)q * a.lds + d0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) row[j] = acc[j];
+}
+
+__global__ void bm25_doc_norms_kernel(const int32_t* __restrict__ doc_len, int N, double avgdl, double k1, double b, double* __restrict__ out) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x)
+        out[j] = k1 * (1.0 - b + b * (double)doc_len[j] / avgdl);   // the sub-expression of bm25.py:154, once per document
 }
 
 }  // namespace fz
 
 using namespace fz;
 
+extern "C" int fz_bm25_doc_norms_f64(const int32_t* doc_len, int N, double avgdl, double k1, double b, double* out, void* stream) {
+    if (!doc_len || !out || N < 0) return FZ_ERR_ARG;
+    if (N == 0) return FZ_OK;
+    bm25_doc_norms_kernel<<<(N + 255) / 256, 256, 0, as_stream(stream)>>>(doc_len, N, avgdl, k1, b, out);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
 extern "C" int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf,
-                                  const int32_t* doc_len, double avgdl, double k1, double b, const int64_t* qoff,
+                                  const int32_t* doc_len, const double* doc_norm, double avgdl, double k1, double b, const int64_t* qoff,
                                   const int32_t* qterms, int Q, int N, double* scores, int lds, void* stream) {
     if (!toff || !idf || !doc_len || !qoff || !scores || Q < 0 || N < 0 || lds < N) return FZ_ERR_ARG;
     if (Q == 0) return FZ_OK;
-    Bm25Args a{toff, pdoc, ptf, idf, doc_len, avgdl, k1, b, qoff, qterms, N, scores, lds};
-    bm25_kernel<<<Q, 1024, 0, as_stream(stream)>>>(a);
+    if (N == 0) return FZ_OK;
+    Bm25Args a{toff, pdoc, ptf, idf, doc_len, doc_norm, avgdl, k1, b, qoff, qterms, N, scores, lds};
+    constexpr size_t lds_bytes = (size_t)BM25_SLICE * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FZ_HIP_TRY(hipFuncSetAttribute((const void*)bm25_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((N + BM25_SLICE - 1) / BM25_SLICE), (unsigned)Q);
+    bm25_kernel<<<grid, 1024, lds_bytes, as_stream(stream)>>>(a);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

@@ -381,11 +381,21 @@ def topk_merge(in_scores: torch.Tensor, in_ids: torch.Tensor):
 # ---------------------------------------------------------------------------------------
 # BM25
 # ---------------------------------------------------------------------------------------
-def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float, qoff, qterms, Q: int, N: int) -> torch.Tensor:
+def bm25_doc_norms(doc_len: torch.Tensor, avgdl: float, k1: float, b: float) -> torch.Tensor:
+    """k1*(1-b+b*|d|/avgdl) per document (the per-document sub-expression of bm25.py:154), float64."""
+    _dev(doc_len, torch.int32, "bm25_doc_norms(doc_len)")
+    out = torch.empty(doc_len.numel(), dtype=torch.float64, device=doc_len.device)
+    check(_lib.lib().fz_bm25_doc_norms_f64(_ptr(doc_len), doc_len.numel(), float(avgdl), float(k1), float(b), _ptr(out), _stream(doc_len)),
+          "fz_bm25_doc_norms_f64")
+    return out
+
+
+def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float, qoff, qterms, Q: int, N: int,
+                doc_norm: torch.Tensor | None = None) -> torch.Tensor:
     dev = idf.device
     out = torch.empty((max(Q, 1), max(round_up(N, _PAD), _PAD)), dtype=torch.float64, device=dev)[:Q, :N]
-    check(_lib.lib().fz_bm25_scores_f64(_ptr(toff), _ptr(pdoc), _ptr(ptf), _ptr(idf), _ptr(doc_len), float(avgdl), float(k1), float(b),
-                                        _ptr(qoff), _ptr(qterms), Q, N, _ptr(out), _ld(out), _stream(idf)), "fz_bm25_scores_f64")
+    check(_lib.lib().fz_bm25_scores_f64(_ptr(toff), _ptr(pdoc), _ptr(ptf), _ptr(idf), _ptr(doc_len), _ptr(doc_norm), float(avgdl), float(k1),
+                                        float(b), _ptr(qoff), _ptr(qterms), Q, N, _ptr(out), _ld(out), _stream(idf)), "fz_bm25_scores_f64")
     return out
 
 

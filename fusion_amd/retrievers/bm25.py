@@ -47,8 +47,17 @@ class BM25:
         self.idf = torch.from_numpy(self.idf_host).to(d)
         self.doc_len = torch.from_numpy(self.doc_len_host).to(d)
 
+        self._norm_key, self._norm = None, None
+
     def update_params(self, k1: float, b: float) -> None:
         self.k1, self.b = k1, b
+
+    def _doc_norm(self) -> torch.Tensor:
+        key = (self.k1, self.b)
+        if self._norm_key != key:
+            self._norm = ops.bm25_doc_norms(self.doc_len, self.avgdl, self.k1, self.b)
+            self._norm_key = key
+        return self._norm
 
     def scores(self, queries: list[str]) -> torch.Tensor:
         """[Q, N] float64 plane; query terms are NOT de-duplicated (bm25.py:152)."""
@@ -57,7 +66,8 @@ class BM25:
         np.cumsum([len(x) for x in qt], out=qoff[1:])
         flat = np.array([t for x in qt for t in x] or [0], dtype=np.int32)
         return ops.bm25_scores(self.toff, self.pdoc, self.ptf, self.idf, self.doc_len, self.avgdl, self.k1, self.b,
-                               torch.from_numpy(qoff).to(self.device), torch.from_numpy(flat).to(self.device), len(queries), self.corpus_size)
+                               torch.from_numpy(qoff).to(self.device), torch.from_numpy(flat).to(self.device), len(queries), self.corpus_size,
+                               doc_norm=self._doc_norm())
 
     def search_device(self, queries: list[str], ids: np.ndarray | None = None) -> RankedSystem:
         sc64 = self.scores(queries)

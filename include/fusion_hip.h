@@ -144,10 +144,13 @@ int fz_topk_merge(const float* in_scores, const int64_t* in_ids, int G, int rows
 /* ---- A1: BM25 scoring on device, bm25.py:149-156 -------------------------------------- */
 /* scores[q][j] (fp64) = sum over query terms in query order of idf*tf*(k1+1)/(tf+k1*(1-b+b*dl/avgdl)).
  * CSR postings by term (toff [V+1], pdoc, ptf), idf [V] fp64, doc_len [N]; queries as CSR of term
- * ids (qoff [Q+1], qterms; -1 = out of vocabulary). */
+ * ids (qoff [Q+1], qterms; -1 = out of vocabulary).
+ * doc_norm (nullable): per-document k1*(1-b+b*dl/avgdl) from fz_bm25_doc_norms_f64 -- the same fp64 bits as the inline
+ * sub-expression, computed once per document instead of once per posting. */
+int fz_bm25_doc_norms_f64(const int32_t* doc_len, int N, double avgdl, double k1, double b, double* out, void* stream);
 int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf, const int32_t* doc_len,
-                       double avgdl, double k1, double b, const int64_t* qoff, const int32_t* qterms, int Q, int N,
-                       double* scores, int lds, void* stream);
+                       const double* doc_norm, double avgdl, double k1, double b, const int64_t* qoff, const int32_t* qterms,
+                       int Q, int N, double* scores, int lds, void* stream);
 
 /* ---- N1: weight-grid sweep of the linear fusion, hybrid.py:404-426 ------------------------ */
 /* Fused ranks of the gold documents for W weight vectors at once, without fusing or sorting:
