@@ -42,7 +42,7 @@ _PROTOS = {
     "fz_abi_version": (_i, []),
     "fz_normalize_rows_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "fz_dot_scores_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
-    "fz_maxsim_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp]),
+    "fz_maxsim_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "fz_sort_max_n": (_i, []),
     "fz_sort_max_n_f64": (_i, []),
     "fz_sort_rows_desc": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -29,6 +29,7 @@ constexpr int MS_WAVES = 8;
 constexpr int MS_BLOCKS_PER_WAVE = 4;   // query blocks of 32 tokens held per wave
 constexpr int MS_DOCS_PER_WG = 32;
 constexpr int MS_TILE_BYTES = 32 * MS_DIM * 2;  // 8 KiB
+constexpr int MS_TABLE = MS_DOCS_PER_WG * 16;   // tile-table entries per workgroup (32 documents x 512 tokens)
 
 struct MaxSimArgs {
     const _Float16* Qtok;   // [Q][Lq][128]
@@ -38,12 +39,14 @@ struct MaxSimArgs {
     int Q, Lq, N;
     int QB;                 // Lq / 32
     int QG;                 // query groups = ceil(Q*QB / (MS_WAVES*MS_BLOCKS_PER_WAVE))
-    int DR;                 // document ranges = ceil(N / MS_DOCS_PER_WG)
+    int DR;                 // document ranges = ceil(N / docs_per_wg)
+    int docs_per_wg;        // <= MS_DOCS_PER_WG, chosen so that docs_per_wg * ceil(max_doc_len/32) <= MS_TABLE tiles
+    int max_doc_len;        // tokens beyond this are ignored (the reference's doc_maxlen, hybrid.py:129)
     int64_t sumL;
 };
 
 __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char tile[2][MS_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char tile[4][MS_TILE_BYTES];   // ring of 4 x 8 KiB
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int qg = idx % a.QG;
@@ -69,8 +72,8 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
         }
     }
 
-    const int d_begin = dr * MS_DOCS_PER_WG;
-    const int d_end = (d_begin + MS_DOCS_PER_WG < a.N) ? d_begin + MS_DOCS_PER_WG : a.N;
+    const int d_begin = dr * a.docs_per_wg;
+    const int d_end = (d_begin + a.docs_per_wg < a.N) ? d_begin + a.docs_per_wg : a.N;
 
     // ---- tile walk: tiles are aligned to document starts -------------------------------
     // staging: 512 threads x one 16-B chunk = one 32-token tile; thread -> (row = tid/16, chunk = tid%16)
@@ -82,7 +85,6 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
         return *reinterpret_cast<const uint4*>(a.Dtok + (size_t)t * MS_DIM + schunk * 8);
     };
 
-    auto doc_len = [&](int d) -> int { return (int)(a.Doff[d + 1] - a.Doff[d]); };
     // vals[b]: per-block sums already reduced over the wave; lane 0 writes one score per query.
     // An empty document scores 0 for every query (sum of an empty max := 0, as in the oracle).
     auto write_scores = [&](int d, const float* vals) {
@@ -100,58 +102,81 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
     };
     const float zeros[MS_BLOCKS_PER_WAVE] = {0.f, 0.f, 0.f, 0.f};
 
-    // (document, tile) walk; all bookkeeping below is block-uniform
-    int cur_doc = d_begin;
-    while (cur_doc < d_end && doc_len(cur_doc) == 0) { write_scores(cur_doc, zeros); ++cur_doc; }
-    if (cur_doc >= d_end) return;
-    const int64_t cur_tok = a.Doff[cur_doc];
-    int cur_len = doc_len(cur_doc);
-    int tile_in_doc = 0;
-    int buf = 0;
-    float run[MS_BLOCKS_PER_WAVE];
-
-    uint4 stage = stage_load(cur_tok);
-    *reinterpret_cast<uint4*>(&tile[0][swz]) = stage;
+    // ---- tile table of this document range, built ONCE into LDS ------------------------------------------
+    // (walking Doff[] with scalar global loads per tile put ~0.5 us of load latency on the critical path of every
+    //  0.45 us of MFMA work).  Tiles are aligned to document starts; entry k: first token, valid rows, document, last flag.
+    __shared__ int64_t s_tok[MS_TABLE + 4];
+    __shared__ int s_meta[MS_TABLE + 4];      // doc_local | rows_valid << 8 | last << 16
+    __shared__ int s_len[MS_DOCS_PER_WG];
+    __shared__ int s_ntiles;
+    if (tid < 64) {   // wave 0; lanes >= MS_DOCS_PER_WG idle along
+        const int d = d_begin + lane;
+        const bool live = lane < a.docs_per_wg && d < d_end;
+        const int64_t t0 = live ? a.Doff[d] : 0;
+        int len = live ? (int)(a.Doff[d + 1] - t0) : 0;
+        if (len > a.max_doc_len) len = a.max_doc_len;   // caller's doc_maxlen (hybrid.py:129)
+        const int nt = (len + 31) >> 5;
+        int incl = nt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        const int excl = incl - nt;
+        for (int i = 0; i < nt; ++i) {
+            const int rows = (len - 32 * i) < 32 ? (len - 32 * i) : 32;
+            s_tok[excl + i] = t0 + 32 * i;
+            s_meta[excl + i] = lane | (rows << 8) | ((i == nt - 1) ? (1 << 16) : 0);
+        }
+        if (lane < MS_DOCS_PER_WG) s_len[lane] = live ? len : -1;
+        if (lane == 63) s_ntiles = incl;
+    }
     __syncthreads();
+    const int ntiles = s_ntiles;
+    for (int i = 0; i < MS_DOCS_PER_WG; ++i)
+        if (s_len[i] == 0) write_scores(d_begin + i, zeros);   // empty documents
+    if (ntiles == 0) return;   // block-uniform
+
+    // ---- tile ring.  Tile k lives in slot k % 4.  Tile k+3 is fetched (global -> registers) during iteration k
+    // and written to its slot at the start of iteration k+1, i.e. two tiles ahead of its use, so ONE workgroup
+    // barrier every SECOND tile orders both the RAW (slot written -> read two iterations later) and the WAR
+    // (slot read -> overwritten two iterations later) hazards.
+    *reinterpret_cast<uint4*>(&tile[0][swz]) = stage_load(s_tok[0]);
+    if (ntiles > 1) *reinterpret_cast<uint4*>(&tile[1][swz]) = stage_load(s_tok[1]);
+    uint4 stage = make_uint4(0, 0, 0, 0);
+    if (ntiles > 2) stage = stage_load(s_tok[2]);
+    __syncthreads();
+
+    float run[MS_BLOCKS_PER_WAVE];
 #pragma unroll
     for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) run[b] = -INFINITY;
 
-    while (true) {
-        // ---- what comes next (block-uniform scalar bookkeeping) ------------------------
-        const int rows_valid = cur_len - tile_in_doc * 32;          // > 0
-        const bool last_tile_of_doc = rows_valid <= 32;
-        int nxt_doc = cur_doc, nxt_tile = tile_in_doc + 1, nxt_len = cur_len;
-        if (last_tile_of_doc) {
-            nxt_doc = cur_doc + 1; nxt_tile = 0;
-            while (nxt_doc < d_end && doc_len(nxt_doc) == 0) ++nxt_doc;
-            nxt_len = nxt_doc < d_end ? doc_len(nxt_doc) : 0;
-        }
-        const bool have_next = nxt_doc < d_end;
-        if (have_next) stage = stage_load(a.Doff[nxt_doc] + (int64_t)nxt_tile * 32);
+    for (int k = 0; k < ntiles; ++k) {
+        const int meta = __builtin_amdgcn_readfirstlane(s_meta[k]);
+        const int rows_valid = (meta >> 8) & 0xff;
+        const bool last_tile_of_doc = (meta >> 16) & 1;
+        if (k + 2 < ntiles) *reinterpret_cast<uint4*>(&tile[(k + 2) & 3][swz]) = stage;   // tile k+2: read at iteration k+2
+        if (k + 3 < ntiles) stage = stage_load(s_tok[k + 3]);
 
         // ---- A fragments from LDS: lane l -> row l&31, k = 16*ks + 8*(l>>5) .. +7 ------------
         f16x8 af[8];
         {
             const int r = lane & 31, h = lane >> 5;
-            const unsigned char* base = &tile[buf][r * 256];
+            const unsigned char* base = &tile[k & 3][r * 256];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const int chunk = 2 * ks + h;
-                af[ks] = *reinterpret_cast<const f16x8*>(base + ((chunk ^ (r & 15)) << 4));
-            }
+            for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const f16x8*>(base + (((2 * ks + h) ^ (r & 15)) << 4));
         }
-        // ---- 4 query blocks x 8 k-steps ------------------------------------------------
-#pragma unroll
-        for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) {
+        // ---- 4 query blocks x 8 k-steps, two accumulators in ping-pong: the 16-way max of block b runs on the
+        //      VALU while the MFMA chain of block b+1 occupies the matrix pipe ---------------------------------
+        auto chain = [&](int b) -> f32x16 {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bq[b][ks], acc, 0, 0, 0);
-            if (last_tile_of_doc && rows_valid < 32) {
-                // row of register r = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            return acc;
+        };
+        auto fold = [&](f32x16 acc, int b) {
+            if (rows_valid < 32) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < 16; ++r) {   // row of register r = (r&3) + 8*(r>>2) + 4*(lane>>5)
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (row >= rows_valid) acc[r] = -INFINITY;
                 }
@@ -160,6 +185,16 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[r]);
             run[b] = m;
+        };
+        {
+            f32x16 accA = chain(0);
+            f32x16 accB = chain(1);
+            fold(accA, 0);
+            accA = chain(2);
+            fold(accB, 1);
+            accB = chain(3);
+            fold(accA, 2);
+            fold(accB, 3);
         }
         // ---- end of a document: finish max over the two lane halves, sum over query tokens
         if (last_tile_of_doc) {
@@ -167,21 +202,14 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
 #pragma unroll
             for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) {
                 float m = fmaxf(run[b], __shfl_xor(run[b], 32, 64));   // both halves now hold the column max
-                // sum over the 32 columns (lanes 0..31); lanes 32..63 duplicate them
 #pragma unroll
-                for (int o = 16; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+                for (int o = 16; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);   // sum over the 32 columns
                 sums[b] = m;
                 run[b] = -INFINITY;
             }
-            write_scores(cur_doc, sums);
-            for (int d = cur_doc + 1; d < nxt_doc && d < d_end; ++d) write_scores(d, zeros);  // skipped empty documents
+            write_scores(d_begin + (meta & 0xff), sums);
         }
-        if (!have_next) break;
-        // ---- publish the prefetched tile into the other buffer --------------------------
-        *reinterpret_cast<uint4*>(&tile[buf ^ 1][swz]) = stage;
-        __syncthreads();
-        buf ^= 1;
-        cur_doc = nxt_doc; tile_in_doc = nxt_tile; cur_len = nxt_len;
+        if (k & 1) __syncthreads();   // every second tile (see the ring invariant above)
     }
 }
 
@@ -189,15 +217,16 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
 
 using namespace fz;
 
-extern "C" int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* Doff, int64_t sumL, int Q, int Lq, int N, int dim,
-                             float* scores, int lds, void* stream) {
+extern "C" int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* Doff, int64_t sumL, int max_doc_len, int Q, int Lq, int N,
+                             int dim, float* scores, int lds, void* stream) {
     if (!Qtok || !Dtok || !Doff || !scores || Q < 0 || N < 0 || Lq <= 0 || lds < N) return FZ_ERR_ARG;
     if (dim != MS_DIM) return FZ_ERR_UNSUPPORTED;
     if (Lq % 32 != 0 || (MS_BLOCKS_PER_WAVE % (Lq / 32)) != 0) return FZ_ERR_UNSUPPORTED;  // Lq in {32, 64, 128}
     if (((uintptr_t)Qtok % 16) || ((uintptr_t)Dtok % 16)) return FZ_ERR_UNSUPPORTED;
     if (Q == 0 || N == 0) return FZ_OK;
     hipStream_t st = as_stream(stream);
-    if (sumL < 0) return FZ_ERR_ARG;
+    if (sumL < 0 || max_doc_len <= 0) return FZ_ERR_ARG;
+    if (max_doc_len > 32 * MS_TABLE) return FZ_ERR_UNSUPPORTED;   // one document must fit the tile table (16,384 tokens)
     if (sumL == 0) {  // every document empty: all scores 0
         FZ_HIP_TRY(hipMemset2DAsync(scores, (size_t)lds * 4, 0, (size_t)N * 4, (size_t)Q, st));
         return FZ_OK;
@@ -209,7 +238,10 @@ extern "C" int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* 
     a.QB = Lq / 32;
     const int blocks_per_wg = MS_WAVES * MS_BLOCKS_PER_WAVE;
     a.QG = (Q * a.QB + blocks_per_wg - 1) / blocks_per_wg;
-    a.DR = (N + MS_DOCS_PER_WG - 1) / MS_DOCS_PER_WG;
+    a.max_doc_len = max_doc_len;
+    const int tiles_per_doc = (max_doc_len + 31) / 32;
+    a.docs_per_wg = MS_TABLE / tiles_per_doc < MS_DOCS_PER_WG ? MS_TABLE / tiles_per_doc : MS_DOCS_PER_WG;
+    a.DR = (N + a.docs_per_wg - 1) / a.docs_per_wg;
     const long nblk = 8L * a.QG * ((a.DR + 7) / 8);
     if (nblk > 0x7fffffffL) return FZ_ERR_UNSUPPORTED;
     maxsim_kernel<<<(unsigned)nblk, 512, 0, st>>>(a);

@@ -150,8 +150,10 @@ def cos_scores(Qe: torch.Tensor, De: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------
 # K2 MaxSim
 # ---------------------------------------------------------------------------------------
-def maxsim(Qtok: torch.Tensor, Dtok: torch.Tensor, Doff: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-    """Exact ColBERT late interaction. Qtok [Q,Lq,128] f16, Dtok [sumL,128] f16 packed, Doff [N+1] int64."""
+def maxsim(Qtok: torch.Tensor, Dtok: torch.Tensor, Doff: torch.Tensor, out: torch.Tensor | None = None,
+           max_doc_len: int | None = None) -> torch.Tensor:
+    """Exact ColBERT late interaction. Qtok [Q,Lq,128] f16, Dtok [sumL,128] f16 packed, Doff [N+1] int64.
+    max_doc_len: upper bound of the document lengths (default: measured from Doff, one small D2H read)."""
     _dev(Qtok, torch.float16, "maxsim(Qtok)")
     _dev(Dtok, torch.float16, "maxsim(Dtok)")
     _dev(Doff, torch.int64, "maxsim(Doff)")
@@ -160,8 +162,10 @@ def maxsim(Qtok: torch.Tensor, Dtok: torch.Tensor, Doff: torch.Tensor, out: torc
     N = Doff.numel() - 1
     if out is None:
         out = alloc_plane(Q, N, torch.float32, Qtok.device)
-    check(_lib.lib().fz_maxsim_f16(_ptr(Qtok), _ptr(Dtok), _ptr(Doff), int(Dtok.shape[0]), Q, Lq, N, dim, _ptr(out), _ld(out),
-                                   _stream(Qtok)), "fz_maxsim_f16")
+    if max_doc_len is None:
+        max_doc_len = max(int((Doff[1:] - Doff[:-1]).max().item()), 1) if N > 0 else 1
+    check(_lib.lib().fz_maxsim_f16(_ptr(Qtok), _ptr(Dtok), _ptr(Doff), int(Dtok.shape[0]), int(max_doc_len), Q, Lq, N, dim, _ptr(out),
+                                   _ld(out), _stream(Qtok)), "fz_maxsim_f16")
     return out
 
 

@@ -119,7 +119,7 @@ class Ranker:
         model = encoder if encoder is not None else encoders.from_pretrained(model_name_or_path, "colbert", device=_device())
         Dtok, Doff = model.encode_docs(documents, batch_size=64)
         Qtok = model.encode_queries(queries, batch_size=64)
-        scores = ops.maxsim(Qtok, Dtok, Doff)
+        scores = ops.maxsim(Qtok, Dtok, Doff, max_doc_len=model.max_doc_length)
         rs = _rank_scores(scores, ids, return_topk)
         del Dtok, Qtok
         if encoder is None:

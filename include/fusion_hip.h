@@ -70,10 +70,11 @@ int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int ldd, int Q,
 /* ---- K2: ColBERT late interaction, hybrid.py:108-137 (exact MaxSim) ------ */
 /* scores[q][j] = sum_{i<Lq} max_{t in doc j} <Qtok[q][i], Dtok[t]>.
  * Qtok [Q][Lq][dim] fp16; Dtok packed ragged [sumL][dim] fp16, doc j owns rows [Doff[j], Doff[j+1]);
- * Doff [N+1] int64 (device), sumL = Doff[N] (known to the host: rows of Dtok).
+ * Doff [N+1] int64 (device), sumL = Doff[N] (known to the host: rows of Dtok); max_doc_len = upper bound of the
+ * document lengths (the reference's doc_maxlen = 512, hybrid.py:129; tokens beyond it are ignored; <= 16384).
  * dim must be 128 (run_colbert.sh:26); Lq in {32, 64, 128} (64: hybrid.py:129).  Empty documents score 0. */
-int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* Doff, int64_t sumL, int Q, int Lq, int N, int dim,
-                  float* scores, int lds, void* stream);
+int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* Doff, int64_t sumL, int max_doc_len, int Q, int Lq, int N,
+                  int dim, float* scores, int lds, void* stream);
 
 /* ---- K5a/K6: stable descending row sort ---------------------------------------------- */
 /* Python sorted(..., reverse=True) is stable (bm25.py:104, hybrid.py:306).  For each row:
