@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--no-encode", action="store_true", help="skip the transformer forward (score+fuse only; not the headline metric)")
     p.add_argument("--encoder-size", default="base", choices=["base", "tiny"])
     p.add_argument("--encode-buckets", type=int, default=8, help="length buckets for the query encoder (1 = pad everything to the batch maximum)")
+    p.add_argument("--encode-mode", default="fused", choices=["fused", "hf"],
+                   help="fused: lean forward, linears over all buckets' tokens at once; hf: the HF module per length bucket")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--mmarco-docs", type=int, default=8841823)
     p.add_argument("--topk", type=int, default=1000)
@@ -122,6 +124,7 @@ def build_lleqa(args, dev, rank):
     st["lens2"] = torch.full((2, Q), N, dtype=torch.int32, device=dev)
     st["Q"], st["N"], st["d"] = Q, N, d
     st["buckets"] = args.encode_buckets
+    st["encode_mode"] = args.encode_mode
     st["host"] = dict(idf=idf, toff=toff, pd=pd, tf=tf, lens=lens, qoff=qoff, qterms=qterms)
     return st
 
@@ -131,7 +134,12 @@ def step_lleqa(st, ev=None):
     Q, N = st["Q"], st["N"]
     b = st["bm25"]
     if ev: ev.mark("start")
-    q_emb = st["enc"].encode_ids_bucketed(st["ids"], st["mask"], st["qlen"], st["buckets"]) if "enc" in st else st["q_emb"]
+    if "enc" not in st:
+        q_emb = st["q_emb"]
+    elif st["encode_mode"] == "fused":
+        q_emb = st["enc"].encode_ids_fused(st["ids"], st["qlen"], st["buckets"])
+    else:
+        q_emb = st["enc"].encode_ids_bucketed(st["ids"], st["mask"], st["qlen"], st["buckets"])
     if ev: ev.mark("encode")
     Qn = ops.normalize_rows(q_emb)
     S = ops.dot_scores(Qn, st["Dn"])

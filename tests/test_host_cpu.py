@@ -211,3 +211,17 @@ def test_metrics_from_gold_ranks_equals_metrics_class():
     assert list(got) == list(exp)
     for k in exp:
         assert got[k] == pytest.approx(float(exp[k]), rel=0, abs=1e-14), k
+
+
+def test_fused_forward_equals_hf_forward():
+    from fusion_amd import encoders
+    enc = encoders.random_init("dpr", device="cpu", size="tiny")
+    rng = np.random.default_rng(1)
+    n, L = 41, 30
+    lens = rng.integers(2, L + 1, n)
+    ids = rng.integers(7, 500, (n, L))
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    ids = np.where(mask == 1, ids, 1)
+    a = enc.encode_ids(torch.from_numpy(ids), torch.from_numpy(mask))
+    b = enc.encode_ids_fused(torch.from_numpy(ids), lens, n_buckets=4)
+    assert torch.allclose(a, b, atol=3e-6), float((a - b).abs().max())
