@@ -166,8 +166,23 @@ def algorithmic_work(st):
         "dpr_rank": dict(kernel="sort_rows_kernel<1024,28,1>", bound="hbm", work=e * (4 + 4 + 4), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
         "bm25_rank": dict(kernel="sort_rows_kernel<1024,28,2>", bound="hbm", work=e * (8 + 4 + 4), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
         "fuse_rrf": dict(kernel="fuse_rank_kernel", bound="hbm", work=e * (2 * 4 + 8), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
-        "final_order": dict(kernel="sort_rows_kernel<1024,28,2>+gather", bound="hbm", work=e * (8 + 4 + 4 + 8), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
+        "final_order": dict(kernel="sort_rows_kernel<1024,28,2> (placed)", bound="hbm", work=e * (8 + 4 + 4 + 8), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
     }
+
+
+def measured_traffic(stage, st):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_hbm_traffic.json; FETCH_SIZE doubled
+    per the gfx950 correction of MI355X_MICROARCH.md).  Only valid for the shape they were collected on."""
+    if (st["Q"], st["N"], st["d"]) != (1024, 27942, 768):
+        return None
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+    except OSError:
+        return None
+    key = {"dpr_score": "fz::dot_scores_kernel<true>(fz::GemmArgs)", "dpr_rank": "fz::sort_rows_kernel<1024, 28, 1>(fz::SortArgs)",
+           "bm25_rank": "fz::sort_rows_kernel<1024, 28, 2>(fz::SortArgs)", "final_order": "fz::sort_rows_kernel<1024, 28, 2>(fz::SortArgs)",
+           "fuse_rrf": "fz::fuse_rank_kernel<true>(fz::ElemArgs, double*)"}.get(stage)
+    return t.get(key, {}).get("hbm_bytes_corrected")
 
 
 def cpu_baseline_lleqa(st, S_dev, B_dev, budget_s=20.0):
@@ -270,7 +285,7 @@ def main():
         achieved = w["work"] / (kern[dom] * 1e-3)
         scale = 1e12 if w["unit"] == "TFLOP/s" else 1e9
         roof = dict(kernel=w["kernel"], stage=dom, bound=w["bound"], achieved=achieved / scale, peak=w["peak"] / scale, unit=w["unit"],
-                    frac=achieved / w["peak"], traffic=None, ms=kern[dom])
+                    frac=achieved / w["peak"], traffic=measured_traffic(dom, st), ms=kern[dom])
         all_roof = {k: dict(kernel=work[k]["kernel"], ms=kern[k], achieved=work[k]["work"] / (kern[k] * 1e-3) / (1e12 if work[k]["unit"] == "TFLOP/s" else 1e9),
                             unit=work[k]["unit"], frac=work[k]["work"] / (kern[k] * 1e-3) / work[k]["peak"]) for k in kern}
         res = {

@@ -332,6 +332,18 @@ def test_cos_scores_vs_oracle(ops, oracle, Q, N, d):
     assert np.max(np.abs(got - exp)) <= 2e-6     # contract: 1e-4 (north_star); fp32 MFMA chain is ~1e-7
 
 
+def test_splade_shaped_scoring(ops, oracle):
+    """SPLADE activations (hybrid.py:95-103): V = 32,005 non-negative sparse-ish vectors, scored DENSELY with cos_sim as
+    the reference does; 32,005 is not a multiple of 4 -> the binding zero-pads the vocabulary axis."""
+    rng = np.random.default_rng(11)
+    Q, N, V = 9, 300, 32005
+    Qe = np.log1p(np.maximum(0, rng.normal(-1.5, 1.0, (Q, V)))).astype(np.float32)     # amax log1p relu: >= 0, mostly 0
+    De = np.log1p(np.maximum(0, rng.normal(-1.0, 1.0, (N, V)))).astype(np.float32)
+    got = ops.cos_scores(dev(Qe), dev(De)).cpu().numpy()
+    exp = oracle.cos_scores(Qe, De)
+    assert got.shape == (Q, N) and np.max(np.abs(got - exp)) <= 2e-6
+
+
 def test_normalize_zero_row(ops):
     X = torch.zeros((2, 8), device="cuda"); X[1, 0] = 3.0
     Y = ops.normalize_rows(X).cpu().numpy()

@@ -68,6 +68,22 @@ def bench_gemm(Q=1024, N=27942, d=768):
     emit("normalize_rows_kernel", ms, 2 * N * d * 4, HBM, "GB/s", rows=N, d=d)
 
 
+def bench_splade(Q=1024, N=27942, V=32005):
+    """A3: SPLADE vectors scored densely like the reference (hybrid.py:101-103): 1.83 TFLOP at Q=1024."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Vp = ops.round_up(V, 4)
+    Dn = torch.zeros((N, Vp), device="cuda")
+    for c0 in range(0, N, 4096):
+        c1 = min(N, c0 + 4096)
+        Dn[c0:c1, :V] = torch.log1p(torch.relu(torch.randn((c1 - c0, V), generator=g, device="cuda") - 1.0))
+    Dn = ops.normalize_rows(Dn)
+    Qn = torch.zeros((Q, Vp), device="cuda"); Qn[:, :V] = torch.log1p(torch.relu(torch.randn((Q, V), generator=g, device="cuda") - 1.5))
+    Qn = ops.normalize_rows(Qn)
+    out = ops.alloc_plane(Q, N, torch.float32, "cuda")
+    ms = timeit(lambda: ops.dot_scores(Qn, Dn, out=out), n=3, warm=1)
+    emit("dot_scores_kernel (SPLADE V=32005)", ms, 2.0 * Q * N * V, F32, "TFLOP/s", Q=Q, N=N, d=V)
+
+
 def bench_maxsim(N=27942, Qs=(195, 1024)):
     rng = np.random.default_rng(0)
     lens = np.clip(rng.normal(300, 120, N), 16, 512).astype(np.int64)
@@ -104,7 +120,7 @@ def bench_mmarco(Q=1024, N=8841823 // 8, d=768, k=1000):
     emit("mmarco shard: GEMM+topk chunks", ms, 2.0 * Q * N * d, F32, "TFLOP/s", Q=Q, N=N, k=k)
 
 
-ALL = dict(nsf=bench_nsf, gemm=bench_gemm, maxsim=bench_maxsim, topk=bench_topk, mmarco=bench_mmarco)
+ALL = dict(nsf=bench_nsf, gemm=bench_gemm, splade=bench_splade, maxsim=bench_maxsim, topk=bench_topk, mmarco=bench_mmarco)
 if __name__ == "__main__":
     for n in (sys.argv[1:] or list(ALL)):
         ALL[n]()
