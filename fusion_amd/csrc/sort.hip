@@ -347,6 +347,73 @@ __global__ void topk_pad_kernel(float* out_scores, int64_t* out_ids, int rows, i
     }
 }
 
+// ---- streaming top-k update -------------------------------------------------------------------------------
+// After the first chunk of a corpus shard, the running k-th best score tau[row] bounds what can still enter the
+// top-k: chunks arrive in ascending id order, so an element tying with tau has a larger id than the current k-th
+// entry and loses; only s > tau (or NaN, which sorts first in this build) survives.  For i.i.d. scores the expected
+// number of survivors per row is k * chunk / seen: a few hundred.  One workgroup per row streams the chunk (16-B
+// loads), compacts the survivors STABLY (ascending column = ascending id) behind the running list, and the ordinary
+// row sort then merges [running k | survivors] (ties: running entries first, then ascending id).
+// A row with more survivors than `cap` sets *overflow (checked by the caller, who redoes that chunk exactly).
+struct FilterArgs {
+    const float* scores; int n; long ld;     // chunk [rows][ld]
+    int64_t id_base;
+    const float* run_scores;                 // [rows][k] current top-k (sorted desc; -inf padding)
+    const int64_t* run_ids;                  // [rows][k]
+    int k, cap;
+    float* buf_scores; int64_t* buf_ids;     // [rows][k + cap]: running list copied to the front, survivors behind
+    int32_t* buf_len;                        // [rows] = k + survivors
+    int32_t* overflow;                       // set to 1 if any row exceeded cap
+};
+
+__global__ __launch_bounds__(1024) void topk_filter_kernel(FilterArgs a) {
+    constexpr int T = 1024, NW = T / 64;
+    __shared__ int wtot[NW];
+    const int row = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* __restrict__ x = a.scores + (size_t)row * a.ld;
+    float* __restrict__ bs = a.buf_scores + (size_t)row * (a.k + a.cap);
+    int64_t* __restrict__ bi = a.buf_ids + (size_t)row * (a.k + a.cap);
+    for (int i = threadIdx.x; i < a.k; i += T) { bs[i] = a.run_scores[(size_t)row * a.k + i]; bi[i] = a.run_ids[(size_t)row * a.k + i]; }
+    const float tau = a.run_scores[(size_t)row * a.k + a.k - 1];   // k-th best so far (-inf while the list is short)
+    const bool vec = (a.ld % 4 == 0) && ((uintptr_t)a.scores % 16 == 0);
+    int base = 0;
+    bool over = false;
+    for (int c0 = 0; c0 < a.n; c0 += 4 * T) {
+        const int j0 = c0 + 4 * threadIdx.x;
+        float v[4];
+        if (vec && j0 + 3 < a.n) { const float4 f = *reinterpret_cast<const float4*>(x + j0); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (j0 + c < a.n) ? x[j0 + c] : -INFINITY;
+        }
+        int cnt = 0;
+        bool keep[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { keep[c] = (j0 + c < a.n) && (v[c] > tau || v[c] != v[c]); cnt += keep[c] ? 1 : 0; }
+        // stable block-wide exclusive prefix of cnt
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        __syncthreads();
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { const int c = wtot[i]; if (i < w) woff += c; tot += c; }
+        int pos = base + woff + incl - cnt;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (keep[c]) {
+                if (pos < a.cap) { bs[a.k + pos] = v[c]; bi[a.k + pos] = a.id_base + j0 + c; }
+                else over = true;
+                ++pos;
+            }
+        base += tot;
+    }
+    if (threadIdx.x == 0) a.buf_len[row] = a.k + (base < a.cap ? base : a.cap);
+    if (over) atomicExch(a.overflow, 1);
+}
+
 struct SortCfg { int T, E; };
 
 static inline bool pick_cfg(int n, int kw, SortCfg& c) {
@@ -498,6 +565,40 @@ extern "C" int fz_topk_rows_f32(const float* scores, int rows, int n, int ld, in
     a.sorted_keys = out_scores; a.out_ids = out_ids; a.id_base = id_base; a.out_row_stride = k; a.out_limit = have;
     a.colmap = cur_cols; a.colmap_row_stride = cur_stride;
     return launch_sort(a, 1, rows, cur, st);
+}
+
+extern "C" size_t fz_topk_update_workspace_bytes(int rows, int k, int cap) {
+    if (rows <= 0 || k <= 0 || cap <= 0) return 0;
+    return (size_t)rows * (k + cap) * (4 + 8) + (size_t)rows * 4 + 256;
+}
+
+/* One streaming step of the chunked top-k (sentence_transformers.py:346-364): merge a new chunk of scores into the
+ * running per-row top-k.  run_* [rows][k] in, new_* [rows][k] out (distinct buffers).  *overflow (device int32,
+ * zeroed by the caller) becomes 1 if some row had more than `cap` candidates above its running threshold: the caller
+ * must then redo this chunk with fz_topk_rows_f32 + fz_topk_merge (exact, slower).  k + cap <= 35840. */
+extern "C" int fz_topk_update_f32(const float* scores, int rows, int n, int ld, int64_t id_base, const float* run_scores,
+                                  const int64_t* run_ids, int k, int cap, float* new_scores, int64_t* new_ids, int32_t* overflow,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (!scores || !run_scores || !run_ids || !new_scores || !new_ids || !overflow || rows < 0 || n < 0 || ld < n || k <= 0 || cap <= 0)
+        return FZ_ERR_ARG;
+    if ((long)k + cap > 35840) return FZ_ERR_UNSUPPORTED;
+    if (rows == 0) return FZ_OK;
+    if (!workspace || workspace_bytes < fz_topk_update_workspace_bytes(rows, k, cap)) return FZ_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    char* ws = reinterpret_cast<char*>(workspace);
+    FilterArgs f{};
+    f.scores = scores; f.n = n; f.ld = ld; f.id_base = id_base; f.run_scores = run_scores; f.run_ids = run_ids; f.k = k; f.cap = cap;
+    f.buf_ids = reinterpret_cast<int64_t*>(ws); ws += (size_t)rows * (k + cap) * 8;
+    f.buf_scores = reinterpret_cast<float*>(ws); ws += (size_t)rows * (k + cap) * 4;
+    f.buf_len = reinterpret_cast<int32_t*>(ws);
+    f.overflow = overflow;
+    topk_filter_kernel<<<rows, 1024, 0, st>>>(f);
+    FZ_LAUNCH_CHECK();
+    SortArgs a{};
+    a.keys = f.buf_scores; a.row_len = f.buf_len; a.n_total = k + cap; a.key_row_stride = k + cap; a.seg_len = k + cap;
+    a.chunks = 1; a.chunk_len = k + cap;
+    a.sorted_keys = new_scores; a.out_ids = new_ids; a.idmap = f.buf_ids; a.out_row_stride = k; a.out_limit = k;
+    return launch_sort(a, 1, rows, k + cap, st);
 }
 
 extern "C" int fz_topk_merge(const float* in_scores, const int64_t* in_ids, int G, int rows, int k, float* out_scores,

@@ -49,22 +49,31 @@ class ShardedDenseIndex:
     """One rank's shard of the L2-normalised corpus embeddings + the chunked score -> top-k loop."""
 
     CHUNK = 8 * 28672   # documents per GEMM launch: 8 sort-kernel rows per query
+    CAP = 7168          # candidate slots per row and chunk on the streaming path (k + CAP = one 8192-key sort row at k = 1024)
 
     def __init__(self, Dn_local: torch.Tensor, id_base: int, group=None):
         self.Dn, self.id_base, self.group = Dn_local, int(id_base), group
 
-    def local_topk(self, Qn: torch.Tensor, k: int):
+    def local_topk(self, Qn: torch.Tensor, k: int, streaming: bool = True):
+        """Chunked score -> top-k over this shard.  First chunk: exact chunk-sort-truncate.  Later chunks: only scores
+        above the running k-th best can enter, so they go through the streaming threshold filter (ops.topk_update);
+        if any row overflowed its candidate buffer the search is redone on the exact path (flag read once, at the end)."""
         from . import ops
         n = self.Dn.shape[0]
         best_s = best_i = None
+        overflow = None
         for c0 in range(0, max(n, 1), self.CHUNK):
             c1 = min(n, c0 + self.CHUNK)
             S = ops.dot_scores(Qn, self.Dn[c0:c1])
-            s, i = ops.topk_rows(S, k, id_base=self.id_base + c0)
             if best_s is None:
-                best_s, best_i = s, i
-            else:   # running top-k: merge two id-ascending lists (chunks arrive in id order)
+                best_s, best_i = ops.topk_rows(S, k, id_base=self.id_base + c0)
+            elif streaming and k + self.CAP <= 35840:
+                best_s, best_i, overflow = ops.topk_update(S, self.id_base + c0, best_s, best_i, self.CAP, overflow)
+            else:   # exact path: per-chunk top-k, then merge two id-ascending lists (chunks arrive in id order)
+                s, i = ops.topk_rows(S, k, id_base=self.id_base + c0)
                 best_s, best_i = ops.topk_merge(torch.stack([best_s, s]), torch.stack([best_i, i]))
+        if overflow is not None and int(overflow.item()) != 0:
+            return self.local_topk(Qn, k, streaming=False)
         return best_s, best_i
 
     def search(self, Qn: torch.Tensor, k: int = 1000):

@@ -370,6 +370,28 @@ def topk_rows(scores: torch.Tensor, k: int, id_base: int = 0):
     return os_, oi
 
 
+def topk_update(scores: torch.Tensor, id_base: int, run_scores: torch.Tensor, run_ids: torch.Tensor, cap: int = 7168,
+                overflow: torch.Tensor | None = None):
+    """Merge one more chunk of scores into the running top-k (streaming threshold filter + small sort).
+    Returns (new_scores, new_ids, overflow_flag_tensor); the caller checks the flag once at the end of the search."""
+    _dev(scores, torch.float32, "topk_update(scores)")
+    _dev(run_scores, torch.float32, "topk_update(run_scores)")
+    _dev(run_ids, torch.int64, "topk_update(run_ids)")
+    rows, n = scores.shape
+    k = run_scores.shape[1]
+    dev = scores.device
+    lib = _lib.lib()
+    if overflow is None:
+        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    ns = torch.empty((rows, k), dtype=torch.float32, device=dev)
+    ni = torch.empty((rows, k), dtype=torch.int64, device=dev)
+    wsb = int(lib.fz_topk_update_workspace_bytes(rows, k, cap))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    check(lib.fz_topk_update_f32(_ptr(scores), rows, n, _ld(scores), int(id_base), _ptr(run_scores.contiguous()), _ptr(run_ids.contiguous()), k, cap,
+                                 _ptr(ns), _ptr(ni), _ptr(overflow), _ptr(ws), wsb, _stream(scores)), "fz_topk_update_f32")
+    return ns, ni, overflow
+
+
 def topk_merge(in_scores: torch.Tensor, in_ids: torch.Tensor):
     """[G,rows,k] per-shard lists -> global top-k [rows,k] (after the RCCL all-gather)."""
     _dev(in_scores, torch.float32, "topk_merge(in_scores)")

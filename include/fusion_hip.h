@@ -138,6 +138,15 @@ int fz_topk_max_k(void);
 size_t fz_topk_workspace_bytes(int rows, int n, int k);
 int fz_topk_rows_f32(const float* scores, int rows, int n, int ld, int k, int64_t id_base, float* out_scores,
                      int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream);
+/* streaming form of the same loop: merge one more chunk of scores into the running per-row top-k.  Only scores strictly
+ * above a row's current k-th best can enter (chunks arrive in ascending id order, so ties lose), so the chunk is filtered
+ * in one streaming pass and only the survivors (+ the running list) are sorted.  run_* [rows][k] -> new_* [rows][k]
+ * (distinct buffers, sorted by score desc, id asc; (-inf,-1) padding).  *overflow (device int32, zeroed by the caller)
+ * is set when a row had more than `cap` survivors: redo that chunk with fz_topk_rows_f32 + fz_topk_merge. */
+size_t fz_topk_update_workspace_bytes(int rows, int k, int cap);
+int fz_topk_update_f32(const float* scores, int rows, int n, int ld, int64_t id_base, const float* run_scores,
+                       const int64_t* run_ids, int k, int cap, float* new_scores, int64_t* new_ids, int32_t* overflow,
+                       void* workspace, size_t workspace_bytes, void* stream);
 /* merge G per-shard lists [G][rows][k] (as all-gathered over RCCL) into the global top-k [rows][k] */
 int fz_topk_merge(const float* in_scores, const int64_t* in_ids, int G, int rows, int k, float* out_scores, int64_t* out_ids,
                   void* stream);

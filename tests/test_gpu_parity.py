@@ -410,6 +410,29 @@ def test_topk_merge(ops, oracle):
     np.testing.assert_array_equal(gi.cpu().numpy(), fi)
 
 
+@pytest.mark.parametrize("streaming", [True, False])
+def test_sharded_index_search_equals_oracle(ops, oracle, streaming):
+    """Chunked GEMM -> (streaming) top-k over a shard == oracle top-k of the full score matrix (given the device's scores)."""
+    from fusion_amd.distributed import ShardedDenseIndex
+    g = torch.Generator(device="cuda").manual_seed(0)
+    N, d, Q, k = 70000, 64, 6, 100
+    Dn = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
+    Qn = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
+    idx = ShardedDenseIndex(Dn, id_base=5_000_000_000)
+    idx.CHUNK = 16384            # 5 chunks: first exact, then 4 updates
+    idx.CAP = 2000
+    s, i = idx.local_topk(Qn, k, streaming=streaming)
+    S = ops.dot_scores(Qn, Dn).cpu().numpy()
+    es, ei = oracle.topk_rows(S, k, id_base=5_000_000_000)
+    np.testing.assert_array_equal(s.cpu().numpy(), es)
+    np.testing.assert_array_equal(i.cpu().numpy(), ei)
+    # candidate-buffer overflow falls back to the exact path (ascending scores: everything beats the threshold)
+    S2 = torch.arange(Q * 40000, device="cuda", dtype=torch.float32).reshape(Q, 40000) / 7.0
+    rs, ri = ops.topk_rows(ops.as_plane(S2[:, :16384].contiguous()), k)
+    ns, ni, flag = ops.topk_update(ops.as_plane(S2[:, 16384:].contiguous()), 16384, rs, ri, cap=500)
+    assert int(flag.item()) == 1
+
+
 # ---- BM25 ----------------------------------------------------------------------------------------------
 def test_bm25_matches_reference_golden():
     from fusion_amd.retrievers.bm25 import BM25
