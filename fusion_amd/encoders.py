@@ -128,7 +128,9 @@ class FusedBertForward:
             keep = torch.arange(L, device=dev).unsqueeze(0) < lens.unsqueeze(1)             # [b, L] real tokens
             pos = torch.where(keep, torch.arange(L, device=dev).unsqueeze(0) + self.pad_idx + 1,
                               torch.full((1, 1), self.pad_idx, device=dev, dtype=torch.long))  # RoBERTa position ids
-            buckets.append((sel, len(idx), L, off, keep, lens))
+            # additive key mask built ONCE per bucket (SDPA would otherwise re-materialise it from the bool mask in every layer)
+            amask = torch.zeros((len(idx), 1, 1, L), dtype=torch.float32, device=dev).masked_fill_(~keep[:, None, None, :], float("-inf"))
+            buckets.append((sel, len(idx), L, off, keep, lens, amask))
             ids_rows.append(ids.reshape(-1)); pos_rows.append(pos.reshape(-1))
             off += len(idx) * L
         ids_cat, pos_cat = torch.cat(ids_rows), torch.cat(pos_rows)
@@ -139,16 +141,16 @@ class FusedBertForward:
         for ly in self.layers:
             qkv = F.linear(x, ly["wqkv"], ly["bqkv"])                                        # [T, 3*hidden], one GEMM
             ctx = torch.empty_like(x)
-            for sel, b, L, o, keep, lens in buckets:
+            for sel, b, L, o, keep, lens, amask in buckets:
                 blk = qkv[o: o + b * L].view(b, L, 3, H, D)
                 q, k, v = blk[:, :, 0].transpose(1, 2), blk[:, :, 1].transpose(1, 2), blk[:, :, 2].transpose(1, 2)
-                a = F.scaled_dot_product_attention(q, k, v, attn_mask=keep[:, None, None, :])
+                a = F.scaled_dot_product_attention(q, k, v, attn_mask=amask)
                 ctx[o: o + b * L] = a.transpose(1, 2).reshape(b * L, H * D)
             x = F.layer_norm(F.linear(ctx, ly["wo"], ly["bo"]) + x, (x.shape[1],), *ly["ln1"])
             h = F.gelu(F.linear(x, ly["w1"], ly["b1"]))
             x = F.layer_norm(F.linear(h, ly["w2"], ly["b2"]) + x, (x.shape[1],), *ly["ln2"])
         out = torch.empty((n, x.shape[1]), dtype=torch.float32, device=dev)
-        for sel, b, L, o, keep, lens in buckets:
+        for sel, b, L, o, keep, lens, amask in buckets:
             hb = x[o: o + b * L].view(b, L, -1)
             m = keep.unsqueeze(-1).to(hb.dtype)
             out.index_copy_(0, sel, ((hb * m).sum(1) / lens.clamp_min(1).unsqueeze(1).to(hb.dtype)).float())   # Pooling(mean)
