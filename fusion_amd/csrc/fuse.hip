@@ -154,7 +154,7 @@ struct NsfArgs {
     const float* distr[FZ_MAX_SYSTEMS];
     int P[FZ_MAX_SYSTEMS];
     float w[FZ_MAX_SYSTEMS];
-    int S, N, ld;
+    int S, N, ld, Q;
 };
 
 // Combined block reduction of up to 3 doubles (one barrier pair for all statistics of a row).
@@ -232,10 +232,22 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
     float* rowbuf = reinterpret_cast<float*>(smem_raw);                                 // DMA: [T*E4*4] floats
     double* red_d = reinterpret_cast<double*>(smem_raw + (DMA ? (size_t)T * E4 * 16 : 0)); // [2][3*T/64]
     float* red_f = reinterpret_cast<float*>(red_d + 2 * 3 * T / 64);                    // [2][3*T/64]
-    const int q = blockIdx.x;
     const int N = a.N;
-    const size_t rowoff = (size_t)q * a.ld;
     const int lane = threadIdx.x & 63;
+    // persistent workgroups (DMA): rows blockIdx.x, blockIdx.x + gridDim.x, ...; the first system of the NEXT row is
+    // already streaming into LDS while the current row's last system is transformed and the result stored, so there is
+    // no launch / first-load bubble at row boundaries (one 1024-thread workgroup fills a CU: nothing else could hide it)
+    int red_parity = 0;
+    if (DMA && blockIdx.x < a.Q) {
+        const float* __restrict__ x0 = a.planes[0] + (size_t)blockIdx.x * a.ld;
+#pragma unroll
+        for (int i = 0; i < E4; ++i) {
+            const int j0 = 4 * (threadIdx.x + T * i);
+            if (j0 < N) __builtin_amdgcn_global_load_lds(x0 + j0, (__attribute__((address_space(3))) void*)(rowbuf + 4 * (threadIdx.x - lane + T * i)), 16, 0, 0);
+        }
+    }
+  for (int q = blockIdx.x; q < a.Q; q += gridDim.x) {
+    const size_t rowoff = (size_t)q * a.ld;
 
     float acc[E4][4];
     uint64_t present = 0ull;   // VALID only: some system lists the column (bit 4*i+c)
@@ -247,8 +259,8 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
     float v[E4][4];
     uint64_t ok = 0ull;        // column inside the row (and listed by the system when VALID)
 
-    auto dma_row = [&](int s) {   // HBM -> LDS, one 1-KiB piece per wave-instruction; lanes past the row end stay off
-        const float* __restrict__ x = a.planes[s] + rowoff;
+    auto dma_row = [&](int s, size_t roff) {   // HBM -> LDS, one 1-KiB piece per wave-instruction; lanes past the row end stay off
+        const float* __restrict__ x = a.planes[s] + roff;
 #pragma unroll
         for (int i = 0; i < E4; ++i) {
             const int j0 = 4 * (threadIdx.x + T * i);
@@ -293,12 +305,12 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
         }
     };
 
-    if (DMA) dma_row(0);
     for (int s = 0; s < a.S; ++s) {
         take_row(s);
-        if (DMA && s + 1 < a.S) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // our ds_reads of row s are done before the DMA overwrites the slots
-            dma_row(s + 1);                                       // in flight during the reduction + transform below
+        if (DMA) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // our ds_reads of this row are done before the DMA overwrites the slots
+            if (s + 1 < a.S) dma_row(s + 1, rowoff);             // in flight during the reduction + transform below
+            else if (q + (int)gridDim.x < a.Q) dma_row(0, (size_t)(q + gridDim.x) * a.ld);   // next row's first system
         }
         float sa = 0.f, sb = 0.f;
         if (NORM == FZ_NORM_MINMAX) {
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
                     mx = fmaxf(mx, in ? x : -INFINITY);
                     nanf_ = (in && x != x) ? 1.f : nanf_;
                 }
-            block_minmax_nan<T>(mn, mx, nanf_, red_f, s & 1);
+            block_minmax_nan<T>(mn, mx, nanf_, red_f, red_parity); red_parity ^= 1;
             sa = nanf_ > 0.f ? __uint_as_float(0x7fc00000u) : mn;   // torch.min/max propagate NaN
             sb = nanf_ > 0.f ? __uint_as_float(0x7fc00000u) : mx;
         } else if (NORM == FZ_NORM_ZSCORE) {
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
                     const double d = in ? (double)v[i][c] - x0 : 0.0;
                     st[0] += d; st[1] += d * d; st[2] += in ? 1.0 : 0.0;
                 }
-            block_sum_n_nodrain<T, 3>(st, red_d, s & 1);
+            block_sum_n_nodrain<T, 3>(st, red_d, red_parity); red_parity ^= 1;
             const double n = st[2];
             const double mean = n > 0.0 ? x0 + st[0] / n : (double)NAN;
             const double var = n > 1.0 ? (st[1] - st[0] * st[0] / n) / (n - 1.0) : (double)NAN;
@@ -381,6 +393,7 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
                 if (j0 + c < N) out[j0 + c] = o[c];
         }
     }
+  }   // persistent row loop
 }
 
 // general-N path: statistics from a separate pass (stat arrays [S][Q]), then elementwise.
@@ -562,7 +575,9 @@ static int launch_nsf_cfg(const NsfArgs& a, int Q, float* fused, hipStream_t st)
         FZ_HIP_TRY(hipFuncSetAttribute((const void*)fuse_nsf_row_kernel<NORM, TT, E4, VEC, VALID, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    fuse_nsf_row_kernel<NORM, TT, E4, VEC, VALID, DMA><<<Q, TT, lds, st>>>(a, fused);
+    // DMA variants are persistent: one workgroup per CU (256 CUs) walks the rows; the others launch one per row
+    const int grid = DMA ? (Q < 256 ? Q : 256) : Q;
+    fuse_nsf_row_kernel<NORM, TT, E4, VEC, VALID, DMA><<<grid, TT, lds, st>>>(a, fused);
     return 0;
 }
 
@@ -595,7 +610,7 @@ extern "C" int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* cons
     if (needs_distr && (!distr_h || !P_h)) return FZ_ERR_ARG;
     if (Q == 0 || N == 0) return FZ_OK;
     NsfArgs a{};
-    a.S = S; a.N = N; a.ld = ld;
+    a.S = S; a.N = N; a.ld = ld; a.Q = Q;
     for (int s = 0; s < S; ++s) {
         if (!planes_h[s]) return FZ_ERR_ARG;
         a.planes[s] = planes_h[s];
@@ -631,7 +646,7 @@ extern "C" int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t
     if (needs_distr && (!distr_h || !P_h)) return FZ_ERR_ARG;
     if (Q == 0 || N == 0) return FZ_OK;
     NsfArgs a{};
-    a.S = S; a.N = N; a.ld = ld;
+    a.S = S; a.N = N; a.ld = ld; a.Q = Q;
     for (int s = 0; s < S; ++s) {
         if (!planes_h[s]) return FZ_ERR_ARG;
         a.planes[s] = planes_h[s];

@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the HIP library is built in-tree and git-ignored: a fresh clone builds it here (hipcc cross-compiles without a GPU)
+    from fusion_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
 
 
 @pytest.fixture(scope="session")
