@@ -338,14 +338,16 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
             const double x0 = (double)x0c;
             double st[3] = {0.0, 0.0, 0.0};   // sum d, sum d^2, count
 #pragma unroll
-            for (int i = 0; i < E4; ++i)
+            for (int i = 0; i < E4; ++i) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                {
+                for (int c = 0; c < 4; ++c) {
                     const bool in = (ok >> (4 * i + c)) & 1ull;
                     const double d = in ? (double)v[i][c] - x0 : 0.0;
-                    st[0] += d; st[1] += d * d; st[2] += in ? 1.0 : 0.0;
+                    st[0] += d; st[1] += d * d;
                 }
+                __builtin_amdgcn_sched_barrier(0);   // keep the fp64 temporaries of 4 elements, not 28, alive
+            }
+            st[2] = (double)__popcll(ok);
             block_sum_n_nodrain<T, 3>(st, red_d, red_parity); red_parity ^= 1;
             const double n = st[2];
             const double mean = n > 0.0 ? x0 + st[0] / n : (double)NAN;
@@ -698,9 +700,10 @@ extern "C" int fz_fuse_none_f64(const float* const* planes_h, const int32_t* con
 
 extern "C" int fz_fuse_rank_f64(const int32_t* const* ranks_h, const int32_t* lens, int S, int Q, int N, int ld, int method,
                                 double* fused, void* stream) {
-    if (!ranks_h || !lens || !fused || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (Q == 0 || N == 0) return (method == FZ_RRF || method == FZ_BCF) ? FZ_OK : FZ_ERR_ARG;   // empty tensors carry null pointers
+    if (!ranks_h || !lens || !fused) return FZ_ERR_ARG;
     if (method != FZ_RRF && method != FZ_BCF) return FZ_ERR_ARG;
-    if (Q == 0 || N == 0) return FZ_OK;
     ElemArgs a{};
     a.S = S; a.N = N; a.ld = ld; a.Q = Q; a.method = method; a.lens = lens;
     for (int s = 0; s < S; ++s) {

@@ -460,8 +460,9 @@ extern "C" int fz_sort_max_n_f64(void) { return 28672; }
 
 extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows,
                                  int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream) {
-    if (!keys || (key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
-    if (rows == 0 || n == 0) return FZ_OK;
+    if ((key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
+    if (rows == 0 || n == 0) return FZ_OK;      // nothing to do (empty tensors carry null pointers)
+    if (!keys) return FZ_ERR_ARG;
     if (n > (key_bits == 32 ? 35840 : 28672)) return FZ_ERR_UNSUPPORTED;
     SortArgs a{};
     a.keys = keys; a.init_order = init_order; a.row_len = row_len;
@@ -474,8 +475,9 @@ extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* 
 
 extern "C" int fz_sort_rows_desc_placed(const void* keys, int key_bits, const int32_t* init_rank, const int32_t* row_len, int rows,
                                         int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream) {
-    if (!keys || !init_rank || (key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
+    if ((key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
     if (rows == 0 || n == 0) return FZ_OK;
+    if (!keys || !init_rank) return FZ_ERR_ARG;
     if (n > (key_bits == 32 ? 35840 : 28672)) return FZ_ERR_UNSUPPORTED;
     SortArgs a{};
     a.keys = keys; a.init_rank = init_rank; a.row_len = row_len;
@@ -521,9 +523,10 @@ extern "C" size_t fz_topk_workspace_bytes(int rows, int n, int k) {
 
 extern "C" int fz_topk_rows_f32(const float* scores, int rows, int n, int ld, int k, int64_t id_base, float* out_scores,
                                 int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!scores || !out_scores || !out_ids || rows < 0 || n < 0 || ld < n || k <= 0) return FZ_ERR_ARG;
+    if (rows < 0 || n < 0 || ld < n || k <= 0) return FZ_ERR_ARG;
     if (k > fz_topk_max_k()) return FZ_ERR_UNSUPPORTED;
     if (rows == 0) return FZ_OK;
+    if (!out_scores || !out_ids || (!scores && n > 0)) return FZ_ERR_ARG;
     hipStream_t st = as_stream(stream);
     const int have = n < k ? n : k;
     if (have < k) {

@@ -312,3 +312,68 @@ def from_pretrained(model_name_or_path: str, kind: str, device="cuda"):
         enc = ColbertEncoder(AutoModel.from_pretrained(model_name_or_path, local_files_only=True), _Tok(), device)
         return enc
     raise ValueError(kind)
+
+
+class CrossEncoder(_Base):
+    """monoBERT reranker (hybrid.py:139-163, CrossEncoderCustom): CamemBERT sequence classifier over "<s> query </s></s> doc </s>",
+    one logit per pair, fp32.  `predict(pairs)` is what Ranker.cross_encoder_search calls."""
+
+    def __init__(self, classifier, tokenizer, device, max_length: int = 512):
+        super().__init__(tokenizer, device)
+        self.model = classifier.to(self._device).eval()
+        self._clamp_lengths(classifier.config)
+        self.max_length = min(max_length, self.max_doc_length)
+
+    @torch.no_grad()
+    def predict(self, pairs: list[tuple[str, str]], batch_size: int = 64) -> torch.Tensor:
+        out = torch.empty(len(pairs), dtype=torch.float32, device=self._device)
+        texts = [q + " </s> " + d for q, d in pairs]    # HashTokenizer has no pair API: the separator is an ordinary token
+        for idx, ids, mask in self._batches(texts, batch_size, self.max_length):
+            logits = self.model(input_ids=ids, attention_mask=mask).logits
+            out[torch.tensor(idx, device=self._device)] = logits[:, 0].float()
+        return out
+
+
+def random_cross_encoder(device="cuda", size: str = "tiny", seed: int = 0):
+    from transformers import CamembertConfig, CamembertForSequenceClassification
+    cfg = dict(CAMEMBERT_BASE if size == "base" else TINY)
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        model = CamembertForSequenceClassification(CamembertConfig(num_labels=1, **cfg))
+        tok = HashTokenizer(cfg["vocab_size"], cfg["pad_token_id"], cfg["bos_token_id"], cfg["eos_token_id"])
+        return CrossEncoder(model, tok, device)
+    finally:
+        torch.random.set_rng_state(g)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N2: corpus-side cache.  run_hybrid.sh starts one process per (combo, fusion, normalisation): 99 processes that each
+# re-encode the same 27.9 k articles with the same checkpoint (hybrid.py:101, run_hybrid.sh:43).  The encoded corpus is
+# a pure function of (checkpoint, corpus text): keep it on disk, keyed by both, and memory-map it back.
+# ---------------------------------------------------------------------------------------------------------------
+def corpus_cache_key(model_name_or_path: str, documents: list[str], extra: str = "") -> str:
+    h = hashlib.blake2b(digest_size=16)
+    h.update(model_name_or_path.encode()); h.update(extra.encode()); h.update(str(len(documents)).encode())
+    for d in documents:
+        h.update(hashlib.blake2b(d.encode("utf-8"), digest_size=8).digest())
+    return h.hexdigest()
+
+
+def cached_tensors(cache_dir: str | None, key: str, names: list[str], compute):
+    """Return `compute()`'s tensors (tuple, CPU or GPU), loading them from / saving them to `cache_dir/key.*.npy`."""
+    import os
+    import numpy as np
+    if cache_dir is None:
+        return compute()
+    paths = [os.path.join(cache_dir, f"{key}.{n}.npy") for n in names]
+    if all(os.path.exists(p) for p in paths):
+        return tuple(torch.from_numpy(np.array(np.load(p, mmap_mode="r"))) for p in paths)   # memory-mapped read
+    out = compute()
+    os.makedirs(cache_dir, exist_ok=True)
+    for p, t in zip(paths, out):
+        tmp = p + f".tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            np.save(f, t.detach().cpu().numpy())
+        os.replace(tmp, p)       # atomic: concurrent sweep processes never see a half-written file
+    return out

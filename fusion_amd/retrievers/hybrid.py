@@ -90,15 +90,19 @@ class Ranker:
 
     @staticmethod
     def single_vector_search(queries: list[str], corpus: dict[int, str], model_name_or_path: str, return_topk: int = None,
-                             *, encoder=None, as_device: bool = False):
+                             *, encoder=None, as_device: bool = False, cache_dir: str | None = None):
         """hybrid.py:77-106: encode docs + queries (batch 64), cosine similarity, full ranking.
-        `encoder` (optional) injects an already-built fusion_amd.encoders module (e.g. random_init for synthetic runs)."""
+        `encoder` (optional) injects an already-built fusion_amd.encoders module (e.g. random_init for synthetic runs);
+        `cache_dir` (optional) keeps the encoded corpus on disk, keyed by (checkpoint, corpus text) -- the sweep of
+        scripts/run_hybrid.sh otherwise re-encodes the corpus in each of its 99 processes."""
         from .. import encoders
         documents = list(corpus.values())
         ids = np.array(list(corpus.keys()))
         kind = "splade" if "splade" in model_name_or_path.lower() else "dpr"
         model = encoder if encoder is not None else encoders.from_pretrained(model_name_or_path, kind, device=_device())
-        d_embs = model.encode(documents, batch_size=64, query_mode=False)
+        key = encoders.corpus_cache_key(model_name_or_path, documents, kind) if cache_dir else ""
+        (d_embs,) = encoders.cached_tensors(cache_dir, key, ["emb"], lambda: (model.encode(documents, batch_size=64, query_mode=False),))
+        d_embs = d_embs.to(_device())
         q_embs = model.encode(queries, batch_size=64, query_mode=True)
         scores = ops.cos_scores(q_embs, d_embs)   # hybrid.py:103 always uses cos_sim (SURVEY D13)
         rs = _rank_scores(scores, ids, return_topk)
@@ -110,14 +114,18 @@ class Ranker:
 
     @staticmethod
     def multi_vector_search(queries: list[str], corpus: dict[int, str], model_name_or_path: str, output_dir: str = "output",
-                            return_topk: int = None, *, encoder=None, as_device: bool = False):
+                            return_topk: int = None, *, encoder=None, as_device: bool = False, cache_dir: str | None = None):
         """hybrid.py:108-137.  The reference goes through colbert-ai's PLAID index (approximate, candidate-pruned);
         here every (query, document) pair gets its exact MaxSim score on the device, a superset ranking of PLAID's."""
         from .. import encoders
         documents = list(corpus.values())
         ids = np.array(list(corpus.keys()))
         model = encoder if encoder is not None else encoders.from_pretrained(model_name_or_path, "colbert", device=_device())
-        Dtok, Doff = model.encode_docs(documents, batch_size=64)
+        # the reference reuses its on-disk PLAID index when it exists (hybrid.py:126-130); the analogue here is the
+        # cached exact token matrix
+        key = encoders.corpus_cache_key(model_name_or_path, documents, "colbert") if cache_dir else ""
+        Dtok, Doff = encoders.cached_tensors(cache_dir, key, ["tok", "off"], lambda: model.encode_docs(documents, batch_size=64))
+        Dtok, Doff = Dtok.to(_device()), Doff.to(_device())
         Qtok = model.encode_queries(queries, batch_size=64)
         scores = ops.maxsim(Qtok, Dtok, Doff, max_doc_len=model.max_doc_length)
         rs = _rank_scores(scores, ids, return_topk)
@@ -128,19 +136,25 @@ class Ranker:
         return rs if as_device else rs.to_lists()
 
     @staticmethod
-    def cross_encoder_search(queries: list[str], candidates: list, model_name_or_path: str, return_topk: int = None, *, model=None):
-        """hybrid.py:139-163 is dead code in the reference (`docs` undefined, candidates type mismatch).
-        Working form: `candidates[i]` is a dict id->text (or a fused list of {'corpus_id'} plus `corpus` in `model.corpus`);
-        `model.predict(list[(query, doc)]) -> scores` is any PyTorch-ROCm cross-encoder."""
+    def cross_encoder_search(queries: list[str], candidates: list, model_name_or_path: str, return_topk: int = None, *, model=None,
+                             corpus: dict[int, str] = None):
+        """monoBERT rerank (hybrid.py:139-163).  The reference's version is dead code (`docs` undefined at :159, and main passes
+        fused lists where it expects dicts, :462).  Working form: `candidates[i]` is a dict id->text, or -- as main
+        passes it -- a fused ranked list of {'corpus_id', 'score'} together with `corpus` to look the texts up.
+        `model` = fusion_amd.encoders.CrossEncoder (PyTorch-ROCm forward); ties keep the candidate order (stable sort)."""
+        from .. import encoders
         if model is None:
-            raise NotImplementedError("no cross-encoder checkpoint available offline: pass model=<object with predict()>")
+            raise NotImplementedError(f"no cross-encoder checkpoint for {model_name_or_path!r} offline: pass model=encoders.CrossEncoder(...)")
         ranked_lists = []
         for query, cands in zip(queries, candidates):
-            cids = list(cands.keys())
-            docs = list(cands.values())
-            scores = model.predict([(query, d) for d in docs])
-            order = sorted(range(len(docs)), key=lambda i: -float(scores[i]))[: return_topk or len(docs)]
-            ranked_lists.append([{"corpus_id": cids[i], "score": float(scores[i])} for i in order])
+            if isinstance(cands, dict):
+                cids, docs = list(cands.keys()), list(cands.values())
+            else:
+                cids = [x["corpus_id"] for x in cands]
+                docs = [corpus[c] for c in cids]
+            scores = model.predict([(query, d) for d in docs]).cpu().tolist() if docs else []
+            order = sorted(range(len(docs)), key=lambda i: scores[i], reverse=True)[: return_topk or len(docs)]
+            ranked_lists.append([{"corpus_id": cids[i], "score": scores[i]} for i in order])
         return ranked_lists
 
 
@@ -421,6 +435,8 @@ def main(args):
     results: dict[str, RankedSystem] = {}
     synth = bool(getattr(args, "synthetic", None))
 
+    cache = join(args.output_dir, "corpus_cache") if not getattr(args, "no_corpus_cache", False) else None
+
     def enc(kind):
         if synth:   # random-init CamemBERT-shaped encoder (no checkpoints offline)
             return encoders.random_init(kind, device=_device(), size=getattr(args, "synthetic_model", "tiny"))
@@ -430,13 +446,13 @@ def main(args):
         results["bm25"] = Ranker.bm25_search(queries, corpus, do_preprocessing=False, k1=2.5, b=0.2, as_device=True)
     if args.run_dpr:
         print(f"{sep}\n# Ranking with DPR\n{sep}")
-        results["dpr"] = Ranker.single_vector_search(queries, corpus, MODEL_CKPTS["dpr"][args.models_domain], encoder=enc("dpr"), as_device=True)
+        results["dpr"] = Ranker.single_vector_search(queries, corpus, MODEL_CKPTS["dpr"][args.models_domain], encoder=enc("dpr"), as_device=True, cache_dir=cache)
     if args.run_splade:
         print(f"{sep}\n# Ranking with SPLADE\n{sep}")
-        results["splade"] = Ranker.single_vector_search(queries, corpus, MODEL_CKPTS["splade"][args.models_domain], encoder=enc("splade"), as_device=True)
+        results["splade"] = Ranker.single_vector_search(queries, corpus, MODEL_CKPTS["splade"][args.models_domain], encoder=enc("splade"), as_device=True, cache_dir=cache)
     if args.run_colbert:
         print(f"{sep}\n# Ranking with ColBERT\n{sep}")
-        results["colbert"] = Ranker.multi_vector_search(queries, corpus, MODEL_CKPTS["colbert"][args.models_domain], encoder=enc("colbert"), as_device=True)
+        results["colbert"] = Ranker.multi_vector_search(queries, corpus, MODEL_CKPTS["colbert"][args.models_domain], encoder=enc("colbert"), as_device=True, cache_dir=cache)
 
     if args.analyze_score_distributions:
         print(f"{sep}\n# Analyzing the score distributions per system\n{sep}")
@@ -463,8 +479,16 @@ def main(args):
     print(f"{sep}\n# Fusing results with {args.fusion.upper()}{' (' + args.normalization + ')' if args.fusion == 'nsf' else ''}\n{sep}")
     fused = Aggregator.fuse(results, method=args.fusion, normalization=args.normalization, percentile_distributions=distr,
                             linear_weights=weights, as_device=True)
+    predictions = fused.predictions(1000)
+    if args.run_monobert:   # hybrid.py:460-462, with the argument bug fixed: rerank the fused top-k with the cross-encoder
+        print(f"{sep}\n# Re-ranking with monoBERT \n{sep}")
+        ce = encoders.random_cross_encoder(device=_device(), size=getattr(args, "synthetic_model", "tiny")) if synth else None
+        k = getattr(args, "rerank_topk", 100)
+        reranked = Ranker.cross_encoder_search(queries, [[{"corpus_id": c} for c in p[:k]] for p in predictions],
+                                               MODEL_CKPTS["monobert"][args.models_domain], model=ce, corpus=corpus)
+        predictions = [[x["corpus_id"] for x in r] + p[k:] for r, p in zip(reranked, predictions)]
     print(f"{sep}\n# Evaluation \n{sep}")
-    return run_evaluation(predictions=fused.predictions(1000), labels=pos_pids, args=args)
+    return run_evaluation(predictions=predictions, labels=pos_pids, args=args)
 
 
 def analyze_score_distributions(args, results: dict[str, RankedSystem], corpus: dict, pos_pids: list[list]):
@@ -537,6 +561,8 @@ def build_parser():
     parser.add_argument("--data_dir", type=str, default=os.environ.get("LLEQA_DIR"))
     parser.add_argument("--synthetic", type=str, default=None, help="N,Q: synthetic corpus/queries of that size")
     parser.add_argument("--synthetic_model", type=str, default="tiny", choices=["tiny", "base"])
+    parser.add_argument("--no_corpus_cache", action="store_true", default=False, help="do not keep encoded corpora under <output_dir>/corpus_cache")
+    parser.add_argument("--rerank_topk", type=int, default=100, help="candidates per query handed to monoBERT")
     return parser
 
 

@@ -550,5 +550,48 @@ def test_cli_main_end_to_end(tmp_path):
     assert 0.0 <= main(a)["recall@1000"] <= 1.0
     a, _ = build_parser().parse_known_args(base + "--run_bm25 --run_dpr --fusion nsf --normalization min-max --tune_linear_fusion_weight".split())
     rows = main(a)
+    assert os.listdir(os.path.join(out, "corpus_cache"))          # N2: encoded corpora are kept on disk ...
+    a2, _ = build_parser().parse_known_args(base + "--run_bm25 --run_dpr --run_monobert --rerank_topk 20 --fusion rrf --normalization none".split())
+    sc2 = main(a2)                                                 # ... reused here, plus the monoBERT rerank stage (N3)
+    assert 0.0 <= sc2["recall@1000"] <= 1.0
     df = pd.read_csv(os.path.join(out, "nsf_min-max_indomain.csv"))
     assert len(rows) == len(df) == 21 and list(df.columns)[-2:] == ["weight_bm25", "weight_dpr"] and "recall@10" in df.columns
+
+
+# ---- edge cases ---------------------------------------------------------------------------------------------------
+def test_edge_cases_empty_and_degenerate(ops, oracle):
+    e = torch.empty((0, 10), device="cuda")
+    o, k, r = ops.sort_rows_desc(e, want_rank=True)
+    assert o.shape == (0, 10) and r.shape == (0, 10)
+    one = torch.tensor([[3.0]], device="cuda")
+    o, k, r = ops.sort_rows_desc(one, want_rank=True)
+    assert o.tolist() == [[0]] and k.tolist() == [[3.0]] and r.tolist() == [[0]]
+    # all-equal, all-NaN, +-inf, denormals: stable order = ascending position; NaN first
+    rows = np.zeros((5, 3000), dtype=np.float32)
+    rows[1] = np.nan
+    rows[2, ::2] = np.inf; rows[2, 1::2] = -np.inf
+    rows[3] = np.float32(1e-42) * np.arange(3000)             # subnormals, ascending
+    rows[4, :10] = [np.nan, 1.0, -0.0, 0.0, np.inf, -np.inf, 1.0, np.nan, -1e-45, 1e-45]
+    o, k, r = ops.sort_rows_desc(plane(ops, rows), want_rank=True)
+    eo, ek, er = oracle.sort_rows_desc(rows, want_rank=True)
+    np.testing.assert_array_equal(o.cpu().numpy(), eo)
+    np.testing.assert_array_equal(r.cpu().numpy(), er)
+    assert (o.cpu().numpy()[0] == np.arange(3000)).all()
+    # fusion of an empty batch / zero-length rows is a no-op, not an error
+    z = ops.fuse_rank([torch.empty((0, 8), dtype=torch.int32, device="cuda")], torch.empty((1, 0), dtype=torch.int32, device="cuda"), "rrf")
+    assert z.shape == (0, 8)
+    # top-k with k > n pads with (-inf, -1)
+    s, i = ops.topk_rows(plane(ops, np.array([[0.5, 2.0, 1.0]], dtype=np.float32)), 5, id_base=10)
+    assert s.tolist()[0][:3] == [2.0, 1.0, 0.5] and i.tolist()[0] == [11, 12, 10, -1, -1] and s.tolist()[0][3] == float("-inf")
+
+
+def test_fuse_rank_single_system_and_no_coverage(ops, oracle):
+    """A document listed by no system gets -inf and never appears in the fused list."""
+    ranks = np.array([[0, -1, 1, -1]], dtype=np.int32)
+    lens = np.array([[2]], dtype=np.int32)
+    got = ops.fuse_rank([plane(ops, ranks)], dev(lens), "bcf").cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.fuse_rank([ranks], lens, "bcf"))
+    assert got[0, 1] == -np.inf and got[0, 0] == (2 - 0 + 1) / 2          # Borda (n - idx + 1)/n, sic (hybrid.py:249)
+    order = np.array([[0, 2, -1, -1]], dtype=np.int32)
+    ins, U = ops.insertion_order([plane(ops, order)], dev(lens), 4)
+    assert U.tolist() == [2] and ins.cpu().numpy()[0, :2].tolist() == [0, 2]

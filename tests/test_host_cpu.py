@@ -32,6 +32,8 @@ def test_abi_argument_validation_without_gpu():
     from fusion_amd import _lib
     L = _lib.lib()
     assert L.fz_sort_rows_desc(None, 32, None, None, 1, 1, 1, None, None, None, None) == _lib.FZ_ERR_ARG
+    assert L.fz_sort_rows_desc(None, 32, None, None, 0, 5, 8, None, None, None, None) == _lib.FZ_OK      # empty batch: nothing to do
+    assert L.fz_sort_rows_desc(None, 16, None, None, 1, 1, 1, None, None, None, None) == _lib.FZ_ERR_ARG
     assert L.fz_fuse_rank_f64(None, None, 2, 1, 1, 1, 0, None, None) == _lib.FZ_ERR_ARG
     assert L.fz_dot_scores_f32(None, 4, None, 4, 1, 1, 4, None, 1, None) == _lib.FZ_ERR_ARG
     assert L.fz_topk_workspace_bytes(4, 100000, 1000) > 0 and L.fz_topk_workspace_bytes(4, 1000, 10) <= 256
@@ -225,3 +227,28 @@ def test_fused_forward_equals_hf_forward():
     a = enc.encode_ids(torch.from_numpy(ids), torch.from_numpy(mask))
     b = enc.encode_ids_fused(torch.from_numpy(ids), lens, n_buckets=4)
     assert torch.allclose(a, b, atol=3e-6), float((a - b).abs().max())
+
+
+def test_corpus_cache_and_cross_encoder(tmp_path):
+    from fusion_amd import encoders
+    docs = ["le chat noir dort", "article premier du code civil", "loi"]
+    k1 = encoders.corpus_cache_key("ckpt-a", docs, "dpr")
+    assert k1 == encoders.corpus_cache_key("ckpt-a", docs, "dpr")
+    assert k1 != encoders.corpus_cache_key("ckpt-b", docs, "dpr") != encoders.corpus_cache_key("ckpt-a", docs[:2], "dpr")
+    calls = []
+
+    def compute():
+        calls.append(1)
+        return (torch.arange(12, dtype=torch.float32).reshape(3, 4), torch.tensor([0, 2, 5], dtype=torch.int64))
+    a = encoders.cached_tensors(str(tmp_path), k1, ["emb", "off"], compute)
+    b = encoders.cached_tensors(str(tmp_path), k1, ["emb", "off"], compute)
+    assert len(calls) == 1 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and b[1].dtype == torch.int64
+    ce = encoders.random_cross_encoder(device="cpu", size="tiny")
+    s = ce.predict([("chat", docs[0]), ("chat", docs[1]), ("loi", docs[2])])
+    assert s.shape == (3,) and torch.isfinite(s).all()
+    from fusion_amd.retrievers.hybrid import Ranker
+    out = Ranker.cross_encoder_search(["chat", "loi"], [{7: docs[0], 8: docs[1]}, [{"corpus_id": 9, "score": 1.0}]], "x", model=ce,
+                                      corpus={7: docs[0], 8: docs[1], 9: docs[2]})
+    assert sorted(x["corpus_id"] for x in out[0]) == [7, 8] and out[0][0]["score"] >= out[0][1]["score"] and out[1][0]["corpus_id"] == 9
+    with pytest.raises(NotImplementedError):
+        Ranker.cross_encoder_search(["q"], [{1: "d"}], "maastrichtlawtech/monobert-legal-french")
