@@ -190,15 +190,15 @@ class Aggregator:
             lens = torch.stack([s.lens for s in S]).contiguous()
             fused = ops.fuse_rank([s.rank for s in S], lens, method)
         elif method == "nsf":
+            if percentile_distributions is None:            # the reference calls .get() on it for every system (hybrid.py:213)
+                raise AttributeError("'NoneType' object has no attribute 'get'")
             w = [linear_weights[n] for n in names]          # KeyError when a system has no weight (hybrid.py:214)
             if normalization in ("percentile-rank", "normal-curve-equivalent"):
-                distr = [cls._table(percentile_distributions.get(n), dev) for n in names]   # AttributeError on None (hybrid.py:213)
+                distr = [cls._table(percentile_distributions.get(n), dev) for n in names]
                 fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, distr)
             elif normalization in ("min-max", "z-score", "arctan"):
-                percentile_distributions.get                # same AttributeError as hybrid.py:213 when None is passed
                 fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization)
             else:                                           # 'none' / unknown string: passthrough (hybrid.py:280)
-                percentile_distributions.get
                 fused = ops.fuse_none([s.scores for s in S], ranks, w)
         else:                                               # unknown method: raw scores are summed (hybrid.py:203-218)
             fused = ops.fuse_none([s.scores for s in S], ranks, [1.0] * len(S))

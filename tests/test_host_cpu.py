@@ -52,13 +52,16 @@ def test_no_cpu_fallback():
 
 
 def test_product_does_not_import_oracle():
-    pkg = os.path.join(ROOT, "fusion_amd")
-    for dp, _, fs in os.walk(pkg):
-        for f in fs:
-            if f.endswith((".py", ".hip", ".h")):
+    """The oracle is test infrastructure: nothing under fusion_amd/ (or the CLI shim) may import, load or link it."""
+    roots = [os.path.join(ROOT, "fusion_amd"), os.path.join(ROOT, "src")]
+    for root in roots:
+        for dp, _, fs in os.walk(root):
+            for f in fs:
+                if not f.endswith((".py", ".hip", ".h")) and f != "Makefile":
+                    continue
                 src = open(os.path.join(dp, f)).read()
-                assert "oracle" not in src.replace("# oracle", "").lower() or f == "fuse.hip" or "as in the oracle" in src or "oracle checks" in src, f
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "libfusion_oracle" not in src and "fusion_oracle.c" not in src and "oracle/" not in src, f
 
 
 def test_metrics_match_reference_golden():
