@@ -595,3 +595,54 @@ def test_fuse_rank_single_system_and_no_coverage(ops, oracle):
     order = np.array([[0, 2, -1, -1]], dtype=np.int32)
     ins, U = ops.insertion_order([plane(ops, order)], dev(lens), 4)
     assert U.tolist() == [2] and ins.cpu().numpy()[0, :2].tolist() == [0, 2]
+
+
+def test_maxsim_full_length_docs_vs_torch(ops):
+    """LLeQA-shaped documents (lengths ~ N(300,120) clipped to [16,512]) against an independent fp32 torch reference."""
+    rng = np.random.default_rng(5)
+    N, Q = 600, 16
+    lens = np.clip(rng.normal(300, 120, N), 16, 512).astype(np.int64)
+    off = np.zeros(N + 1, dtype=np.int64); off[1:] = np.cumsum(lens)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Dtok = torch.nn.functional.normalize(torch.randn((int(off[-1]), 128), generator=g, device="cuda"), dim=-1).half()
+    Qtok = torch.nn.functional.normalize(torch.randn((Q, 64, 128), generator=g, device="cuda"), dim=-1).half()
+    got = ops.maxsim(Qtok, Dtok, torch.from_numpy(off).cuda(), max_doc_len=512)
+    ref = torch.empty((Q, N), device="cuda")
+    Qf = Qtok.float()
+    for j in range(N):
+        d = Dtok[off[j]:off[j + 1]].float()                       # [L, 128]
+        ref[:, j] = torch.einsum("qid,ld->qil", Qf, d).max(dim=2).values.sum(dim=1)
+    assert float((got - ref).abs().max()) <= 2e-4                   # 64 maxima of unit-vector dot products, fp32 accumulate
+
+
+def test_recall_at_500_identical_to_oracle_pipeline(ops, oracle):
+    """north_star acceptance: recall@500 of the GPU pipeline == recall@500 of the CPU restatement on the same inputs
+    (LLeQA-sized corpus, synthetic qrels)."""
+    from fusion_amd.planes import RankedSystem
+    from fusion_amd.retrievers.hybrid import Aggregator
+    from fusion_amd.utils.metrics import Metrics
+    rng = np.random.default_rng(21)
+    Q, N = 24, 27942
+    ids = np.arange(1, N + 1)
+    bm = np.maximum(0, rng.gamma(0.5, 4.0, (Q, N)) - 2).astype(np.float32)        # ~40 % exact zeros: many ties
+    dp = rng.uniform(-0.2, 0.9, (Q, N)).astype(np.float32)
+    labels = [rng.choice(ids, size=int(rng.integers(1, 6)), replace=False).tolist() for _ in range(Q)]
+    systems, o_rank, o_order = {}, [], []
+    for name, sc in (("bm25", bm), ("dpr", dp)):
+        pl = plane(ops, sc)
+        od, _, rk = ops.sort_rows_desc(pl, want_rank=True)
+        systems[name] = RankedSystem(scores=pl, order=od, rank=rk, lens=torch.full((Q,), N, dtype=torch.int32, device="cuda"), ids=ids)
+        eo, _, er = oracle.sort_rows_desc(sc, want_rank=True)
+        o_rank.append(er); o_order.append(eo)
+    ev = Metrics(recall_at_k=[10, 500])
+    for method, norm, w in (("rrf", None, None), ("bcf", None, None), ("nsf", "min-max", {"bm25": 0.3, "dpr": 0.7})):
+        fused = Aggregator.fuse(systems, method, norm, w, {}, as_device=True)
+        got = ev.compute_all_metrics(labels, fused.predictions())
+        if method == "nsf":
+            f = oracle.fuse_nsf([bm, dp], None, [w["bm25"], w["dpr"]], norm)
+        else:
+            f = oracle.fuse_rank(o_rank, np.full((2, Q), N, dtype=np.int32), method)
+        eo, _ = oracle.sort_rows_desc(f, init_order=o_order[0])
+        exp = ev.compute_all_metrics(labels, [ids[eo[q]].tolist() for q in range(Q)])
+        assert got == exp, (method, got, exp)                                     # identical, not approximately equal
+        np.testing.assert_array_equal(fused.order.cpu().numpy(), eo)              # because the ranked lists are identical
