@@ -188,14 +188,20 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int THREADS>
 __device__ __forceinline__ void block_minmax_nan(float& mn, float& mx, float& nanflag, float* red /* 2 x 3*THREADS/64 */, int parity) {
     constexpr int NW = THREADS / 64;
+    static_assert(NW <= 16, "final combine uses 16 lanes");
     float* r = red + parity * 3 * NW;
     mn = wave_reduce_min(mn); mx = wave_reduce_max(mx); nanflag = wave_reduce_max(nanflag);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { r[w] = mn; r[NW + w] = mx; r[2 * NW + w] = nanflag; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { r[w] = mn; r[NW + w] = mx; r[2 * NW + w] = nanflag; }
     lds_barrier();
-    mn = r[0]; mx = r[NW]; nanflag = r[2 * NW];
+    // every wave folds the NW partials with its own lanes (lane L takes partial L): 3 LDS reads + 4 shuffle steps per
+    // thread instead of 3*NW reads and 3*NW min/max
+    const int L = lane & 15;
+    mn = L < NW ? r[L] : INFINITY; mx = L < NW ? r[NW + L] : -INFINITY; nanflag = L < NW ? r[2 * NW + L] : 0.f;
 #pragma unroll
-    for (int i = 1; i < NW; ++i) { mn = fminf(mn, r[i]); mx = fmaxf(mx, r[NW + i]); nanflag = fmaxf(nanflag, r[2 * NW + i]); }
+    for (int o = 8; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); nanflag = fmaxf(nanflag, __shfl_xor(nanflag, o, 64));
+    }
 }
 template <int THREADS, int NV>
 __device__ __forceinline__ void block_sum_n_nodrain(double (&v)[NV], double* red /* 2 x NV*THREADS/64 */, int parity) {
@@ -330,30 +336,60 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
             sa = nanf_ > 0.f ? __uint_as_float(0x7fc00000u) : mn;   // torch.min/max propagate NaN
             sb = nanf_ > 0.f ? __uint_as_float(0x7fc00000u) : mx;
         } else if (NORM == FZ_NORM_ZSCORE) {
-            // one pass, shifted by x0 = the row's column-0 score (any finite sample of the row makes the one-pass
-            // variance stable; a uniform scalar load, no reduction):
-            //   d = x - x0;  mean = x0 + sum(d)/n;  var = (sum(d^2) - sum(d)^2/n)/(n-1)       (all fp64)
-            float x0c = a.planes[s][rowoff];
+            // one pass per wave, shifted by that wave's own first register value (any finite sample of the row keeps the
+            // one-pass sums stable; readfirstlane: no memory access), then the 16 per-wave (n, mean, M2) triples are
+            // merged with the parallel-variance update (Chan et al.), in wave order, by every thread identically:
+            //   d = x - x0_w;  mean_w = x0_w + sum(d)/n_w;  M2_w = sum(d^2) - sum(d)^2/n_w          (all fp64)
+            float x0c = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[0][0])));
             if (!(x0c == x0c) || fabsf(x0c) == INFINITY) x0c = 0.f;
             const double x0 = (double)x0c;
-            double st[3] = {0.0, 0.0, 0.0};   // sum d, sum d^2, count
+            double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-            for (int i = 0; i < E4; ++i) {
+            for (int i = 0; i < E4; ++i)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const bool in = (ok >> (4 * i + c)) & 1ull;
                     const double d = in ? (double)v[i][c] - x0 : 0.0;
-                    st[0] += d; st[1] += d * d;
+                    s1 += d; s2 += d * d;
                 }
-                __builtin_amdgcn_sched_barrier(0);   // keep the fp64 temporaries of 4 elements, not 28, alive
+            double cnt = (double)__popcll(ok);
+            s1 = wave_reduce_sum(s1); s2 = wave_reduce_sum(s2); cnt = wave_reduce_sum(cnt);
+            {
+                constexpr int NW = T / 64;
+                double* r = red_d + red_parity * 3 * NW;
+                red_parity ^= 1;
+                if (lane == 0) {
+                    const int w = threadIdx.x >> 6;
+                    r[w] = cnt;
+                    r[NW + w] = cnt > 0.0 ? x0 + s1 / cnt : 0.0;
+                    r[2 * NW + w] = cnt > 0.0 ? s2 - s1 * s1 / cnt : 0.0;
+                }
+                lds_barrier();
+                // lane L of every wave takes partial L; a 4-step tree towards lane 0 merges (n, mean, M2) pairs with the
+                // parallel-variance update; lane 0's result is broadcast, so every thread of every wave uses the same bits
+                const int L = lane & 15;
+                double n = L < NW ? r[L] : 0.0, mean = L < NW ? r[NW + L] : 0.0, M2 = L < NW ? r[2 * NW + L] : 0.0;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    const double nb = __shfl_down(n, o, 64), mb = __shfl_down(mean, o, 64), m2b = __shfl_down(M2, o, 64);
+                    const double nn = n + nb;
+                    if (nb > 0.0) {
+                        const double delta = mb - mean, f = nb / nn;
+                        mean = (n > 0.0) ? mean + delta * f : mb;
+                        M2 = M2 + m2b + delta * delta * (n * f);
+                        n = nn;
+                    }
+                }
+                auto bcast = [](double x) -> double {
+                    const long long b = __double_as_longlong(x);
+                    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+                    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+                };
+                n = bcast(n); mean = bcast(mean); M2 = bcast(M2);
+                const double var = n > 1.0 ? M2 / (n - 1.0) : (double)NAN;
+                sa = (float)(n > 0.0 ? mean : (double)NAN);
+                sb = (float)sqrt(var < 0.0 ? 0.0 : var);
             }
-            st[2] = (double)__popcll(ok);
-            block_sum_n_nodrain<T, 3>(st, red_d, red_parity); red_parity ^= 1;
-            const double n = st[2];
-            const double mean = n > 0.0 ? x0 + st[0] / n : (double)NAN;
-            const double var = n > 1.0 ? (st[1] - st[0] * st[0] / n) / (n - 1.0) : (double)NAN;
-            sa = (float)mean;
-            sb = (float)sqrt(var < 0.0 ? 0.0 : var);
         }
         const float w = a.w[s];
         const float* __restrict__ distr = a.distr[s];
