@@ -45,8 +45,9 @@ def parse():
     p.add_argument("--no-encode", action="store_true", help="skip the transformer forward (score+fuse only; not the headline metric)")
     p.add_argument("--encoder-size", default="base", choices=["base", "tiny"])
     p.add_argument("--encode-buckets", type=int, default=8, help="length buckets for the query encoder (1 = pad everything to the batch maximum)")
-    p.add_argument("--encode-mode", default="fused", choices=["fused", "hf"],
-                   help="fused: lean forward, linears over all buckets' tokens at once; hf: the HF module per length bucket")
+    p.add_argument("--encode-mode", default="packed", choices=["packed", "fused", "hf"],
+                   help="packed: padding-free token rows, HIP attention/LayerNorm/pooling kernels between the hipBLASLt GEMMs; fused: lean torch forward, "
+                        "linears over all length buckets' tokens at once; hf: the HF module per length bucket")
     p.add_argument("--overlap-bm25", action="store_true", help="run the BM25 branch on a second stream next to the encoder (measured: no gain, the encoder saturates the GPU)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--mmarco-docs", type=int, default=8841823)
@@ -155,6 +156,8 @@ def step_lleqa(st, ev=None):
             B, o_b, r_b = bm25_branch()
     if "enc" not in st:
         q_emb = st["q_emb"]
+    elif st["encode_mode"] == "packed":
+        q_emb = st["enc"].encode_ids_packed(st["ids"], st["qlen"])
     elif st["encode_mode"] == "fused":
         q_emb = st["enc"].encode_ids_fused(st["ids"], st["qlen"], st["buckets"])
     else:

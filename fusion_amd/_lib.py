@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfusion_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 FZ_OK, FZ_ERR_ARG, FZ_ERR_UNSUPPORTED, FZ_ERR_HIP, FZ_ERR_WORKSPACE = 0, -1, -2, -3, -4
 NORMS = {"min-max": 1, "z-score": 2, "arctan": 3, "percentile-rank": 4, "normal-curve-equivalent": 5}
@@ -64,6 +64,9 @@ _PROTOS = {
     "fz_bm25_scores_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "fz_tune_max_gold": (_i, []),
     "fz_gold_ranks_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "fz_attn_varlen_f32": (_i, [_vp, _i, _vp, _i, _i, _i, C.c_float, _vp, _i, _vp]),
+    "fz_add_layernorm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, C.c_float, _i, _i, _vp, _i, _vp]),
+    "fz_segment_mean_f32": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     "fz_fill_i32": (_i, [_vp, _sz, C.c_int32, _vp]),
     "fz_f64_to_f32": (_i, [_vp, _vp, _sz, _vp]),
 }

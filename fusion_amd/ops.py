@@ -434,3 +434,69 @@ def f64_to_f32(src: torch.Tensor) -> torch.Tensor:
     # convert the whole padded buffer when it is one allocation; otherwise row views
     check(_lib.lib().fz_f64_to_f32(_ptr(src), _ptr(dst), rows * ld - (ld - n) if rows > 0 else 0, _stream(src)), "fz_f64_to_f32")
     return dst[:rows, :n]
+
+
+# ---------------------------------------------------------------------------------------
+# encoder side: packed (padding-free) token rows
+# ---------------------------------------------------------------------------------------
+def attn_strips(lengths, cu_rows=None):
+    """HOST helper: the strip table fz_attn_varlen_f32 walks -- one (first row, length, first query, 0) entry per 32 queries
+    of every sequence, longest sequences first.  Returns (strips int32 [n_strips, 4] numpy, cu_rows int32 [B+1] numpy)."""
+    import numpy as np
+    lengths = np.asarray(lengths, dtype=np.int64)
+    if cu_rows is None:
+        cu_rows = np.zeros(len(lengths) + 1, dtype=np.int64)
+        np.cumsum(lengths, out=cu_rows[1:])
+    per = (lengths + 31) // 32
+    order = np.argsort(-lengths, kind="stable")
+    seq = np.repeat(order, per[order])
+    first = np.zeros(len(order) + 1, dtype=np.int64)
+    np.cumsum(per[order], out=first[1:])
+    q0 = (np.arange(len(seq)) - np.repeat(first[:-1], per[order])) * 32
+    strips = np.stack([cu_rows[seq], lengths[seq], q0, np.zeros_like(q0)], 1).astype(np.int32)
+    return np.ascontiguousarray(strips), cu_rows.astype(np.int32)
+
+
+def attn_varlen(qkv: torch.Tensor, strips: torch.Tensor, heads: int, scale: float | None = None, out: torch.Tensor | None = None):
+    """softmax(q k^T scale) v per sequence and head over packed rows; qkv [T, 3*heads*64] fp32 -> [T, heads*64]."""
+    _dev(qkv, torch.float32, "attn_varlen(qkv)")
+    _dev(strips, torch.int32, "attn_varlen(strips)")
+    T, W = qkv.shape
+    if W != 3 * heads * 64:
+        raise ValueError(f"attn_varlen: qkv is {W} wide, expected 3*{heads}*64 (head_dim 64 only)")
+    if strips.dim() != 2 or strips.shape[1] != 4 or not strips.is_contiguous():
+        raise ValueError("attn_varlen: strips must be a contiguous [n_strips, 4] int32 tensor (ops.attn_strips)")
+    if out is None:
+        out = torch.empty((T, heads * 64), dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().fz_attn_varlen_f32(_ptr(qkv), qkv.stride(0) if T > 1 else W, _ptr(strips), strips.shape[0], heads, 64,
+                                        float(64 ** -0.5 if scale is None else scale), _ptr(out), out.stride(0) if T > 1 else heads * 64,
+                                        _stream(qkv)), "fz_attn_varlen_f32")
+    return out
+
+
+def add_layernorm(x: torch.Tensor, res: torch.Tensor | None, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor | None = None):
+    """LayerNorm(x + res) over the last dimension, fp32, one HBM pass."""
+    _dev(x, torch.float32, "add_layernorm(x)")
+    rows, d = x.shape
+    if res is not None:
+        _dev(res, torch.float32, "add_layernorm(res)")
+        if res.shape != x.shape:
+            raise ValueError("add_layernorm: x and res differ in shape")
+    if out is None:
+        out = torch.empty((rows, d), dtype=torch.float32, device=x.device)
+    ldr = 0 if res is None else (res.stride(0) if rows > 1 else d)
+    check(_lib.lib().fz_add_layernorm_f32(_ptr(x), x.stride(0) if rows > 1 else d, _ptr(res), ldr, _ptr(_dev(gamma, torch.float32, "gamma")),
+                                          _ptr(_dev(beta, torch.float32, "beta")), float(eps), rows, d, _ptr(out),
+                                          out.stride(0) if rows > 1 else d, _stream(x)), "fz_add_layernorm_f32")
+    return out
+
+
+def segment_mean(x: torch.Tensor, cu_rows: torch.Tensor) -> torch.Tensor:
+    """Mean over each sequence's rows: x [T, d] fp32, cu_rows [B+1] int32 -> [B, d]."""
+    _dev(x, torch.float32, "segment_mean(x)")
+    _dev(cu_rows, torch.int32, "segment_mean(cu_rows)")
+    B, d = cu_rows.numel() - 1, x.shape[1]
+    out = torch.empty((max(B, 0), d), dtype=torch.float32, device=x.device)
+    check(_lib.lib().fz_segment_mean_f32(_ptr(x), x.stride(0) if x.shape[0] > 1 else d, _ptr(cu_rows), B, d, _ptr(out), d, _stream(x)),
+          "fz_segment_mean_f32")
+    return out

@@ -85,8 +85,10 @@ int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* Doff, int64
  *   order[row][r]       payload (corpus position) at output rank r, r < row_len[row]
  *   sorted_keys[row][r] its key (same type as keys)
  *   rank[row][payload]  = r  (inverse permutation; other entries untouched: pre-fill with -1)
- * Supported n: 1 .. fz_sort_max_n(). */
+ * Supported n: 1 .. fz_sort_max_n() for fp32 keys, 1 .. fz_sort_max_n_f64() for fp64 keys (a row lives in the registers of
+ * one workgroup). */
 int fz_sort_max_n(void);
+int fz_sort_max_n_f64(void);
 int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows, int n,
                       int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream);
 
@@ -119,6 +121,12 @@ int fz_row_stats_f32(const float* scores, const int32_t* rank, int rows, int N, 
  * norm = FZ_NORM_NONE is rejected here: use fz_fuse_none_f64 (the reference stays in float64). */
 int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
                     int ld, int norm, const float* const* distr_h, const int32_t* P_h, float* fused, void* stream);
+/* Same result for rows longer than the one-pass kernel holds in registers (N > 32768: fz_fuse_nsf_f32 returns
+ * FZ_ERR_UNSUPPORTED): min-max / z-score statistics are supplied by the caller, [S][Q] fp32 each, from fz_row_stats_f32
+ * (nullable for the other normalisations).  Two passes over HBM. */
+int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
+                          int ld, int norm, const float* const* distr_h, const int32_t* P_h, const float* stat_a,
+                          const float* stat_b, float* fused, void* stream);
 /* 'none' / unknown normalisation: fused[q][j] = sum_s (double)score_s * w_s in fp64 (hybrid.py:280,291,304) */
 int fz_fuse_none_f64(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
                      int ld, double* fused, void* stream);
@@ -173,6 +181,22 @@ int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* 
 int fz_tune_max_gold(void);
 int fz_gold_ranks_f32(const float* const* T_h, const int32_t* pos, const float* weights, const int32_t* gold, int S, int W,
                       int Q, int N, int ld, int32_t* out_ranks, void* stream);
+
+/* ---- encoder side: the per-sequence parts of SentenceTransformer.encode (hybrid.py:97-102) on PACKED token rows -- */
+/* Self-attention of a BERT/CamemBERT layer for ragged sequences without padding: for every sequence and head,
+ * out = softmax(q k^T * scale) v in fp32 (MFMA products, online softmax).  qkv [T][ld] = fused projection rows
+ * (q | k | v, each H*head_dim wide); strips [n_strips][4] int32 (device): (first row of the sequence, its length,
+ * first query row of this strip of <= 32 queries, 0) -- one entry per 32 queries of every sequence, any order
+ * (longest sequences first balances best).  head_dim must be 64.  out [T][ldo], H*head_dim wide. */
+int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
+                       float* out, int ldo, void* stream);
+/* out = LayerNorm(x + res) * gamma + beta over the last dimension d (biased variance, as torch.nn.LayerNorm);
+ * res nullable.  d % 4 == 0, d <= 4096. */
+int fz_add_layernorm_f32(const float* x, int ldx, const float* res, int ldr, const float* gamma, const float* beta, float eps,
+                         int rows, int d, float* out, int ldo, void* stream);
+/* mean Pooling (sentence_transformers Pooling(mean)): out[b] = mean of rows [cu_rows[b], cu_rows[b+1]) of x; zeros for an
+ * empty sequence.  cu_rows [B+1] int32 (device). */
+int fz_segment_mean_f32(const float* x, int ldx, const int32_t* cu_rows, int B, int d, float* out, int ldo, void* stream);
 
 /* ---- small utilities ------------------------------------------------------------------ */
 int fz_fill_i32(int32_t* p, size_t count, int32_t value, void* stream);

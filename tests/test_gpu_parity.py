@@ -646,3 +646,74 @@ def test_recall_at_500_identical_to_oracle_pipeline(ops, oracle):
         exp = ev.compute_all_metrics(labels, [ids[eo[q]].tolist() for q in range(Q)])
         assert got == exp, (method, got, exp)                                     # identical, not approximately equal
         np.testing.assert_array_equal(fused.order.cpu().numpy(), eo)              # because the ranked lists are identical
+
+
+# ---- encoder side (packed token rows): fz_attn_varlen_f32 / fz_add_layernorm_f32 / fz_segment_mean_f32 -----------
+# floating point: compared with the plain torch fp32 maths of the same op; tolerances are stated per test.
+@pytest.mark.parametrize("lengths,H", [([1], 1), ([5, 70, 32, 33, 1], 3), ([64] * 7 + [9, 17], 12), ([130, 512, 31], 2)])
+def test_attn_varlen_vs_torch(ops, lengths, H):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    T = sum(lengths)
+    qkv = torch.randn((T, 3 * H * 64), generator=g, device="cuda") * 1.5
+    strips, cu = ops.attn_strips(lengths)
+    out = ops.attn_varlen(qkv, torch.from_numpy(strips).cuda(), H)
+    ref = torch.empty_like(out)
+    for b, L in enumerate(lengths):
+        blk = qkv[cu[b]: cu[b] + L].double().view(L, 3, H, 64)
+        q, k, v = blk[:, 0].transpose(0, 1), blk[:, 1].transpose(0, 1), blk[:, 2].transpose(0, 1)
+        p = torch.softmax(q @ k.transpose(1, 2) / 8.0, -1)
+        ref[cu[b]: cu[b] + L] = (p @ v).transpose(0, 1).reshape(L, H * 64).float()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())   # fp32 products and sums over <= 512 keys
+
+
+@pytest.mark.parametrize("rows,d,with_res", [(1, 4, False), (7, 768, True), (1000, 768, False), (5, 1024, True), (3, 2048, True), (9, 100, True)])
+def test_add_layernorm_vs_torch(ops, rows, d, with_res):
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn((rows, d), generator=g, device="cuda") * 3 + 1
+    res = torch.randn((rows, d), generator=g, device="cuda") if with_res else None
+    gamma, beta = torch.randn(d, generator=g, device="cuda"), torch.randn(d, generator=g, device="cuda")
+    out = ops.add_layernorm(x, res, gamma, beta, 1e-5)
+    ref = torch.nn.functional.layer_norm((x + res if with_res else x).double(), (d,), gamma.double(), beta.double(), 1e-5)
+    assert (out.double() - ref).abs().max().item() <= 5e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_segment_mean_vs_torch(ops):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    lengths = [3, 0, 64, 1, 200]
+    x = torch.randn((sum(lengths), 768), generator=g, device="cuda")
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lengths)]), dtype=torch.int32, device="cuda")
+    out = ops.segment_mean(x, cu)
+    for b, L in enumerate(lengths):
+        ref = x[int(cu[b]): int(cu[b + 1])].double().mean(0) if L else torch.zeros(768, dtype=torch.float64, device="cuda")
+        assert (out[b].double() - ref).abs().max().item() <= 1e-6
+
+
+def test_packed_encoder_matches_hf_forward():
+    """PackedBertForward (HIP attention / LayerNorm / pooling on packed rows) == the HF module + mean pooling, 5e-5 abs on
+    embeddings of magnitude ~1 (fp32 throughout; different summation orders in 2-12 layers)."""
+    from fusion_amd import encoders
+    cfg = dict(encoders.TINY, hidden_size=128, num_attention_heads=2, intermediate_size=256)
+    torch.manual_seed(0)
+    enc = encoders.DenseEncoder(encoders._backbone(cfg), encoders.HashTokenizer(cfg["vocab_size"]), "cuda")
+    rng = np.random.default_rng(0)
+    n, Lmax = 37, 64
+    lens = rng.integers(2, Lmax + 1, size=n)
+    lens[0] = Lmax
+    ids = np.full((n, Lmax), cfg["pad_token_id"], dtype=np.int64)
+    for i, L in enumerate(lens):
+        ids[i, :L] = rng.integers(7, cfg["vocab_size"], size=L)
+    I = torch.from_numpy(ids).cuda()
+    M = (torch.arange(Lmax, device="cuda")[None, :] < torch.from_numpy(lens).cuda()[:, None]).long()
+    a = enc.encode_ids(I, M)
+    b = enc.encode_ids_packed(I, lens)
+    assert b.shape == a.shape and (a - b).abs().max().item() <= 5e-5
+    # the text entry point takes the packed path (token-budgeted sub-batches) and agrees with the HF forward sentence by sentence
+    texts = [" ".join(f"w{rng.integers(0, 300)}" for _ in range(int(k))) for k in rng.integers(1, 150, size=23)]
+    enc.packed_tokens = 256
+    e = enc.encode(texts, batch_size=4)
+    for i, t in enumerate(texts):
+        ids1, m1 = enc.tokenizer([t], enc.max_doc_length)
+        assert (enc.encode_ids(ids1.cuda(), m1.cuda())[0] - e[i]).abs().max().item() <= 5e-5
+    with pytest.raises(ValueError):
+        encoders.random_init("dpr", "cuda", size="tiny").encode_ids_packed(I[:, :32] % 500, np.minimum(lens, 32))   # head_dim 16
