@@ -19,109 +19,137 @@ namespace fz {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 struct AttnArgs {
     const float* qkv;   // [T][ld]: q | k | v, each H*64 wide
     int ld;
-    const int4* strips;  // (first row of the sequence, its length L, first query of this strip, unused)
-    int n_strips;
+    const int4* blocks;  // (first row of the sequence, its length L, first query of this block of <= 64 queries, unused)
+    int n_blocks;
     int H;
     float* out;  // [T][ldo]
     int ldo;
-    float scale;
+    float scale_log2e;   // scale * log2(e): softmax runs in the base-2 domain
+    int T;
 };
 
-// one wave = one (strip of 32 queries, head); 4 waves of a workgroup = 4 consecutive heads of the same strip (their
-// rows are contiguous in memory).  No LDS, no barriers.
-__global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs a) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int hgroups = (a.H + 3) >> 2;
-    const int strip = blockIdx.x / hgroups;
-    const int h = (blockIdx.x - strip * hgroups) * 4 + wave;
-    if (h >= a.H) return;
-    const int4 st = a.strips[strip];
-    const int tok0 = st.x, L = st.y, q0 = st.z;
+#define ATT_LDT 68   // LDS row stride in floats: 64 + 4 -> the 16 lanes of one ds_read_b128 phase hit 64 distinct banks
+
+// One wave = one (32-query strip, head); a workgroup = the two strips of one 64-query block x two heads (the strips share
+// their K/V rows through L1/L2; a strip past the end of the sequence exits at once).  No barriers: every wave transposes
+// through its own LDS slice.
+//
+// Global -> MFMA layout.  S^T = K Q^T needs lane = token, registers = dims (the contraction), i.e. the transpose of the
+// row-major activations: a direct load would touch 64 different cache lines per instruction.  Tiles are therefore read
+// as whole 256-B head rows (4 rows per wave-instruction, bounds-checked buffer loads: rows past the end of the buffer
+// read 0, rows of the next sequence are masked out below) and turned through LDS.  V needs lane = dim: direct dword loads are
+// already two full lines per instruction.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_varlen_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * ATT_LDT];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int hpairs = (a.H + 1) >> 1;
+    const int blk = blockIdx.x / hpairs;
+    const int h = (blockIdx.x - blk * hpairs) * 2 + (wave >> 1);
+    const int4 st = a.blocks[blk];
+    const int tok0 = st.x, L = st.y, q0 = st.z + 32 * (wave & 1);
+    if (h >= a.H || q0 >= L) return;
     const int r = lane & 31, half = lane >> 5;
     const int hid = a.H * 64;
-    const float* base = a.qkv + (size_t)tok0 * a.ld + h * 64;
+    const int ldb = a.ld * 4;   // row pitch in bytes
 
-    // Q fragment (B operand of S^T): query q0 + r, contraction slots kk -> dim half*32 + kk
-    float qf[32];
-    {
-        const int qi = min(q0 + r, L - 1);
-        const float4* qp = reinterpret_cast<const float4*>(base + (size_t)qi * a.ld + half * 32);
+    // everything below addresses the sequence through one descriptor: base = its first row, this head's q columns
+    const float* base = a.qkv + (size_t)tok0 * a.ld + h * 64;
+    const size_t avail = ((size_t)(a.T - tok0) * a.ld - (size_t)h * 64) * 4;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, avail > 0xffffffffull ? (int)0xffffffffu : (int)avail, 0x00020000);
+
+    float* my = lds + wave * (32 * ATT_LDT);
+    const int ld_row = lane >> 4, ld_c4 = lane & 15;                 // coalesced tile load: 4 rows x 16 float4 per instruction
+    const int voff_t = ld_row * ldb + ld_c4 * 16;
+    float* const wr = my + ld_row * ATT_LDT + ld_c4 * 4;
+    const float* const rd = my + r * ATT_LDT + half * 32;
+    const int voff_v = (4 * half) * ldb + r * 4;
+
+    auto load_tile = [&](int row0, int col_bytes, float (&f)[32]) {   // rows row0..row0+31, 64 floats at col_bytes -> f = [row r][half*32 + kk]
+        i32x4 raw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_t, (row0 + 4 * i) * ldb + col_bytes, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<i32x4*>(wr + 4 * i * ATT_LDT) = raw[i];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float4 t = qp[i];
-            qf[4 * i] = t.x; qf[4 * i + 1] = t.y; qf[4 * i + 2] = t.z; qf[4 * i + 3] = t.w;
+            const float4 t = *reinterpret_cast<const float4*>(rd + 4 * i);
+            f[4 * i] = t.x; f[4 * i + 1] = t.y; f[4 * i + 2] = t.z; f[4 * i + 3] = t.w;
         }
-    }
-    float m = -INFINITY, l = 0.0f;
+    };
+
+    float qf[32];
+    load_tile(q0, 0, qf);
+    float m = -INFINITY, l = 0.0f;   // running max (base-2 domain) and sum of this lane's query
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.0f; o1[i] = 0.0f; }
 
     for (int j0 = 0; j0 < L; j0 += 32) {
-        // K fragment (A operand): key j0 + r, same contraction slots as Q
         float kf[32];
-        {
-            const int kj = min(j0 + r, L - 1);
-            const float4* kp = reinterpret_cast<const float4*>(base + (size_t)kj * a.ld + hid + half * 32);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 t = kp[i];
-                kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
-            }
-        }
-        // V fragments (A operand of O^T): row = dim r (and 32 + r), contraction slot (reg, half) -> key j(reg, half)
-        float v0[16], v1[16];
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int j = min(j0 + 8 * (g >> 2) + (g & 3) + 4 * half, L - 1);
-            const float* vp = base + (size_t)j * a.ld + 2 * hid + r;
-            v0[g] = vp[0];
-            v1[g] = vp[32];
-        }
+        load_tile(j0, hid * 4, kf);
         f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.0f;
 #pragma unroll
         for (int kk = 0; kk < 32; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kk], qf[kk], s, 0, 0, 0);
-        // s[g] = <q_{q0+r}, k_j>, j = j0 + 8(g/4) + 4 half + g%4
-        float mx = -INFINITY;
+        // s[g] = <q_{q0+r}, k_j>, j = j0 + 8(g/4) + 4 half + g%4.  V in the matching layout: row = dim r (and 32 + r)
+        float v0[16], v1[16];
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            const int j = j0 + 8 * (g >> 2) + (g & 3) + 4 * half;
-            s[g] = j < L ? s[g] * a.scale : -INFINITY;
-            mx = fmaxf(mx, s[g]);
+            const int so = (j0 + 8 * (g >> 2) + (g & 3)) * ldb + 2 * hid * 4;
+            v0[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_v, so, 0));
+            v1[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_v + 128, so, 0));
         }
+        if (j0 + 32 > L) {   // last, partial tile: keys past the sequence (the next sequence's rows, or zeros) drop out
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                if (j0 + 8 * (g >> 2) + (g & 3) + 4 * half >= L) s[g] = -INFINITY;
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) mx = fmaxf(mx, s[g]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m, mx);          // finite: key j0 < L is in this tile
-        const float alpha = __expf(m - mnew);     // first tile: exp(-inf) = 0
+        const float mnew = fmaxf(m, mx * a.scale_log2e);   // finite: key j0 < L is in this tile
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);   // first tile: exp2(-inf) = 0
         float psum = 0.0f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            s[g] = __expf(s[g] - mnew);
+            // one rounding: the error of mnew itself is common to the whole row and cancels in p / sum(p)
+            s[g] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[g], a.scale_log2e, -mnew));
             psum += s[g];
         }
         psum += __shfl_xor(psum, 32, 64);
         l = l * alpha + psum;
         m = mnew;
+        if (j0 > 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[g], s[g], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[g], s[g], o1, 0, 0, 0);
         }
     }
-    if (q0 + r < L) {
-        const float inv = 1.0f / l;
-        float* op = a.out + (size_t)(tok0 + q0 + r) * a.ldo + h * 64 + 4 * half;
+    // O^T (lane = query, registers = dims) -> rows through the LDS slice -> whole 256-B rows out
+    const float inv = 1.0f / l;
+    float* const ow = my + r * ATT_LDT + 4 * half;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            *reinterpret_cast<float4*>(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            *reinterpret_cast<float4*>(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-        }
+    for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(ow + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(ow + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+    float* const op = a.out + (size_t)(tok0 + q0) * a.ldo + h * 64 + ld_c4 * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + ld_row;
+        const float4 t = *reinterpret_cast<const float4*>(my + row * ATT_LDT + ld_c4 * 4);
+        if (q0 + row < L) *reinterpret_cast<float4*>(op + (size_t)row * a.ldo) = t;
     }
 }
 
@@ -198,16 +226,17 @@ using namespace fz;
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
+extern "C" int fz_attn_varlen_f32(const float* qkv, int ld, int T, const int32_t* blocks, int n_blocks, int H, int head_dim, float scale,
                                   float* out, int ldo, void* stream) {
-    if (n_strips < 0 || H <= 0) return FZ_ERR_ARG;
-    if (n_strips == 0) return FZ_OK;
-    if (!qkv || !strips || !out) return FZ_ERR_ARG;
+    if (n_blocks < 0 || H <= 0 || T < 0) return FZ_ERR_ARG;
+    if (n_blocks == 0 || T == 0) return FZ_OK;
+    if (!qkv || !blocks || !out) return FZ_ERR_ARG;
     if (head_dim != 64) return FZ_ERR_UNSUPPORTED;
     if (ld < 3 * H * 64 || ldo < H * 64) return FZ_ERR_ARG;
-    if ((ld & 3) || (ldo & 3) || !aligned16(qkv) || !aligned16(out) || !aligned16(strips)) return FZ_ERR_UNSUPPORTED;
-    AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(strips), n_strips, H, out, ldo, scale};
-    const long long grid = (long long)n_strips * ((H + 3) / 4);
+    if ((ld & 3) || (ldo & 3) || !aligned16(qkv) || !aligned16(out) || !aligned16(blocks)) return FZ_ERR_UNSUPPORTED;
+    if ((long long)ld * 4 * 16384 > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;   // in-sequence byte offsets are 32-bit
+    AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(blocks), n_blocks, H, out, ldo, scale * 1.4426950408889634f, T};
+    const long long grid = (long long)n_blocks * ((H + 1) / 2);
     if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
     attn_varlen_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
     FZ_LAUNCH_CHECK();

@@ -440,19 +440,19 @@ def f64_to_f32(src: torch.Tensor) -> torch.Tensor:
 # encoder side: packed (padding-free) token rows
 # ---------------------------------------------------------------------------------------
 def attn_strips(lengths, cu_rows=None):
-    """HOST helper: the strip table fz_attn_varlen_f32 walks -- one (first row, length, first query, 0) entry per 32 queries
-    of every sequence, longest sequences first.  Returns (strips int32 [n_strips, 4] numpy, cu_rows int32 [B+1] numpy)."""
+    """HOST helper: the block table fz_attn_varlen_f32 walks -- one (first row, length, first query, 0) entry per 64 queries
+    of every sequence, longest sequences first.  Returns (blocks int32 [n_blocks, 4] numpy, cu_rows int32 [B+1] numpy)."""
     import numpy as np
     lengths = np.asarray(lengths, dtype=np.int64)
     if cu_rows is None:
         cu_rows = np.zeros(len(lengths) + 1, dtype=np.int64)
         np.cumsum(lengths, out=cu_rows[1:])
-    per = (lengths + 31) // 32
+    per = (lengths + 63) // 64
     order = np.argsort(-lengths, kind="stable")
     seq = np.repeat(order, per[order])
     first = np.zeros(len(order) + 1, dtype=np.int64)
     np.cumsum(per[order], out=first[1:])
-    q0 = (np.arange(len(seq)) - np.repeat(first[:-1], per[order])) * 32
+    q0 = (np.arange(len(seq)) - np.repeat(first[:-1], per[order])) * 64
     strips = np.stack([cu_rows[seq], lengths[seq], q0, np.zeros_like(q0)], 1).astype(np.int32)
     return np.ascontiguousarray(strips), cu_rows.astype(np.int32)
 
@@ -468,7 +468,9 @@ def attn_varlen(qkv: torch.Tensor, strips: torch.Tensor, heads: int, scale: floa
         raise ValueError("attn_varlen: strips must be a contiguous [n_strips, 4] int32 tensor (ops.attn_strips)")
     if out is None:
         out = torch.empty((T, heads * 64), dtype=torch.float32, device=qkv.device)
-    check(_lib.lib().fz_attn_varlen_f32(_ptr(qkv), qkv.stride(0) if T > 1 else W, _ptr(strips), strips.shape[0], heads, 64,
+    if scale is not None and not scale > 0:
+        raise ValueError("attn_varlen: scale must be positive")
+    check(_lib.lib().fz_attn_varlen_f32(_ptr(qkv), qkv.stride(0) if T > 1 else W, T, _ptr(strips), strips.shape[0], heads, 64,
                                         float(64 ** -0.5 if scale is None else scale), _ptr(out), out.stride(0) if T > 1 else heads * 64,
                                         _stream(qkv)), "fz_attn_varlen_f32")
     return out
