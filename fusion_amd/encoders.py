@@ -165,7 +165,9 @@ class PackedBertForward(FusedBertForward):
     (residual + LayerNorm in one pass) and fz_segment_mean_f32 (mean Pooling).  head_dim must be 64 (BERT-base family)."""
 
     @torch.no_grad()
-    def __call__(self, input_ids: torch.Tensor, lengths, n_buckets: int = 0) -> torch.Tensor:
+    def __call__(self, input_ids: torch.Tensor, lengths, n_buckets: int = 0, mark=None) -> torch.Tensor:
+        """`mark(name)`: optional instrumentation hook (bench.py records a HIP event per call): "encode" closes an interval
+        of everything but attention, "encode_attn" closes one fz_attn_varlen_f32 launch."""
         import numpy as np
         from . import ops
         F = torch.nn.functional
@@ -191,7 +193,9 @@ class PackedBertForward(FusedBertForward):
         x = ops.add_layernorm(x, None, *self.emb_ln)
         for ly in self.layers:
             qkv = F.linear(x, ly["wqkv"], ly["bqkv"])
+            if mark: mark("encode")
             ctx = ops.attn_varlen(qkv, strips_d, H)
+            if mark: mark("encode_attn")
             x = ops.add_layernorm(F.linear(ctx, ly["wo"], ly["bo"]), x, *ly["ln1"])
             h = F.gelu(F.linear(x, ly["w1"], ly["b1"]))
             x = ops.add_layernorm(F.linear(h, ly["w2"], ly["b2"]), x, *ly["ln2"])
@@ -223,11 +227,11 @@ class DenseEncoder(_Base):
         return self._fused(input_ids, lengths, n_buckets)
 
     @torch.no_grad()
-    def encode_ids_packed(self, input_ids: torch.Tensor, lengths) -> torch.Tensor:
+    def encode_ids_packed(self, input_ids: torch.Tensor, lengths, mark=None) -> torch.Tensor:
         """Same embeddings again, padding-free (PackedBertForward: HIP attention / LayerNorm / pooling kernels)."""
         if getattr(self, "_packed", None) is None:
             self._packed = PackedBertForward(self.backbone)
-        return self._packed(input_ids, lengths)
+        return self._packed(input_ids, lengths, mark=mark)
 
     @torch.no_grad()
     def encode_ids_bucketed(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, lengths, n_buckets: int = 8) -> torch.Tensor:
