@@ -30,7 +30,6 @@ struct AttnArgs {
     float* out;  // [T][ldo]
     int ldo;
     float scale_log2e;   // scale * log2(e): softmax runs in the base-2 domain
-    int T;
 };
 
 #define ATT_LDT 68   // LDS row stride in floats: 64 + 4 -> the 16 lanes of one ds_read_b128 phase hit 64 distinct banks
@@ -41,8 +40,8 @@ struct AttnArgs {
 //
 // Global -> MFMA layout.  S^T = K Q^T needs lane = token, registers = dims (the contraction), i.e. the transpose of the
 // row-major activations: a direct load would touch 64 different cache lines per instruction.  Tiles are therefore read
-// as whole 256-B head rows (4 rows per wave-instruction, bounds-checked buffer loads: rows past the end of the buffer
-// read 0, rows of the next sequence are masked out below) and turned through LDS.  V needs lane = dim: direct dword loads are
+// as whole 256-B head rows (4 rows per wave-instruction, bounds-checked buffer loads: rows past the end of the sequence
+// read 0) and turned through LDS.  V needs lane = dim: direct dword loads are
 // already two full lines per instruction.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_varlen_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 32 * ATT_LDT];
@@ -57,10 +56,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int hid = a.H * 64;
     const int ldb = a.ld * 4;   // row pitch in bytes
 
-    // everything below addresses the sequence through one descriptor: base = its first row, this head's q columns
+    // everything below addresses the sequence through one descriptor: base = its first row, this head's q columns; the
+    // range ends with the sequence's last row, so the rows a partial tile reaches past it read 0 WITHOUT touching memory
+    // (tiles are 32 rows whatever the length: unchecked loads moved 1.4x the algorithmic bytes at the LLeQA length mix)
     const float* base = a.qkv + (size_t)tok0 * a.ld + h * 64;
-    const size_t avail = ((size_t)(a.T - tok0) * a.ld - (size_t)h * 64) * 4;
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, avail > 0xffffffffull ? (int)0xffffffffu : (int)avail, 0x00020000);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (L * a.ld - h * 64) * 4, 0x00020000);
 
     float* my = lds + wave * (32 * ATT_LDT);
     const int ld_row = lane >> 4, ld_c4 = lane & 15;                 // coalesced tile load: 4 rows x 16 float4 per instruction
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             v0[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_v, so, 0));
             v1[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_v + 128, so, 0));
         }
-        if (j0 + 32 > L) {   // last, partial tile: keys past the sequence (the next sequence's rows, or zeros) drop out
+        if (j0 + 32 > L) {   // last, partial tile: keys past the sequence (read as zeros) drop out
 #pragma unroll
             for (int g = 0; g < 16; ++g)
                 if (j0 + 8 * (g >> 2) + (g & 3) + 4 * half >= L) s[g] = -INFINITY;
@@ -226,16 +226,16 @@ using namespace fz;
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int fz_attn_varlen_f32(const float* qkv, int ld, int T, const int32_t* blocks, int n_blocks, int H, int head_dim, float scale,
+extern "C" int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* blocks, int n_blocks, int H, int head_dim, float scale,
                                   float* out, int ldo, void* stream) {
-    if (n_blocks < 0 || H <= 0 || T < 0) return FZ_ERR_ARG;
-    if (n_blocks == 0 || T == 0) return FZ_OK;
+    if (n_blocks < 0 || H <= 0 || !(scale > 0.0f)) return FZ_ERR_ARG;
+    if (n_blocks == 0) return FZ_OK;
     if (!qkv || !blocks || !out) return FZ_ERR_ARG;
     if (head_dim != 64) return FZ_ERR_UNSUPPORTED;
     if (ld < 3 * H * 64 || ldo < H * 64) return FZ_ERR_ARG;
     if ((ld & 3) || (ldo & 3) || !aligned16(qkv) || !aligned16(out) || !aligned16(blocks)) return FZ_ERR_UNSUPPORTED;
     if ((long long)ld * 4 * 16384 > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;   // in-sequence byte offsets are 32-bit
-    AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(blocks), n_blocks, H, out, ldo, scale * 1.4426950408889634f, T};
+    AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(blocks), n_blocks, H, out, ldo, scale * 1.4426950408889634f};
     const long long grid = (long long)n_blocks * ((H + 1) / 2);
     if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
     attn_varlen_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);

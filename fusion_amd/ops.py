@@ -470,7 +470,7 @@ def attn_varlen(qkv: torch.Tensor, strips: torch.Tensor, heads: int, scale: floa
         out = torch.empty((T, heads * 64), dtype=torch.float32, device=qkv.device)
     if scale is not None and not scale > 0:
         raise ValueError("attn_varlen: scale must be positive")
-    check(_lib.lib().fz_attn_varlen_f32(_ptr(qkv), qkv.stride(0) if T > 1 else W, T, _ptr(strips), strips.shape[0], heads, 64,
+    check(_lib.lib().fz_attn_varlen_f32(_ptr(qkv), qkv.stride(0) if T > 1 else W, _ptr(strips), strips.shape[0], heads, 64,
                                         float(64 ** -0.5 if scale is None else scale), _ptr(out), out.stride(0) if T > 1 else heads * 64,
                                         _stream(qkv)), "fz_attn_varlen_f32")
     return out

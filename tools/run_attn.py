@@ -6,9 +6,13 @@ from fusion_amd import ops
 
 Q = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-lo, hi, mu, sd = (4, 64, 36, 14) if len(sys.argv) <= 3 else (16, 512, 300, 120)
+mode = sys.argv[3] if len(sys.argv) > 3 else "queries"
 rng = np.random.default_rng(0)
-lens = np.clip(rng.normal(mu, sd, Q).round().astype(np.int64), lo, hi)
+if mode.startswith("fixed:"):
+    lens = np.full(Q, int(mode[6:]), dtype=np.int64)
+else:
+    lo, hi, mu, sd = (4, 64, 36, 14) if mode == "queries" else (16, 512, 300, 120)
+    lens = np.clip(rng.normal(mu, sd, Q).round().astype(np.int64), lo, hi)
 T = int(lens.sum())
 g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn((T, 2304), generator=g, device="cuda")
