@@ -204,20 +204,34 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     }
 }
 
-// out[b] = mean of rows [cu[b], cu[b+1]) (zeros for an empty sequence); one workgroup per sequence
-__global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ x, int ldx, const int32_t* __restrict__ cu, int d,
-                                                           float* __restrict__ out, int ldo) {
+// Per-sequence column reductions over packed rows; one workgroup per (sequence, 1024-column slab).
+//   MODE 0: out[b] = mean of rows [cu[b], cu[b+1])                     (sentence-transformers Pooling(mean))
+//   MODE 1: out[b] = log1p(relu(max of the rows))  = max_t log1p(relu(x_t)), log1p o relu being monotone
+//           (SPLADE-max, splade/splade.py:88-99); an empty sequence gives 0 in both modes.
+template <int MODE, int VEC>
+__global__ __launch_bounds__(256) void segment_reduce_kernel(const float* __restrict__ x, int ldx, const int32_t* __restrict__ cu, int d,
+                                                             float* __restrict__ out, int ldo) {
     const int b = blockIdx.x;
     const int t0 = cu[b], t1 = cu[b + 1];
     const float inv = t1 > t0 ? 1.0f / (float)(t1 - t0) : 0.0f;
-    for (int c = threadIdx.x; c < (d >> 2); c += 256) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t = t0; t < t1; ++t) {
-            const float4 u = reinterpret_cast<const float4*>(x + (size_t)t * ldx)[c];
-            acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+    const int c = (blockIdx.y * 256 + threadIdx.x) * VEC;
+    if (c >= d) return;
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = MODE == 0 ? 0.0f : -INFINITY;
+    for (int t = t0; t < t1; ++t) {
+        float u[VEC];
+        if (VEC == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(x + (size_t)t * ldx + c);
+            u[0] = q.x; u[1 % VEC] = q.y; u[2 % VEC] = q.z; u[3 % VEC] = q.w;
+        } else {
+            u[0] = x[(size_t)t * ldx + c];
         }
-        reinterpret_cast<float4*>(out + (size_t)b * ldo)[c] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = MODE == 0 ? acc[i] + u[i] : fmaxf(acc[i], u[i]);
     }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[(size_t)b * ldo + c + i] = MODE == 0 ? acc[i] * inv : log1pf(fmaxf(acc[i], 0.0f));
 }
 
 }  // namespace fz
@@ -262,12 +276,26 @@ extern "C" int fz_add_layernorm_f32(const float* x, int ldx, const float* res, i
     return FZ_OK;
 }
 
-extern "C" int fz_segment_mean_f32(const float* x, int ldx, const int32_t* cu_rows, int B, int d, float* out, int ldo, void* stream) {
+template <int MODE>
+static int launch_segment_reduce(const float* x, int ldx, const int32_t* cu_rows, int B, int d, float* out, int ldo, void* stream) {
     if (B < 0 || d <= 0) return FZ_ERR_ARG;
     if (B == 0) return FZ_OK;
     if (!x || !cu_rows || !out || ldx < d || ldo < d) return FZ_ERR_ARG;
-    if ((d & 3) || (ldx & 3) || (ldo & 3) || !aligned16(x) || !aligned16(out)) return FZ_ERR_UNSUPPORTED;
-    segment_mean_kernel<<<(unsigned)B, 256, 0, as_stream(stream)>>>(x, ldx, cu_rows, d, out, ldo);
+    const bool vec = !(d & 3) && !(ldx & 3) && aligned16(x);
+    const int per = vec ? 1024 : 256;
+    dim3 grid((unsigned)B, (unsigned)((d + per - 1) / per));
+    if (vec)
+        segment_reduce_kernel<MODE, 4><<<grid, 256, 0, as_stream(stream)>>>(x, ldx, cu_rows, d, out, ldo);
+    else
+        segment_reduce_kernel<MODE, 1><<<grid, 256, 0, as_stream(stream)>>>(x, ldx, cu_rows, d, out, ldo);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
+}
+
+extern "C" int fz_segment_mean_f32(const float* x, int ldx, const int32_t* cu_rows, int B, int d, float* out, int ldo, void* stream) {
+    return launch_segment_reduce<0>(x, ldx, cu_rows, B, d, out, ldo, stream);
+}
+
+extern "C" int fz_segment_splade_max_f32(const float* x, int ldx, const int32_t* cu_rows, int B, int d, float* out, int ldo, void* stream) {
+    return launch_segment_reduce<1>(x, ldx, cu_rows, B, d, out, ldo, stream);
 }

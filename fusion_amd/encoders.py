@@ -58,6 +58,13 @@ def _backbone(cfg: dict, mlm: bool = False):
 class _Base(nn.Module):
     max_query_length = 64
     max_doc_length = 512
+    packed_tokens = 65536   # token rows per padding-free forward (FFN activations: 65536 x 3072 fp32 = 0.8 GB)
+
+    def _packed_forward(self, backbone):
+        """PackedBertForward over `backbone` when this encoder sits on a GPU and the model has 64-wide heads, else None."""
+        if getattr(self, "_packed", None) is None and self._device.type == "cuda" and PackedBertForward.supports(backbone.config):
+            self._packed = PackedBertForward(backbone)
+        return getattr(self, "_packed", None)
 
     def __init__(self, tokenizer, device):
         super().__init__()
@@ -77,6 +84,20 @@ class _Base(nn.Module):
             idx = order[s: s + batch_size]
             ids, mask = self.tokenizer([sentences[i] for i in idx], max_len, pad_to_max)
             yield idx, ids.to(self._device, non_blocking=True), mask.to(self._device, non_blocking=True)
+
+
+def _token_batches(base, sentences, max_len, batch_size):
+    """Sub-batches for the padding-free forward, longest sentences first (as SentenceTransformer.encode sorts), cut by an
+    estimate of the TOKEN count (activations stay under ~1 GB) rather than by sentence count.
+    Yields (indices into `sentences`, ids [b, L] on the HOST, lengths [b] numpy)."""
+    order = sorted(range(len(sentences)), key=lambda i: -len(sentences[i]))
+    s = 0
+    while s < len(order):
+        step = max(batch_size, base.packed_tokens // min(max_len, 8 + 2 * len(sentences[order[s]].split())))
+        idx = order[s: s + step]
+        ids, mask = base.tokenizer([sentences[i] for i in idx], max_len)
+        yield idx, ids, mask.sum(1).numpy()
+        s += step
 
 
 class FusedBertForward:
@@ -164,9 +185,15 @@ class PackedBertForward(FusedBertForward):
     fz_attn_varlen_f32 (attention straight from the fused-QKV rows, no gather/scatter, no mask), fz_add_layernorm_f32
     (residual + LayerNorm in one pass) and fz_segment_mean_f32 (mean Pooling).  head_dim must be 64 (BERT-base family)."""
 
+    @staticmethod
+    def supports(config) -> bool:
+        return config.hidden_size == 64 * config.num_attention_heads
+
     @torch.no_grad()
-    def __call__(self, input_ids: torch.Tensor, lengths, n_buckets: int = 0, mark=None) -> torch.Tensor:
-        """`mark(name)`: optional instrumentation hook (bench.py records a HIP event per call): "encode" closes an interval
+    def hidden(self, input_ids: torch.Tensor, lengths, mark=None):
+        """input_ids [n, Lmax] (anything beyond a row's length is ignored), lengths: HOST token counts ->
+        (last hidden states of the real tokens, packed [T, hidden] fp32 in row order; cu_rows [n+1] int32 on the device).
+        `mark(name)`: optional instrumentation hook (bench.py records a HIP event per call): "encode" closes an interval
         of everything but attention, "encode_attn" closes one fz_attn_varlen_f32 launch."""
         import numpy as np
         from . import ops
@@ -179,13 +206,13 @@ class PackedBertForward(FusedBertForward):
         lengths = np.minimum(np.asarray(lengths, dtype=np.int64), Lmax)
         strips, cu = ops.attn_strips(lengths)
         T = int(cu[-1])
+        tables = torch.from_numpy(np.concatenate([strips.reshape(-1), cu])).to(dev, non_blocking=True)
+        strips_d, cu_d = tables[: strips.size].view(-1, 4), tables[strips.size:]
         if T == 0:
-            return torch.zeros((n, self.word.shape[1]), dtype=torch.float32, device=dev)
+            return torch.zeros((0, self.word.shape[1]), dtype=torch.float32, device=dev), cu_d
         cols = np.arange(T, dtype=np.int64) - np.repeat(cu[:-1].astype(np.int64), lengths)
         host = np.concatenate([np.repeat(np.arange(n, dtype=np.int64) * Lmax, lengths) + cols, cols + (self.pad_idx + 1)])
         meta = torch.from_numpy(host).to(dev, non_blocking=True)                       # one upload: gather indices + position ids
-        tables = torch.from_numpy(np.concatenate([strips.reshape(-1), cu])).to(dev, non_blocking=True)
-        strips_d, cu_d = tables[: strips.size].view(-1, 4), tables[strips.size:]
         ids = input_ids.reshape(-1)[meta[:T]]
         x = self.word[ids]
         x += self.pos[meta[T:]]
@@ -199,13 +226,18 @@ class PackedBertForward(FusedBertForward):
             x = ops.add_layernorm(F.linear(ctx, ly["wo"], ly["bo"]), x, *ly["ln1"])
             h = F.gelu(F.linear(x, ly["w1"], ly["b1"]))
             x = ops.add_layernorm(F.linear(h, ly["w2"], ly["b2"]), x, *ly["ln2"])
+        return x, cu_d
+
+    @torch.no_grad()
+    def __call__(self, input_ids: torch.Tensor, lengths, n_buckets: int = 0, mark=None) -> torch.Tensor:
+        """-> mean-pooled [n, hidden] fp32 (zeros for an empty sequence)."""
+        from . import ops
+        x, cu_d = self.hidden(input_ids, lengths, mark)
         return ops.segment_mean(x, cu_d)
 
 
 class DenseEncoder(_Base):
     """DPR bi-encoder: CamemBERT + mean pooling over the attention mask, fp32."""
-
-    packed_tokens = 65536   # token rows per padding-free forward (FFN activations: 65536 x 3072 fp32 = 0.8 GB)
 
     def __init__(self, backbone, tokenizer, device):
         super().__init__(tokenizer, device)
@@ -231,7 +263,7 @@ class DenseEncoder(_Base):
         """Same embeddings again, padding-free (PackedBertForward: HIP attention / LayerNorm / pooling kernels)."""
         if getattr(self, "_packed", None) is None:
             self._packed = PackedBertForward(self.backbone)
-        return self._packed(input_ids, lengths, mark=mark)
+        return self._packed(input_ids, lengths, mark=mark)   # raises for head_dim != 64
 
     @torch.no_grad()
     def encode_ids_bucketed(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, lengths, n_buckets: int = 8) -> torch.Tensor:
@@ -256,17 +288,10 @@ class DenseEncoder(_Base):
     @torch.no_grad()
     def encode(self, sentences: list[str], batch_size: int = 64, query_mode: bool = True, **_) -> torch.Tensor:
         out = torch.empty((len(sentences), self.dim), dtype=torch.float32, device=self._device)
-        cfg = self.backbone.config
-        if self._device.type == "cuda" and cfg.hidden_size == 64 * cfg.num_attention_heads:
-            # padding-free path: sub-batches are cut by TOKEN count (activations stay under ~1 GB), not by sentence count
-            order = sorted(range(len(sentences)), key=lambda i: -len(sentences[i]))
-            s = 0
-            while s < len(order):
-                step = max(batch_size, self.packed_tokens // min(self.max_doc_length, 8 + 2 * len(sentences[order[s]].split())))
-                idx = order[s: s + step]
-                ids, mask = self.tokenizer([sentences[i] for i in idx], self.max_doc_length)
-                out[torch.tensor(idx, device=self._device)] = self.encode_ids_packed(ids.to(self._device, non_blocking=True), mask.sum(1).numpy())
-                s += step
+        fwd = self._packed_forward(self.backbone)
+        if fwd is not None:
+            for idx, ids, lens in _token_batches(self, sentences, self.max_doc_length, batch_size):
+                out[torch.tensor(idx, device=self._device)] = fwd(ids.to(self._device, non_blocking=True), lens)
             return out
         for idx, ids, mask in self._batches(sentences, batch_size, self.max_doc_length):   # max_seq_length = 512 (hybrid.py:99)
             out[torch.tensor(idx, device=self._device)] = self.encode_ids(ids, mask).float()
@@ -291,6 +316,14 @@ class SpladeEncoder(_Base):
     def encode(self, sentences, batch_size: int = 64, query_mode: bool = True, **_) -> torch.Tensor:
         out = torch.empty((len(sentences), self.dim), dtype=torch.float32, device=self._device)
         max_len = self.max_query_length if query_mode else self.max_doc_length
+        fwd = self._packed_forward(getattr(self.mlm, self.mlm.base_model_prefix))
+        if fwd is not None:
+            from . import ops
+            self.packed_tokens = min(self.packed_tokens, 16384)     # the [T, vocab] logits: 16384 x 32005 fp32 = 2.1 GB
+            for idx, ids, lens in _token_batches(self, sentences, max_len, batch_size):
+                x, cu_d = fwd.hidden(ids.to(self._device, non_blocking=True), lens)
+                out[torch.tensor(idx, device=self._device)] = ops.segment_splade_max(self.mlm.lm_head(x), cu_d)
+            return out
         for idx, ids, mask in self._batches(sentences, batch_size, max_len):
             out[torch.tensor(idx, device=self._device)] = self.encode_ids(ids, mask).float()
         return out
@@ -317,6 +350,18 @@ class ColbertEncoder(_Base):
     def encode_queries(self, queries: list[str], batch_size: int = 64) -> torch.Tensor:
         """-> [Q, 64, 128] fp16; pads with the mask token and attends to it (run_colbert.sh:29)."""
         out = torch.empty((len(queries), self.max_query_length, self.dim), dtype=torch.float16, device=self._device)
+        fwd = self._packed_forward(self.backbone)
+        if fwd is not None:
+            import numpy as np
+            from . import ops
+            Lq = self.max_query_length
+            for s in range(0, len(queries), max(batch_size, self.packed_tokens // Lq)):
+                part = queries[s: s + max(batch_size, self.packed_tokens // Lq)]
+                ids, mask = self.tokenizer(part, Lq, True)
+                ids = torch.where(mask.bool(), ids, torch.full_like(ids, self.tokenizer.mask_token_id)).to(self._device, non_blocking=True)
+                x, _ = fwd.hidden(ids, np.full(len(part), Lq))       # every query is Lq tokens long: [MASK] padding is attended
+                out[s: s + len(part)] = ops.normalize_rows(self.linear(x)).view(len(part), Lq, self.dim).half()
+            return out
         for idx, ids, mask in self._batches(queries, batch_size, self.max_query_length, pad_to_max=True):
             ids = torch.where(mask.bool(), ids, torch.full_like(ids, self.tokenizer.mask_token_id))
             v = self._tokens(ids, torch.ones_like(mask))
@@ -326,6 +371,9 @@ class ColbertEncoder(_Base):
     @torch.no_grad()
     def encode_docs(self, docs: list[str], batch_size: int = 64):
         """-> (Dtok [sumL,128] fp16 packed in corpus order, Doff [N+1] int64): padding and punctuation tokens dropped."""
+        fwd = self._packed_forward(self.backbone)
+        if fwd is not None:
+            return self._encode_docs_packed(fwd, docs, batch_size)
         per_doc: list[torch.Tensor | None] = [None] * len(docs)
         for idx, ids, mask in self._batches(docs, batch_size, self.max_doc_length):
             v = self._tokens(ids, mask).half()
@@ -339,6 +387,39 @@ class ColbertEncoder(_Base):
         off[1:] = torch.cumsum(lens, 0)
         tok = torch.cat(per_doc, 0) if per_doc else torch.empty((0, self.dim), dtype=torch.float16, device=self._device)
         return tok.contiguous(), off.to(self._device)
+
+    @torch.no_grad()
+    def _encode_docs_packed(self, fwd, docs, batch_size):
+        """Padding-free document side: the packed token rows of the forward ARE the ragged layout fz_maxsim_f16 reads; punctuation
+        rows are dropped with a gather whose indices come from the HOST copy of the ids (no device sync), and the sub-batches
+        (longest documents first) are stitched back into corpus order by one final gather."""
+        import numpy as np
+        from . import ops
+        punct = self.punct_ids.cpu().numpy()
+        chunks, counts, place = [], np.zeros(len(docs), dtype=np.int64), []
+        base = 0
+        for idx, ids, lens in _token_batches(self, docs, self.max_doc_length, batch_size):
+            x, _ = fwd.hidden(ids.to(self._device, non_blocking=True), lens)
+            v = ops.normalize_rows(self.linear(x)).half()                               # [T, 128], rows in sub-batch order
+            ids_np = ids.numpy()
+            keep_rows, starts = [], np.zeros(len(idx) + 1, dtype=np.int64)
+            np.cumsum(lens, out=starts[1:])
+            for r, i in enumerate(idx):
+                k = np.flatnonzero(~np.isin(ids_np[r, : lens[r]], punct)) if punct.size else np.arange(lens[r])
+                counts[i] = len(k)
+                keep_rows.append(k + starts[r])
+                place.append((i, base, len(k)))
+                base += len(k)
+            keep = np.concatenate(keep_rows) if keep_rows else np.zeros(0, dtype=np.int64)
+            chunks.append(v if len(keep) == v.shape[0] else v[torch.from_numpy(keep).to(self._device, non_blocking=True)])
+        off = np.zeros(len(docs) + 1, dtype=np.int64)
+        np.cumsum(counts, out=off[1:])
+        gather = np.empty(int(off[-1]), dtype=np.int64)
+        for i, b, c in place:
+            gather[off[i]: off[i] + c] = np.arange(b, b + c)
+        tok = torch.cat(chunks, 0) if chunks else torch.empty((0, self.dim), dtype=torch.float16, device=self._device)
+        tok = tok[torch.from_numpy(gather).to(self._device, non_blocking=True)] if len(gather) else tok
+        return tok.contiguous(), torch.from_numpy(off).to(self._device)
 
 
 def random_init(kind: str, device="cuda", size: str = "base", seed: int = 0):

@@ -493,12 +493,20 @@ def add_layernorm(x: torch.Tensor, res: torch.Tensor | None, gamma: torch.Tensor
     return out
 
 
-def segment_mean(x: torch.Tensor, cu_rows: torch.Tensor) -> torch.Tensor:
-    """Mean over each sequence's rows: x [T, d] fp32, cu_rows [B+1] int32 -> [B, d]."""
-    _dev(x, torch.float32, "segment_mean(x)")
-    _dev(cu_rows, torch.int32, "segment_mean(cu_rows)")
+def _segment_reduce(fn: str, x: torch.Tensor, cu_rows: torch.Tensor) -> torch.Tensor:
+    _dev(x, torch.float32, f"{fn}(x)")
+    _dev(cu_rows, torch.int32, f"{fn}(cu_rows)")
     B, d = cu_rows.numel() - 1, x.shape[1]
     out = torch.empty((max(B, 0), d), dtype=torch.float32, device=x.device)
-    check(_lib.lib().fz_segment_mean_f32(_ptr(x), x.stride(0) if x.shape[0] > 1 else d, _ptr(cu_rows), B, d, _ptr(out), d, _stream(x)),
-          "fz_segment_mean_f32")
+    check(getattr(_lib.lib(), fn)(_ptr(x), x.stride(0) if x.shape[0] > 1 else d, _ptr(cu_rows), B, d, _ptr(out), d, _stream(x)), fn)
     return out
+
+
+def segment_mean(x: torch.Tensor, cu_rows: torch.Tensor) -> torch.Tensor:
+    """Mean over each sequence's rows: x [T, d] fp32, cu_rows [B+1] int32 -> [B, d]."""
+    return _segment_reduce("fz_segment_mean_f32", x, cu_rows)
+
+
+def segment_splade_max(x: torch.Tensor, cu_rows: torch.Tensor) -> torch.Tensor:
+    """SPLADE-max pooling: log1p(relu(max over each sequence's rows)): x [T, V] fp32 logits -> [B, V]."""
+    return _segment_reduce("fz_segment_splade_max_f32", x, cu_rows)

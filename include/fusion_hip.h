@@ -198,6 +198,9 @@ int fz_add_layernorm_f32(const float* x, int ldx, const float* res, int ldr, con
 /* mean Pooling (sentence_transformers Pooling(mean)): out[b] = mean of rows [cu_rows[b], cu_rows[b+1]) of x; zeros for an
  * empty sequence.  cu_rows [B+1] int32 (device). */
 int fz_segment_mean_f32(const float* x, int ldx, const int32_t* cu_rows, int B, int d, float* out, int ldo, void* stream);
+/* SPLADE-max pooling (splade/splade.py:88-99: amax over the tokens of log1p(relu(logits))): out[b] = log1p(relu(max of the
+ * rows [cu_rows[b], cu_rows[b+1]) of x)) -- the same value, log1p o relu being monotone; 0 for an empty sequence. */
+int fz_segment_splade_max_f32(const float* x, int ldx, const int32_t* cu_rows, int B, int d, float* out, int ldo, void* stream);
 
 /* ---- small utilities ------------------------------------------------------------------ */
 int fz_fill_i32(int32_t* p, size_t count, int32_t value, void* stream);

@@ -717,3 +717,53 @@ def test_packed_encoder_matches_hf_forward():
         assert (enc.encode_ids(ids1.cuda(), m1.cuda())[0] - e[i]).abs().max().item() <= 5e-5
     with pytest.raises(ValueError):
         encoders.random_init("dpr", "cuda", size="tiny").encode_ids_packed(I[:, :32] % 500, np.minimum(lens, 32))   # head_dim 16
+
+
+def test_packed_splade_and_colbert_match_padded_forward(ops):
+    """SPLADE and ColBERT encoders on the padding-free forward == the HF module on padded batches, sentence by sentence
+    (1e-4 abs: fp32 everywhere, ColBERT token vectors are unit-norm fp16 -> half an fp16 ulp of 1.0 is 5e-4)."""
+    from fusion_amd import encoders
+    cfg = dict(encoders.TINY, hidden_size=128, num_attention_heads=2, intermediate_size=256)
+    rng = np.random.default_rng(1)
+    texts = [" ".join(f"w{rng.integers(0, 40)}" for _ in range(int(k))) for k in rng.integers(1, 90, size=19)]
+    torch.manual_seed(1)
+    tok = encoders.HashTokenizer(cfg["vocab_size"])
+    sp = encoders.SpladeEncoder(encoders._backbone(cfg, mlm=True), tok, "cuda")
+    sp.packed_tokens = 300
+    got = sp.encode(texts, batch_size=4, query_mode=False)
+    assert sp._packed is not None and got.shape == (len(texts), cfg["vocab_size"])
+    for i, t in enumerate(texts):
+        ids1, m1 = tok([t], sp.max_doc_length)
+        assert (sp.encode_ids(ids1.cuda(), m1.cuda())[0] - got[i]).abs().max().item() <= 1e-4
+    punct = (tok._tok("w3"), tok._tok("w7"))
+    cb = encoders.ColbertEncoder(encoders._backbone(cfg), tok, "cuda", punct_ids=punct)
+    cb.packed_tokens = 300
+    Dtok, Doff = cb.encode_docs(texts, batch_size=4)
+    assert cb._packed is not None and Doff.shape == (len(texts) + 1,) and int(Doff[-1]) == Dtok.shape[0]
+    for i, t in enumerate(texts):
+        ids1, m1 = tok([t], cb.max_doc_length)
+        keep = ~torch.isin(ids1[0], torch.tensor(punct))
+        ref = cb._tokens(ids1.cuda(), m1.cuda())[0][keep.cuda()]
+        mine = Dtok[int(Doff[i]): int(Doff[i + 1])].float()
+        assert mine.shape == ref.shape and (mine - ref).abs().max().item() <= 6e-4
+    Qtok = cb.encode_queries(texts[:5])
+    for i, t in enumerate(texts[:5]):
+        ids1, m1 = tok([t], cb.max_query_length, True)
+        ids1 = torch.where(m1.bool(), ids1, torch.full_like(ids1, tok.mask_token_id))
+        ref = cb._tokens(ids1.cuda(), torch.ones_like(m1).cuda())[0]
+        assert (Qtok[i].float() - ref).abs().max().item() <= 6e-4
+    # the packed document tokens feed the MaxSim kernel as they are
+    s = ops.maxsim(Qtok, Dtok, Doff, max_doc_len=cb.max_doc_length)
+    assert s.shape == (5, len(texts)) and torch.isfinite(s).all()
+
+
+def test_segment_splade_max_vs_torch(ops):
+    g = torch.Generator(device="cuda").manual_seed(6)
+    lengths = [3, 0, 64, 1]
+    for d in (32005, 512):       # unaligned vocabulary (scalar path) and aligned (vector path)
+        x = torch.randn((sum(lengths), d), generator=g, device="cuda") * 3
+        cu = torch.tensor(np.concatenate([[0], np.cumsum(lengths)]), dtype=torch.int32, device="cuda")
+        out = ops.segment_splade_max(x, cu)
+        for b, L in enumerate(lengths):
+            ref = torch.log1p(torch.relu(x[int(cu[b]): int(cu[b + 1])])).amax(0) if L else torch.zeros(d, device="cuda")
+            assert (out[b] - ref).abs().max().item() <= 1e-6
