@@ -8,7 +8,9 @@ this on one GPU, one query at a time (1.2 M launches for mMARCO).
   * every rank scores ALL queries against its shard in document chunks: fp32-MFMA GEMM -> per-row top-k
     (csrc/sort.hip) -> merge into the running top-k -- no host round trip;
   * ONE all-gather of the per-shard [Q, k] (score fp32, id int64) lists over RCCL/xGMI (8.2 MB + 8.2 MB per rank at
-    Q = 1024, k = 1000: < 1 % of the GEMM time) and an identical local G-way merge on every rank.
+    Q = 1024, k = 1000: < 1 % of the GEMM time, SURVEY 5) and an identical local G-way merge on every rank;
+  * the query ENCODER is data-parallel over the queries: every rank runs the transformer on its 1/G of the batch and the
+    [Q, 768] embeddings (3 MB) are all-gathered -- the only other exchange step.
 Ties are broken by ascending global document id everywhere, so the result does not depend on the number of shards.
 """
 from __future__ import annotations
@@ -24,6 +26,23 @@ def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
     base, extra = divmod(n, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def allgather_rows(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """Rows sharded by shard_bounds(total, world, rank) -> the full [total, d] tensor on every rank, in rank order:
+    one all-gather of equal-size (zero-padded) blocks."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    per = -(-total // world)
+    block = local.new_zeros((per, local.shape[1]))
+    block[: local.shape[0]] = local
+    out = local.new_empty((world * per, local.shape[1]))
+    dist.all_gather_into_tensor(out, block, group=group)
+    if total == world * per:
+        return out
+    return torch.cat([out[r * per: r * per + (hi - lo)] for r in range(world) for lo, hi in [shard_bounds(total, world, r)]])
 
 
 def allgather_topk(local_scores: torch.Tensor, local_ids: torch.Tensor, group=None, merge_fn=None):
@@ -99,13 +118,14 @@ def bench_sharded(args, dev, rank, world, dist):
         qlen = rng.integers(8, L + 1, Q)
         ids = rng.integers(7, enc.backbone.config.vocab_size - 1, (Q, L))
         mask = (np.arange(L)[None, :] < qlen[:, None]).astype(np.int64)
-        ids_t = torch.from_numpy(np.where(mask == 1, ids, 1)).to(dev)
-        mask_t = torch.from_numpy(mask).to(dev)
+        qlo, qhi = shard_bounds(Q, world, rank)                         # this rank encodes its 1/world of the queries
+        ids_t = torch.from_numpy(np.where(mask == 1, ids, 1)[qlo:qhi]).to(dev)
+        qlen = qlen[qlo:qhi]
     else:
         q_emb = torch.from_numpy(rng.normal(0, 1, (Q, d)).astype(np.float32)).to(dev)
 
     def step():
-        e = enc.encode_ids(ids_t, mask_t) if not args.no_encode else q_emb
+        e = allgather_rows(enc.encode_ids_packed(ids_t, qlen), Q) if not args.no_encode else q_emb
         return index.search(ops.normalize_rows(e), k)
 
     def barrier():

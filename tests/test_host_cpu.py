@@ -152,7 +152,7 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
-    from fusion_amd.distributed import allgather_topk, shard_bounds
+    from fusion_amd.distributed import allgather_rows, allgather_topk, shard_bounds
     from oracle import oracle
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(0)
@@ -166,7 +166,11 @@ def _worker(rank, world, port, q):
         return torch.from_numpy(a), torch.from_numpy(b)
     gs, gi = allgather_topk(torch.from_numpy(ls), torch.from_numpy(li), merge_fn=merge)
     es, ei = oracle.topk_rows(S, k)
-    q.put((rank, bool(np.array_equal(gs.numpy(), es)), bool(np.array_equal(gi.numpy(), ei))))
+    # query-sharded encoder outputs -> every rank holds all rows, in order (uneven split: 7 rows over 2 ranks)
+    E = torch.arange(7 * 3, dtype=torch.float32).view(7, 3)
+    elo, ehi = shard_bounds(7, world, rank)
+    rows_ok = bool(torch.equal(allgather_rows(E[elo:ehi].clone(), 7), E)) and bool(torch.equal(allgather_rows(E[2 * rank: 2 * rank + 2].clone(), 4), E[:4]))
+    q.put((rank, bool(np.array_equal(gs.numpy(), es)) and rows_ok, bool(np.array_equal(gi.numpy(), ei))))
     dist.destroy_process_group()
 
 
