@@ -63,6 +63,17 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _need(cond: bool, msg: str):
+    """Host-side shape contract of a kernel launch: a mismatch would be an out-of-bounds access on the device."""
+    if not cond:
+        raise ValueError(msg)
+
+
+def _same_shape(ts, what: str):
+    shapes = {tuple(t.shape) for t in ts if t is not None}
+    _need(len(shapes) <= 1, f"{what}: planes differ in shape: {sorted(shapes)}")
+
+
 def _stream(t: torch.Tensor):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -137,6 +148,9 @@ def dot_scores(Qn: torch.Tensor, Dn: torch.Tensor, out: torch.Tensor | None = No
     Q, N, d = Qn.shape[0], Dn.shape[0], Qn.shape[1]
     if out is None:
         out = alloc_plane(Q, N, torch.float32, Qn.device)
+    else:
+        _dev(out, torch.float32, "dot_scores(out)")
+        _need(tuple(out.shape) == (Q, N), f"dot_scores(out): expected shape {(Q, N)}, got {tuple(out.shape)}")
     check(_lib.lib().fz_dot_scores_f32(_ptr(Qn), Qn.stride(0) if Q > 1 else d, _ptr(Dn), Dn.stride(0) if N > 1 else d, Q, N, d,
                                        _ptr(out), _ld(out), _stream(Qn)), "fz_dot_scores_f32")
     return out
@@ -160,8 +174,13 @@ def maxsim(Qtok: torch.Tensor, Dtok: torch.Tensor, Doff: torch.Tensor, out: torc
     Qtok, Dtok, Doff = Qtok.contiguous(), Dtok.contiguous(), Doff.contiguous()
     Q, Lq, dim = Qtok.shape
     N = Doff.numel() - 1
+    _need(Dtok.dim() == 2 and Dtok.shape[1] == dim, f"maxsim: Dtok must be [sumL, {dim}]")
+    _need(N >= 0, "maxsim: Doff must hold N + 1 offsets")
     if out is None:
         out = alloc_plane(Q, N, torch.float32, Qtok.device)
+    else:
+        _dev(out, torch.float32, "maxsim(out)")
+        _need(tuple(out.shape) == (Q, N), f"maxsim(out): expected shape {(Q, N)}, got {tuple(out.shape)}")
     if max_doc_len is None:
         max_doc_len = max(int((Doff[1:] - Doff[:-1]).max().item()), 1) if N > 0 else 1
     check(_lib.lib().fz_maxsim_f16(_ptr(Qtok), _ptr(Dtok), _ptr(Doff), int(Dtok.shape[0]), int(max_doc_len), Q, Lq, N, dim, _ptr(out),
@@ -204,6 +223,7 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
     rank = mk(torch.int32, -1) if want_rank else None
     if init_order is not None:
         _dev(init_order, torch.int32, "init_order")
+        _need(tuple(init_order.shape) == (rows, n), f"init_order: expected shape {(rows, n)}, got {tuple(init_order.shape)}")
         if _ld(init_order) != ld and rows > 1:
             t = mk(torch.int32, -1)
             t.copy_(init_order)
@@ -211,9 +231,11 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
     if row_len is not None:
         _dev(row_len, torch.int32, "row_len")
         row_len = row_len.contiguous()
+        _need(row_len.numel() == rows, f"row_len: expected {rows} entries, got {row_len.numel()}")
     bits = 32 if keys.dtype == torch.float32 else 64
     if init_rank is not None:
         _dev(init_rank, torch.int32, "init_rank")
+        _need(tuple(init_rank.shape) == (rows, n), f"init_rank: expected shape {(rows, n)}, got {tuple(init_rank.shape)}")
         if _ld(init_rank) != ld and rows > 1:
             t = mk(torch.int32, -1)
             t.copy_(init_rank)
@@ -233,10 +255,12 @@ def fuse_rank(ranks: list[torch.Tensor], lens: torch.Tensor, method: str) -> tor
     """rrf / bcf in float64 (hybrid.py:248-252,301-304). ranks[s] [Q,N] int32 planes, lens [S,Q] int32."""
     for r in ranks:
         _dev(r, torch.int32, "fuse_rank(ranks)")
+    _same_shape(ranks, "fuse_rank")
     ranks = harmonise(list(ranks))
     _dev(lens, torch.int32, "fuse_rank(lens)")
     lens = lens.contiguous()
     Q, N = ranks[0].shape
+    _need(tuple(lens.shape) == (len(ranks), Q), f"fuse_rank(lens): expected shape {(len(ranks), Q)}, got {tuple(lens.shape)}")
     ld = _same_ld(*ranks)
     fused = torch.empty((max(Q, 1), ld), dtype=torch.float64, device=ranks[0].device)[:Q, :N]
     check(_lib.lib().fz_fuse_rank_f64(_ptr_array(ranks), _ptr(lens), len(ranks), Q, N, ld, RANK_METHODS[method], _ptr(fused),
@@ -251,6 +275,7 @@ def row_stats(scores: torch.Tensor, rank: torch.Tensor | None, norm: str):
     b = torch.empty(rows, dtype=torch.float32, device=scores.device)
     if rank is not None:
         _dev(rank, torch.int32, "row_stats(rank)")
+        _same_shape([scores, rank], "row_stats")
         _same_ld(scores, rank)
     check(_lib.lib().fz_row_stats_f32(_ptr(scores), _ptr(rank), rows, N, _ld(scores), NORMS[norm], _ptr(a), _ptr(b), _stream(scores)),
           "fz_row_stats_f32")
@@ -263,17 +288,28 @@ def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None
     for p in planes:
         _dev(p, torch.float32, "fuse_nsf(planes)")
     S = len(planes)
+    if ranks:
+        _need(len(ranks) == S, f"fuse_nsf: {S} planes but {len(ranks)} rank planes")
+        for r in ranks:
+            if r is not None:
+                _dev(r, torch.int32, "fuse_nsf(ranks)")
+    _same_shape(list(planes) + (list(ranks) if ranks else []), "fuse_nsf")
+    _need(len(weights) == S, f"fuse_nsf: {S} planes but {len(weights)} weights")
     both = harmonise(list(planes) + (list(ranks) if ranks else []))
     planes, ranks = both[:S], (both[S:] if ranks else None)
     Q, N = planes[0].shape
     ld = _same_ld(*planes, *([r for r in ranks if r is not None] if ranks else []))
     dev = planes[0].device
+    if out is not None:
+        _dev(out, torch.float32, "fuse_nsf(out)")
+        _need(tuple(out.shape) == (Q, N) and (Q <= 1 or _ld(out) == ld), f"fuse_nsf(out): expected a [{Q}, {N}] plane with row stride {ld}")
     fused = out if out is not None else torch.empty((max(Q, 1), ld), dtype=torch.float32, device=dev)[:Q, :N]
     w = (C.c_double * S)(*[float(x) for x in weights])
     dptr, P = None, None
     if norm in ("percentile-rank", "normal-curve-equivalent"):
         if distr is None or any(d is None for d in distr):
             raise AttributeError("percentile distributions are required for percentile-rank / normal-curve-equivalent")
+        _need(len(distr) == S, f"fuse_nsf: {S} planes but {len(distr)} percentile tables")
         distr = [_dev(d, torch.float32, "distr").contiguous() for d in distr]
         dptr = _ptr_array(distr)
         P = (C.c_int32 * S)(*[int(d.numel()) for d in distr])
@@ -300,6 +336,13 @@ def fuse_none(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | Non
     for p in planes:
         _dev(p, torch.float32, "fuse_none(planes)")
     S = len(planes)
+    if ranks:
+        _need(len(ranks) == S, f"fuse_none: {S} planes but {len(ranks)} rank planes")
+        for r in ranks:
+            if r is not None:
+                _dev(r, torch.int32, "fuse_none(ranks)")
+    _same_shape(list(planes) + (list(ranks) if ranks else []), "fuse_none")
+    _need(len(weights) == S, f"fuse_none: {S} planes but {len(weights)} weights")
     both = harmonise(list(planes) + (list(ranks) if ranks else []))
     planes, ranks = both[:S], (both[S:] if ranks else None)
     Q, N = planes[0].shape
@@ -315,10 +358,13 @@ def insertion_order(orders: list[torch.Tensor], lens: torch.Tensor, N: int):
     """First-insertion order of the fused dict (hybrid.py:301-304). Returns (ins_order [Q,N] int32, U [Q] int32)."""
     for o in orders:
         _dev(o, torch.int32, "insertion_order(orders)")
+    _same_shape(orders, "insertion_order")
     orders = harmonise(list(orders))
     _dev(lens, torch.int32, "insertion_order(lens)")
     lens = lens.contiguous()
     Q = orders[0].shape[0]
+    _need(orders[0].shape[1] == N, f"insertion_order: order planes are {orders[0].shape[1]} wide, N = {N}")
+    _need(tuple(lens.shape) == (len(orders), Q), f"insertion_order(lens): expected shape {(len(orders), Q)}, got {tuple(lens.shape)}")
     ld = _same_ld(*orders)
     dev = orders[0].device
     ins = torch.full((max(Q, 1), ld), -1, dtype=torch.int32, device=dev)[:Q, :N]
@@ -339,6 +385,7 @@ def gold_ranks(T: list[torch.Tensor], pos: torch.Tensor, weights: torch.Tensor, 
     _dev(gold, torch.int32, "gold_ranks(gold)")
     lib = _lib.lib()
     G = int(lib.fz_tune_max_gold())
+    _same_shape(list(T) + [pos], "gold_ranks")
     both = harmonise(list(T) + [pos])
     T, pos = both[:-1], both[-1]
     Q, N = T[0].shape
@@ -379,10 +426,13 @@ def topk_update(scores: torch.Tensor, id_base: int, run_scores: torch.Tensor, ru
     _dev(run_ids, torch.int64, "topk_update(run_ids)")
     rows, n = scores.shape
     k = run_scores.shape[1]
+    _need(tuple(run_scores.shape) == (rows, k) and tuple(run_ids.shape) == (rows, k), f"topk_update: running lists must be [{rows}, k]")
     dev = scores.device
     lib = _lib.lib()
     if overflow is None:
         overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    else:
+        _dev(overflow, torch.int32, "topk_update(overflow)")
     ns = torch.empty((rows, k), dtype=torch.float32, device=dev)
     ni = torch.empty((rows, k), dtype=torch.int64, device=dev)
     wsb = int(lib.fz_topk_update_workspace_bytes(rows, k, cap))
@@ -396,6 +446,7 @@ def topk_merge(in_scores: torch.Tensor, in_ids: torch.Tensor):
     """[G,rows,k] per-shard lists -> global top-k [rows,k] (after the RCCL all-gather)."""
     _dev(in_scores, torch.float32, "topk_merge(in_scores)")
     _dev(in_ids, torch.int64, "topk_merge(in_ids)")
+    _need(in_scores.dim() == 3 and in_scores.shape == in_ids.shape, "topk_merge: scores and ids must both be [G, rows, k]")
     in_scores, in_ids = in_scores.contiguous(), in_ids.contiguous()
     G, rows, k = in_scores.shape
     os_ = torch.empty((rows, k), dtype=torch.float32, device=in_scores.device)
@@ -419,6 +470,14 @@ def bm25_doc_norms(doc_len: torch.Tensor, avgdl: float, k1: float, b: float) -> 
 def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float, qoff, qterms, Q: int, N: int,
                 doc_norm: torch.Tensor | None = None) -> torch.Tensor:
     dev = idf.device
+    for t, dt, what in ((toff, torch.int64, "toff"), (pdoc, torch.int32, "pdoc"), (ptf, torch.int32, "ptf"), (idf, torch.float64, "idf"),
+                        (doc_len, torch.int32, "doc_len"), (qoff, torch.int64, "qoff"), (qterms, torch.int32, "qterms")):
+        _need(_dev(t, dt, f"bm25_scores({what})").is_contiguous(), f"bm25_scores({what}) must be contiguous")
+    _need(toff.numel() == idf.numel() + 1, "bm25_scores: toff must hold V + 1 offsets for idf's V terms")
+    _need(pdoc.numel() == ptf.numel(), "bm25_scores: pdoc and ptf differ in length")
+    _need(doc_len.numel() == N and qoff.numel() == Q + 1, f"bm25_scores: doc_len must hold {N} lengths and qoff {Q + 1} offsets")
+    if doc_norm is not None:
+        _need(_dev(doc_norm, torch.float64, "bm25_scores(doc_norm)").numel() == N and doc_norm.is_contiguous(), f"bm25_scores: doc_norm must hold {N} values")
     out = torch.empty((max(Q, 1), max(round_up(N, _PAD), _PAD)), dtype=torch.float64, device=dev)[:Q, :N]
     check(_lib.lib().fz_bm25_scores_f64(_ptr(toff), _ptr(pdoc), _ptr(ptf), _ptr(idf), _ptr(doc_len), _ptr(doc_norm), float(avgdl), float(k1),
                                         float(b), _ptr(qoff), _ptr(qterms), Q, N, _ptr(out), _ld(out), _stream(idf)), "fz_bm25_scores_f64")
@@ -468,6 +527,9 @@ def attn_varlen(qkv: torch.Tensor, strips: torch.Tensor, heads: int, scale: floa
         raise ValueError("attn_varlen: strips must be a contiguous [n_strips, 4] int32 tensor (ops.attn_strips)")
     if out is None:
         out = torch.empty((T, heads * 64), dtype=torch.float32, device=qkv.device)
+    else:
+        _dev(out, torch.float32, "attn_varlen(out)")
+        _need(tuple(out.shape) == (T, heads * 64), f"attn_varlen(out): expected shape {(T, heads * 64)}, got {tuple(out.shape)}")
     if scale is not None and not scale > 0:
         raise ValueError("attn_varlen: scale must be positive")
     check(_lib.lib().fz_attn_varlen_f32(_ptr(qkv), qkv.stride(0) if T > 1 else W, _ptr(strips), strips.shape[0], heads, 64,
@@ -484,8 +546,12 @@ def add_layernorm(x: torch.Tensor, res: torch.Tensor | None, gamma: torch.Tensor
         _dev(res, torch.float32, "add_layernorm(res)")
         if res.shape != x.shape:
             raise ValueError("add_layernorm: x and res differ in shape")
+    _need(gamma.numel() == d and beta.numel() == d and gamma.is_contiguous() and beta.is_contiguous(), f"add_layernorm: gamma and beta must hold {d} values")
     if out is None:
         out = torch.empty((rows, d), dtype=torch.float32, device=x.device)
+    else:
+        _dev(out, torch.float32, "add_layernorm(out)")
+        _need(tuple(out.shape) == (rows, d), f"add_layernorm(out): expected shape {(rows, d)}, got {tuple(out.shape)}")
     ldr = 0 if res is None else (res.stride(0) if rows > 1 else d)
     check(_lib.lib().fz_add_layernorm_f32(_ptr(x), x.stride(0) if rows > 1 else d, _ptr(res), ldr, _ptr(_dev(gamma, torch.float32, "gamma")),
                                           _ptr(_dev(beta, torch.float32, "beta")), float(eps), rows, d, _ptr(out),

@@ -767,3 +767,29 @@ def test_segment_splade_max_vs_torch(ops):
         for b, L in enumerate(lengths):
             ref = torch.log1p(torch.relu(x[int(cu[b]): int(cu[b + 1])])).amax(0) if L else torch.zeros(d, device="cuda")
             assert (out[b] - ref).abs().max().item() <= 1e-6
+
+
+def test_ops_reject_mismatched_shapes_before_launch(ops):
+    """A shape the kernel would index out of bounds with is a ValueError on the host, never a launch."""
+    z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device="cuda")
+    a, b = ops.alloc_plane(4, 100, torch.int32, "cuda", fill=0), ops.alloc_plane(4, 90, torch.int32, "cuda", fill=0)
+    lens = torch.full((2, 4), 100, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        ops.fuse_rank([a, b], lens, "rrf")
+    with pytest.raises(ValueError):
+        ops.fuse_rank([a, a], lens[:1], "rrf")
+    p = ops.alloc_plane(4, 100, torch.float32, "cuda", fill=0.0)
+    with pytest.raises(ValueError):
+        ops.fuse_nsf([p, p], None, [0.5], "min-max")
+    with pytest.raises(ValueError):
+        ops.fuse_nsf([p, p], None, [0.5, 0.5], "min-max", out=z(4, 101))
+    with pytest.raises(ValueError):
+        ops.insertion_order([a, a], lens, 101)
+    with pytest.raises(ValueError):
+        ops.sort_rows_desc(p, row_len=torch.zeros(3, dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.add_layernorm(z(3, 8), None, z(4), z(8), 1e-5)
+    with pytest.raises(ValueError):
+        ops.topk_merge(z(2, 3, 5), torch.zeros((2, 3, 4), dtype=torch.int64, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.dot_scores(z(3, 8), z(5, 8), out=z(3, 6))
