@@ -5,27 +5,21 @@
 // them that the padded formulation pays for twice (padding tokens in every GEMM, a gather/scatter around attention):
 //
 //   fz_attn_varlen_f32     softmax(q k^T / sqrt(64)) v per (sequence, head) straight from the fused-QKV activations of
-//                          packed rows, fp32 MFMA, flash-style online softmax over 32-key tiles, no LDS:
-//                            S^T = K Q^T   so that a query is a LANE: row max / row sum are 16 in-register steps + one
-//                                          cross-half shuffle instead of 80 shuffles;
-//                            O^T = V^T P^T the C-layout registers of S^T ARE the B operand of this product (register r of
-//                                          lane (q, half) holds key 8(r/4) + 4 half + r%4: contraction step r pairs the
-//                                          two halves' keys), so probabilities never move.
+//                          packed rows: fp32 MFMA (16x16x4), online softmax over 16-key tiles (see the kernel's comment);
 //   fz_add_layernorm_f32   LayerNorm(x + residual): one wave per row, row held in registers, one HBM pass.
-//   fz_segment_mean_f32    mean Pooling over each sequence's rows.
+//   fz_segment_mean_f32 / fz_segment_splade_max_f32    mean Pooling / SPLADE-max pooling over each sequence's rows.
 #include "common.h"
 
 namespace fz {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct AttnArgs {
     const float* qkv;   // [T][ld]: q | k | v, each H*64 wide
     int ld;
-    const int4* blocks;  // (first row of the sequence, its length L, first query of this block of <= 64 queries, unused)
-    int n_blocks;
+    const int4* strips;  // (first row of the sequence, its length L, first query of this strip of <= 16 queries, unused)
+    int n_strips;
     int H;
     float* out;  // [T][ldo]
     int ldo;
@@ -34,122 +28,122 @@ struct AttnArgs {
 
 #define ATT_LDT 68   // LDS row stride in floats: 64 + 4 -> the 16 lanes of one ds_read_b128 phase hit 64 distinct banks
 
-// One wave = one (32-query strip, head); a workgroup = the two strips of one 64-query block x two heads (the strips share
-// their K/V rows through L1/L2; a strip past the end of the sequence exits at once).  No barriers: every wave transposes
-// through its own LDS slice.
+// One wave = one (16-query strip, head); the four waves of a workgroup take four consecutive strips of the table for ONE
+// head -- consecutive strips mostly belong to one sequence, so its waves read the same K/V rows (L1 hits) -- and every wave
+// is live whatever the sequence lengths.  No barriers: each wave turns its tiles through its own LDS slice.
 //
-// Global -> MFMA layout.  S^T = K Q^T needs lane = token, registers = dims (the contraction), i.e. the transpose of the
-// row-major activations: a direct load would touch 64 different cache lines per instruction.  Tiles are therefore read
-// as whole 256-B head rows (4 rows per wave-instruction, bounds-checked buffer loads: rows past the end of the sequence
-// read 0) and turned through LDS.  V needs lane = dim: direct dword loads are
-// already two full lines per instruction.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_varlen_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * ATT_LDT];
+//   * S^T = K Q^T: a query is a lane COLUMN, so the row max / row sum of the softmax are 3 in-register steps + two
+//     cross-group shuffles, and the C registers of S^T are, unchanged, the B operand of O^T = V^T P^T (register i of lane
+//     (q, g) holds key 4 g + i of the tile: contraction step i pairs the four groups' keys) -- probabilities never move;
+//   * online softmax over 16-key tiles in the base-2 domain (v_exp_f32; one FMA rounding per element, the rounding of the
+//     running maximum is common to a row and cancels in p / sum p);
+//   * global -> MFMA layout: S^T needs lane = token, registers = dims, i.e. the transpose of the row-major activations
+//     (a direct load would touch 32 cache lines per instruction).  Q/K tiles are read as whole 256-B head rows (4 rows per
+//     wave-instruction) and turned through LDS; V needs lane = dim: direct dword loads.  All loads are bounds-checked
+//     buffer loads whose range ends with the sequence: the rows a partial tile reaches past it read 0 without touching
+//     memory (unchecked, 32-row tiles moved 1.4x the algorithmic bytes at the LLeQA length mix);
+//   * v_mfma_f32_16x16x4_f32 rather than 32x32x2: tiles cut at 16 waste 24 % fewer MFMA cycles on padding at that mix,
+//     and a wave needs 72 VGPRs instead of 128 -> 7 waves per SIMD hide each other's load -> LDS -> MFMA -> softmax chain.
+// Layouts (16x16x4): A lane l -> row l%16, k-slot l/16; B lane l -> col l%16, k-slot l/16; C reg r -> row 4(l/16)+r, col l%16.
+//   S^T step i pairs dim 16*(l/16) + i of key row l%16 with the same dim of query l%16;
+//   O^T step i takes register i of S^T (key 4(l/16) + i of the tile) against V[that key][16 t + l%16].
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void attn_varlen_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * ATT_LDT];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int hpairs = (a.H + 1) >> 1;
-    const int blk = blockIdx.x / hpairs;
-    const int h = (blockIdx.x - blk * hpairs) * 2 + (wave >> 1);
-    const int4 st = a.blocks[blk];
-    const int tok0 = st.x, L = st.y, q0 = st.z + 32 * (wave & 1);
-    if (h >= a.H || q0 >= L) return;
-    const int r = lane & 31, half = lane >> 5;
+    const int grp = blockIdx.x / a.H;
+    const int h = blockIdx.x - grp * a.H;
+    const int strip = grp * 4 + wave;
+    if (strip >= a.n_strips) return;
+    const int4 st = a.strips[strip];
+    const int tok0 = st.x, L = st.y, q0 = st.z;
+    if (q0 >= L) return;
+    const int r = lane & 15, kg = lane >> 4;
     const int hid = a.H * 64;
     const int ldb = a.ld * 4;   // row pitch in bytes
-
-    // everything below addresses the sequence through one descriptor: base = its first row, this head's q columns; the
-    // range ends with the sequence's last row, so the rows a partial tile reaches past it read 0 WITHOUT touching memory
-    // (tiles are 32 rows whatever the length: unchecked loads moved 1.4x the algorithmic bytes at the LLeQA length mix)
+    // one descriptor per wave: base = the sequence's first row, this head's q columns; range = the sequence
     const float* base = a.qkv + (size_t)tok0 * a.ld + h * 64;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (L * a.ld - h * 64) * 4, 0x00020000);
 
-    float* my = lds + wave * (32 * ATT_LDT);
-    const int ld_row = lane >> 4, ld_c4 = lane & 15;                 // coalesced tile load: 4 rows x 16 float4 per instruction
-    const int voff_t = ld_row * ldb + ld_c4 * 16;
-    float* const wr = my + ld_row * ATT_LDT + ld_c4 * 4;
-    const float* const rd = my + r * ATT_LDT + half * 32;
-    const int voff_v = (4 * half) * ldb + r * 4;
+    float* my = lds + wave * (16 * ATT_LDT);
+    const int voff_t = kg * ldb + r * 16;                 // tile load: lane = (row kg of 4, float4 r of 16) per instruction
+    float* const wr = my + kg * ATT_LDT + r * 4;
+    const float* const rd = my + r * ATT_LDT + kg * 16;
+    const int voff_v = (4 * kg) * ldb + r * 4;
 
-    auto load_tile = [&](int row0, int col_bytes, float (&f)[32]) {   // rows row0..row0+31, 64 floats at col_bytes -> f = [row r][half*32 + kk]
-        i32x4 raw[8];
+    auto load_tile = [&](int row0, int col_bytes, float (&f)[16]) {   // rows row0..row0+15 -> f[i] = [row r][16 kg + i]
+        i32x4 raw[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_t, (row0 + 4 * i) * ldb + col_bytes, 0);
+        for (int i = 0; i < 4; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_t, (row0 + 4 * i) * ldb + col_bytes, 0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<i32x4*>(wr + 4 * i * ATT_LDT) = raw[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(wr + 4 * i * ATT_LDT) = raw[i];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const float4 t = *reinterpret_cast<const float4*>(rd + 4 * i);
             f[4 * i] = t.x; f[4 * i + 1] = t.y; f[4 * i + 2] = t.z; f[4 * i + 3] = t.w;
         }
     };
 
-    float qf[32];
+    float qf[16];
     load_tile(q0, 0, qf);
     float m = -INFINITY, l = 0.0f;   // running max (base-2 domain) and sum of this lane's query
-    f32x16 o0, o1;
+    f32x4 o[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o0[i] = 0.0f; o1[i] = 0.0f; }
+    for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int j0 = 0; j0 < L; j0 += 32) {
-        float kf[32];
+    for (int j0 = 0; j0 < L; j0 += 16) {
+        float kf[16];
         load_tile(j0, hid * 4, kf);
-        f32x16 s;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = 0.0f;
+        for (int i = 0; i < 16; ++i) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[i], s, 0, 0, 0);
+        // s[g] = <q_{q0+r}, k_j>, j = j0 + 4 kg + g
+        float v[4][4];   // [dim tile][step]
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kk], qf[kk], s, 0, 0, 0);
-        // s[g] = <q_{q0+r}, k_j>, j = j0 + 8(g/4) + 4 half + g%4.  V in the matching layout: row = dim r (and 32 + r)
-        float v0[16], v1[16];
+        for (int i = 0; i < 4; ++i) {
+            const int so = (j0 + i) * ldb + 2 * hid * 4;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int so = (j0 + 8 * (g >> 2) + (g & 3)) * ldb + 2 * hid * 4;
-            v0[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_v, so, 0));
-            v1[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_v + 128, so, 0));
+            for (int t = 0; t < 4; ++t) v[t][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_v + 64 * t, so, 0));
         }
-        if (j0 + 32 > L) {   // last, partial tile: keys past the sequence (read as zeros) drop out
+        if (j0 + 16 > L) {   // last, partial tile: keys past the sequence (read as zeros) drop out
 #pragma unroll
-            for (int g = 0; g < 16; ++g)
-                if (j0 + 8 * (g >> 2) + (g & 3) + 4 * half >= L) s[g] = -INFINITY;
+            for (int g = 0; g < 4; ++g)
+                if (j0 + 4 * kg + g >= L) s[g] = -INFINITY;
         }
-        float mx = s[0];
-#pragma unroll
-        for (int g = 1; g < 16; ++g) mx = fmaxf(mx, s[g]);
+        float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(m, mx * a.scale_log2e);   // finite: key j0 < L is in this tile
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);   // first tile: exp2(-inf) = 0
         float psum = 0.0f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            // one rounding: the error of mnew itself is common to the whole row and cancels in p / sum(p)
+        for (int g = 0; g < 4; ++g) {
             s[g] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[g], a.scale_log2e, -mnew));
             psum += s[g];
         }
+        psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
         l = l * alpha + psum;
         m = mnew;
         if (j0 > 0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            for (int t = 0; t < 4; ++t) o[t] *= alpha;
         }
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[g], s[g], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[g], s[g], o1, 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t][i], s[i], o[t], 0, 0, 0);
     }
-    // O^T (lane = query, registers = dims) -> rows through the LDS slice -> whole 256-B rows out
+    // o[t][g] = O[query r][16 t + 4 kg + g] -> rows through the LDS slice -> whole 256-B rows out
     const float inv = 1.0f / l;
-    float* const ow = my + r * ATT_LDT + 4 * half;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        *reinterpret_cast<float4*>(ow + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-        *reinterpret_cast<float4*>(ow + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-    }
-    float* const op = a.out + (size_t)(tok0 + q0) * a.ldo + h * 64 + ld_c4 * 4;
+    for (int t = 0; t < 4; ++t)
+        *reinterpret_cast<float4*>(my + r * ATT_LDT + 16 * t + 4 * kg) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+    float* const op = a.out + (size_t)(tok0 + q0) * a.ldo + h * 64 + r * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + ld_row;
-        const float4 t = *reinterpret_cast<const float4*>(my + row * ATT_LDT + ld_c4 * 4);
-        if (q0 + row < L) *reinterpret_cast<float4*>(op + (size_t)row * a.ldo) = t;
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * i + kg;
+        const float4 t4 = *reinterpret_cast<const float4*>(my + row * ATT_LDT + r * 4);
+        if (q0 + row < L) *reinterpret_cast<float4*>(op + (size_t)row * a.ldo) = t4;
     }
 }
 
@@ -240,17 +234,17 @@ using namespace fz;
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* blocks, int n_blocks, int H, int head_dim, float scale,
+extern "C" int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
                                   float* out, int ldo, void* stream) {
-    if (n_blocks < 0 || H <= 0 || !(scale > 0.0f)) return FZ_ERR_ARG;
-    if (n_blocks == 0) return FZ_OK;
-    if (!qkv || !blocks || !out) return FZ_ERR_ARG;
+    if (n_strips < 0 || H <= 0 || !(scale > 0.0f)) return FZ_ERR_ARG;
+    if (n_strips == 0) return FZ_OK;
+    if (!qkv || !strips || !out) return FZ_ERR_ARG;
     if (head_dim != 64) return FZ_ERR_UNSUPPORTED;
     if (ld < 3 * H * 64 || ldo < H * 64) return FZ_ERR_ARG;
-    if ((ld & 3) || (ldo & 3) || !aligned16(qkv) || !aligned16(out) || !aligned16(blocks)) return FZ_ERR_UNSUPPORTED;
+    if ((ld & 3) || (ldo & 3) || !aligned16(qkv) || !aligned16(out) || !aligned16(strips)) return FZ_ERR_UNSUPPORTED;
     if ((long long)ld * 4 * 16384 > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;   // in-sequence byte offsets are 32-bit
-    AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(blocks), n_blocks, H, out, ldo, scale * 1.4426950408889634f};
-    const long long grid = (long long)n_blocks * ((H + 1) / 2);
+    AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(strips), n_strips, H, out, ldo, scale * 1.4426950408889634f};
+    const long long grid = (long long)((n_strips + 3) / 4) * H;
     if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
     attn_varlen_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
     FZ_LAUNCH_CHECK();

@@ -184,12 +184,12 @@ int fz_gold_ranks_f32(const float* const* T_h, const int32_t* pos, const float* 
 
 /* ---- encoder side: the per-sequence parts of SentenceTransformer.encode (hybrid.py:97-102) on PACKED token rows -- */
 /* Self-attention of a BERT/CamemBERT layer for ragged sequences without padding: for every sequence and head,
- * out = softmax(q k^T * scale) v in fp32 (MFMA products, online softmax over 32-key tiles), scale > 0.  qkv [T][ld] = fused
- * projection rows (q | k | v, each H*head_dim wide); blocks [n_blocks][4] int32 (device): (first row of the
- * sequence, its length, first query row of this block of <= 64 queries, 0) -- one entry per 64 queries of every sequence,
- * any order (longest sequences first balances best).  head_dim must be 64; sequence length <= 16384.
+ * out = softmax(q k^T * scale) v in fp32 (MFMA products, online softmax over 16-key tiles), scale > 0.  qkv [T][ld] = fused
+ * projection rows (q | k | v, each H*head_dim wide); strips [n_strips][4] int32 (device): (first row of the sequence, its
+ * length, first query row of this strip of <= 16 queries, 0) -- one entry per 16 queries of every sequence, the strips of a
+ * sequence adjacent, sequences in any order (longest first balances best).  head_dim must be 64; sequence length <= 16384.
  * out [T][ldo], H*head_dim wide. */
-int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* blocks, int n_blocks, int H, int head_dim, float scale,
+int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
                        float* out, int ldo, void* stream);
 /* out = LayerNorm(x + res) * gamma + beta over the last dimension d (biased variance, as torch.nn.LayerNorm);
  * res nullable.  d % 4 == 0, d <= 4096. */
