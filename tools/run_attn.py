@@ -2,7 +2,9 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from fusion_amd import ops
+from fusion_amd import _lib, ops
+if os.environ.get("FZ_LIB"):          # ablation builds (tools/ablate)
+    _lib.LIB_PATH = os.path.abspath(os.environ["FZ_LIB"])
 
 Q = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
