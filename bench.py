@@ -263,13 +263,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # one process per GPU; LOCAL_RANK beyond the visible devices only happens when the N > 1 flow is rehearsed on a
+    # smaller box (FUSION_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device)
+    local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("FUSION_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.workload == "mmarco":
         from fusion_amd import distributed as fd
