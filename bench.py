@@ -252,8 +252,15 @@ def cpu_baseline_lleqa(st, S_dev, B_dev, budget_s=20.0):
     t, _ = run(qs)
     q = int(min(64, max(qs, qs * min(8.0, (budget_s / 2) / max(t, 1e-3)))))
     t, out = run(q)
-    return dict(value=q / t, unit="queries/s", cores=oracle.num_threads(), kind="port",
-                sample=f"first {q} queries of the batch, score+rank+fuse+order only (no encoder forward), N={N}, d={d}, OpenMP"), out, q
+    cores = oracle.num_threads()
+    oracle.set_threads(1)                      # single-thread figure next to the all-core one (2 queries: a few seconds)
+    try:
+        t1, _ = run(2)
+    finally:
+        oracle.set_threads(cores)
+    return dict(value=q / t, unit="queries/s", cores=cores, kind="port",
+                sample=f"first {q} queries of the batch, score+rank+fuse+order only (no encoder forward), N={N}, d={d}, OpenMP",
+                single_thread_value=2 / t1), out, q
 
 
 def main():

@@ -15,6 +15,29 @@ namespace fz {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// Reductions across the four 16-lane groups of a wave on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap) instead of
+// two ds_bpermute round trips through the LDS pipe: every lane ends up with the result of its column.
+//   permlane16_swap(d, s) -> d = [d0 s0 d2 s2], s = [d1 s1 d3 s3] by 16-lane rows; permlane32_swap(d, s) -> d = [d.lo s.lo],
+//   s = [d.hi s.hi] (probed: tools/micro/permlane_probe.hip).  Written as asm: through the builtin, hipcc (ROCm 7.2) treats
+//   the two results of swap(x, x) as one value and drops the second.  s_nop 1: the VALU-write -> permlane-read hazard the
+//   compiler would otherwise cover itself.
+__device__ __forceinline__ void swap16(float& d, float& s) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(d), "+v"(s)); }
+__device__ __forceinline__ void swap32(float& d, float& s) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(d), "+v"(s)); }
+__device__ __forceinline__ float xgroup_max(float x) {
+    float y = x;
+    swap16(x, y);
+    x = y = fmaxf(x, y);
+    swap32(x, y);
+    return fmaxf(x, y);
+}
+__device__ __forceinline__ float xgroup_sum(float x) {
+    float y = x;
+    swap16(x, y);
+    x = y = x + y;
+    swap32(x, y);
+    return x + y;
+}
+
 struct AttnArgs {
     const float* qkv;   // [T][ld]: q | k | v, each H*64 wide
     int ld;
@@ -110,8 +133,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                 if (j0 + 4 * kg + g >= L) s[g] = -INFINITY;
         }
         float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xgroup_max(mx);
         const float mnew = fmaxf(m, mx * a.scale_log2e);   // finite: key j0 < L is in this tile
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);   // first tile: exp2(-inf) = 0
         float psum = 0.0f;
@@ -120,8 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             s[g] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[g], a.scale_log2e, -mnew));
             psum += s[g];
         }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
+        psum = xgroup_sum(psum);
         l = l * alpha + psum;
         m = mnew;
         if (j0 > 0) {
