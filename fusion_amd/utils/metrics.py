@@ -77,37 +77,49 @@ def metrics_from_gold_ranks(ranks: np.ndarray, n_gold: np.ndarray, list_len: np.
     """All metrics of run_evaluation (hybrid.py:24-42) from the 0-based ranks of the gold documents.
     ranks [W, Q, G] int64 (np.iinfo(int64).max = never retrieved), n_gold [Q] = len(ground_truths) as the reference
     divides by it, list_len [Q] = length of the fused list.  Same per-query formulas and summation order as
-    metrics.py:72-136; means over queries use an exactly rounded sum (statistics.mean differs by <= 1 ulp)."""
-    import math
+    metrics.py:72-136; means over queries use an exactly rounded sum (statistics.mean differs by <= 1 ulp).
+    Everything is laid out [gold, query, weight vector] so that every slice below is contiguous (W = 1771 in the 4-system
+    sweep: this function, not the counting kernel, would otherwise dominate the sweep)."""
     W, Q, G = ranks.shape
     INF = np.iinfo(np.int64).max
-    r = np.sort(ranks, axis=2)                                   # ascending gold ranks per (w, q)
+    r = np.ascontiguousarray(np.sort(ranks, axis=2).transpose(2, 1, 0))   # [G, Q, W], ascending gold ranks per (q, w)
     have = r < INF
-    ng = np.maximum(n_gold, 1).astype(np.float64)[None, :]
-    disc = np.where(r == 0, 1.0, 1.0 / np.log2(np.where(have & (r >= 1), r, 1).astype(np.float64) + 1.0))   # metrics.py:108
-    idcg = np.array([1 + sum(1 / np.log2(i + 1) for i in range(1, int(n))) if n > 0 else 1.0 for n in n_gold], dtype=np.float64)[None, :]
-    per_query: dict[str, np.ndarray] = {}
+    ng = np.maximum(n_gold, 1).astype(np.float64)[:, None]                # [Q, 1]
+    top = int(max(NDCG_KS))                                               # only ranks below the largest cut-off are ever discounted
+    table = np.ones(top + 1)
+    table[1:] = 1.0 / np.log2(np.arange(1, top + 1, dtype=np.float64) + 1.0)   # metrics.py:108: 1/log2(i+1) from position 1
+    idcg = np.array([1 + sum(1 / np.log2(i + 1) for i in range(1, int(n))) if n > 0 else 1.0 for n in n_gold], dtype=np.float64)[:, None]
+    per_query: dict[str, np.ndarray] = {}                                 # each [Q, W]
     for k in RECALL_KS:
-        per_query[f"recall@{k}"] = (have & (r < k)).sum(2) / ng
+        per_query[f"recall@{k}"] = (r < k).sum(0) / ng                    # r < k implies retrieved
     for k in MAP_KS:
-        ap = np.zeros((W, Q))
-        for i in range(G):                                       # i-th gold hit sits at rank r[..., i]: precision = (i+1)/(rank+1)
-            ok = have[:, :, i] & (r[:, :, i] < k)
-            ap = ap + np.where(ok, (i + 1) / (np.where(ok, r[:, :, i], 0).astype(np.float64) + 1.0), 0.0)
+        ap = np.zeros((Q, W))
+        for i in range(G):                                                # i-th gold hit sits at rank r[i]: precision = (i+1)/(rank+1)
+            ok = r[i] < k
+            ap = ap + np.where(ok, (i + 1) / (np.where(ok, r[i], 0).astype(np.float64) + 1.0), 0.0)
         per_query[f"map@{k}"] = ap / ng
     for k in MRR_KS:
-        first = r[:, :, 0]
-        ok = have[:, :, 0] & (first < k)
-        per_query[f"mrr@{k}"] = np.where(ok, 1.0 / (np.where(ok, first, 0).astype(np.float64) + 1.0), 0.0)
+        ok = r[0] < k
+        per_query[f"mrr@{k}"] = np.where(ok, 1.0 / (np.where(ok, r[0], 0).astype(np.float64) + 1.0), 0.0)
     for k in NDCG_KS:
-        head = np.where(have & (r == 0), 1.0, 0.0).sum(2)         # relevances[0]
-        tail = np.zeros((W, Q))
-        for i in range(G):                                       # sum(...) for positions >= 1, in rank order
-            ok = have[:, :, i] & (r[:, :, i] >= 1) & (r[:, :, i] < k)
-            tail = tail + np.where(ok, disc[:, :, i], 0.0)
+        head = (r == 0).sum(0).astype(np.float64)                         # relevances[0]
+        tail = np.zeros((Q, W))
+        for i in range(G):                                                # sum(...) for positions >= 1, in rank order
+            ok = (r[i] >= 1) & (r[i] < k)
+            tail = tail + np.where(ok, table[np.minimum(r[i], top)], 0.0)
         per_query[f"ndcg@{k}"] = (head + tail) / idcg
-    per_query["r-precision"] = (have & (r < n_gold[None, :, None])).sum(2) / ng
-    out = []
-    for w in range(W):
-        out.append({name: math.fsum(v[w].tolist()) / Q for name, v in per_query.items()})
-    return out
+    per_query["r-precision"] = (r < n_gold[None, :, None]).sum(0) / ng
+    # mean over the queries with an exactly rounded sum, all (metric, weight vector) pairs at once: error-free TwoSum
+    # accumulation (hi + lo carries the sum to ~106 bits; all terms are >= 0), one rounding at the end -- what
+    # math.fsum(row) / Q gives, without 15 * W Python-level calls
+    names = list(per_query)
+    hi = np.zeros((len(names), W))
+    lo = np.zeros((len(names), W))
+    for q in range(Q):
+        x = np.stack([per_query[n][q] for n in names])
+        t = hi + x
+        bb = t - hi
+        lo += (hi - (t - bb)) + (x - bb)
+        hi = t
+    means = (hi + lo) / Q
+    return [{n: float(means[i, w]) for i, n in enumerate(names)} for w in range(W)]
