@@ -541,7 +541,7 @@ extern "C" int fz_topk_rows_f32(const float* scores, int rows, int n, int ld, in
     const float* cur_keys = scores;
     const int32_t* cur_cols = nullptr;
     long cur_stride = ld;
-    int cur = n, level = 0;
+    int cur = n;
     char* ws = reinterpret_cast<char*>(workspace);
     while (cur > 35840) {
         const int per = TOPK_CHUNK;
@@ -561,7 +561,7 @@ extern "C" int fz_topk_rows_f32(const float* scores, int rows, int n, int ld, in
         a.colmap = cur_cols; a.colmap_row_stride = cur_stride;
         int rc = launch_sort(a, 1, rows * nch, per, st);
         if (rc != FZ_OK) return rc;
-        cur_keys = nk; cur_cols = nc; cur_stride = next; cur = next; ++level;
+        cur_keys = nk; cur_cols = nc; cur_stride = next; cur = next;
     }
     SortArgs a{};
     a.keys = cur_keys; a.n_total = cur; a.key_row_stride = cur_stride; a.seg_len = cur; a.chunks = 1; a.chunk_len = cur;
