@@ -57,6 +57,27 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
     return v;
 }
 
+// ---- VALU-only cross-lane steps (no ds_bpermute round trip through the LDS pipe) ------------------------------
+// DPP controls: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_mirror = 0x140, row_half_mirror = 0x141.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over each 16-lane row; every lane of the row ends up with it
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);   // quads are uniform: mirroring a half row brings the other quad's sum
+    v += dpp_f32<0x140>(v);   // half rows are uniform: mirroring the row brings the other half's sum
+    return v;
+}
+// gfx950 v_permlane16_swap / v_permlane32_swap: swap16(d, s) -> d = [d0 s0 d2 s2], s = [d1 s1 d3 s3] by 16-lane rows;
+// swap32(d, s) -> d = [d.lo s.lo], s = [d.hi s.hi] (probed: tools/micro/permlane_probe.hip).  Written as asm: through
+// the builtin, hipcc (ROCm 7.2) treats the two results of swap(x, x) as one value and drops the second.  The s_nops cover
+// the VALU-write -> permlane-read and permlane-write -> VALU-read hazards the compiler would otherwise handle itself.
+__device__ __forceinline__ void swap16(float& d, float& s) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(d), "+v"(s)); }
+__device__ __forceinline__ void swap32(float& d, float& s) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(d), "+v"(s)); }
+
 // order-preserving bit transforms: larger float  <=>  SMALLER unsigned key (descending sort
 // becomes an ascending LSD radix sort).  -0.0 == +0.0; every NaN maps to key 0 (sorts first).
 __device__ __forceinline__ uint32_t desc_key_f32(float f) {

@@ -15,14 +15,8 @@ namespace fz {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// Reductions across the four 16-lane groups of a wave on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap) instead of
-// two ds_bpermute round trips through the LDS pipe: every lane ends up with the result of its column.
-//   permlane16_swap(d, s) -> d = [d0 s0 d2 s2], s = [d1 s1 d3 s3] by 16-lane rows; permlane32_swap(d, s) -> d = [d.lo s.lo],
-//   s = [d.hi s.hi] (probed: tools/micro/permlane_probe.hip).  Written as asm: through the builtin, hipcc (ROCm 7.2) treats
-//   the two results of swap(x, x) as one value and drops the second.  s_nop 1: the VALU-write -> permlane-read hazard the
-//   compiler would otherwise cover itself.
-__device__ __forceinline__ void swap16(float& d, float& s) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(d), "+v"(s)); }
-__device__ __forceinline__ void swap32(float& d, float& s) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(d), "+v"(s)); }
+// Reductions across the four 16-lane groups of a wave on the VALU (common.h: swap16 / swap32) instead of two ds_bpermute
+// round trips through the LDS pipe: every lane ends up with the result of its column.
 __device__ __forceinline__ float xgroup_max(float x) {
     float y = x;
     swap16(x, y);

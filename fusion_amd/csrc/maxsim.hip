@@ -201,10 +201,15 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
             float sums[MS_BLOCKS_PER_WAVE];
 #pragma unroll
             for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) {
-                float m = fmaxf(run[b], __shfl_xor(run[b], 32, 64));   // both halves now hold the column max
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);   // sum over the 32 columns
-                sums[b] = m;
+                // all on the VALU (DPP + permlane swaps): the ds_bpermute form put six LDS round trips per block on the
+                // critical path of every document
+                float m = run[b], other = m;
+                swap32(m, other);                 // m = [lo, lo], other = [hi, hi]
+                m = fmaxf(m, other);              // both halves now hold the column max
+                m = row16_sum(m);                 // per 16 columns
+                other = m;
+                swap16(m, other);                 // rows (0,1) and (2,3) paired
+                sums[b] = m + other;              // sum over the 32 columns, in every lane
                 run[b] = -INFINITY;
             }
             write_scores(d_begin + (meta & 0xff), sums);
