@@ -1,40 +1,66 @@
 #!/bin/bash
-# Sweep driver with the reference's positional interface (scripts/run_hybrid.sh:3-19 in the reference):
+# Sweep driver behind the reference's positional interface (its scripts/run_hybrid.sh:3-19):
+#
 #   bash scripts/run_hybrid.sh <dev|test> <general|legal> [--tune_linear_fusion_weight|--analyze_score_distributions]
-# 11 retriever combinations x {nsf x normalisers, bcf, rrf}, one hybrid.py process each.
-# Documented deviations: the third argument may be empty (the reference's README says optional, its
-# script rejects it); the normaliser list is reset for every combination (the reference clobbers it after the first).
-# DRY_RUN=1 prints the commands instead of running them.  Extra flags for the python driver: HYBRID_EXTRA="--synthetic 3000,16".
+#
+# Every retriever subset of size >= 2 (11 of them, pairs first, in the reference's order) is fused three ways --
+# nsf under each normaliser, then bcf and rrf without one -- with one hybrid.py process per run.
+# Deviations, on purpose: the third argument may be left out (the reference's README calls it optional,
+# its script refuses that), and nsf sweeps all its normalisers for EVERY subset (the reference loses the list after
+# the first bcf run).
+# Environment: DRY_RUN=1 prints the command lines instead of running them; HYBRID_EXTRA="--synthetic 3000,16" is appended
+# to each of them.
 
-LLEQA_SPLIT=$1
-if [ "$LLEQA_SPLIT" != "test" ] && [ "$LLEQA_SPLIT" != "dev" ]; then
-    echo "ERROR: First argument corresponds to the LLeQA data split, and must be either 'test' or 'dev'."
+usage_error() {
+    echo "ERROR: $1"
     exit 1
-fi
-TRAINING_DOMAIN=$2
-if [ "$TRAINING_DOMAIN" != "general" ] && [ "$TRAINING_DOMAIN" != "legal" ]; then
-    echo "ERROR: Second argument corresponds to the training domain of the neural retrievers, and must be either 'general' or 'legal'."
-    exit 1
-fi
-EXPERIMENT_NAME=$3
-if [ -n "$EXPERIMENT_NAME" ] && [ "$EXPERIMENT_NAME" != "--tune_linear_fusion_weight" ] && [ "$EXPERIMENT_NAME" != "--analyze_score_distributions" ]; then
-    echo "ERROR: Third argument corresponds to the experiment name, and must be either empty or one of '--tune_linear_fusion_weight' '--analyze_score_distributions'."
-    exit 1
-fi
+}
 
-HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-COMBOS=(
-    "--run_bm25 --run_splade" "--run_bm25 --run_dpr" "--run_bm25 --run_colbert"
-    "--run_splade --run_dpr" "--run_splade --run_colbert" "--run_dpr --run_colbert"
-    "--run_bm25 --run_splade --run_dpr" "--run_bm25 --run_splade --run_colbert" "--run_bm25 --run_dpr --run_colbert"
-    "--run_splade --run_dpr --run_colbert" "--run_bm25 --run_splade --run_dpr --run_colbert"
-)
-for R in "${COMBOS[@]}"; do
-    for F in nsf bcf rrf; do
-        if [ "$F" == "nsf" ]; then NORMS=("min-max" "z-score" "percentile-rank"); else NORMS=("none"); fi
-        for N in "${NORMS[@]}"; do
-            CMD="python $HERE/src/retrievers/hybrid.py --data_split $LLEQA_SPLIT --models_domain $TRAINING_DOMAIN $R --fusion $F --normalization $N $EXPERIMENT_NAME --output_dir output/testing $HYBRID_EXTRA"
-            if [ -n "$DRY_RUN" ]; then echo "$CMD"; else $CMD || exit $?; fi
+split=$1
+domain=$2
+experiment=$3
+
+case "$split" in
+    dev|test) ;;
+    *) usage_error "argument 1 is the LLeQA split: 'dev' or 'test' (got '${split}')." ;;
+esac
+case "$domain" in
+    general|legal) ;;
+    *) usage_error "argument 2 is the domain the neural retrievers were trained on: 'general' or 'legal' (got '${domain}')." ;;
+esac
+case "$experiment" in
+    ""|--tune_linear_fusion_weight|--analyze_score_distributions) ;;
+    *) usage_error "argument 3, if given, selects the experiment: '--tune_linear_fusion_weight' or '--analyze_score_distributions' (got '${experiment}')." ;;
+esac
+
+root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+systems=(bm25 splade dpr colbert)
+
+# subsets of the four systems by size (2, 3, 4), members in list order: the enumeration the reference spells out by hand
+subsets=()
+for size in 2 3 4; do
+    for mask in 3 5 9 6 10 12 7 11 13 14 15; do
+        members=""; count=0
+        for i in 0 1 2 3; do
+            if (( (mask >> i) & 1 )); then members+=" --run_${systems[$i]}"; count=$((count + 1)); fi
         done
+        if (( count == size )); then subsets+=("${members# }"); fi
     done
+done
+
+launch() {
+    local cmd="python $root/src/retrievers/hybrid.py --data_split $split --models_domain $domain $1 --fusion $2 --normalization $3 $experiment --output_dir output/testing $HYBRID_EXTRA"
+    if [ -n "$DRY_RUN" ]; then
+        echo "$cmd"
+    else
+        $cmd || exit $?
+    fi
+}
+
+for flags in "${subsets[@]}"; do
+    for norm in min-max z-score percentile-rank; do
+        launch "$flags" nsf "$norm"
+    done
+    launch "$flags" bcf none
+    launch "$flags" rrf none
 done
