@@ -35,7 +35,7 @@ __device__ __forceinline__ float xgroup_sum(float x) {
 struct AttnArgs {
     const float* qkv;   // [T][ld]: q | k | v, each H*64 wide
     int ld;
-    const int4* strips;  // (first row of the sequence, its length L, first query of this strip of <= 16 queries, unused)
+    const int4* strips;  // (first row of the sequence, its length L, first query of this strip of <= 16 * FZ_ATTN_NQ queries, unused)
     int n_strips;
     int H;
     float* out;  // [T][ldo]
@@ -43,9 +43,10 @@ struct AttnArgs {
     float scale_log2e;   // scale * log2(e): softmax runs in the base-2 domain
 };
 
+#define FZ_ATTN_NQ 2   // 16-query sub-strips per wave; the strip table is cut every 16 * FZ_ATTN_NQ queries
 #define ATT_LDT 68   // LDS row stride in floats: 64 + 4 -> the 16 lanes of one ds_read_b128 phase hit 64 distinct banks
 
-// One wave = one (16-query strip, head); the four waves of a workgroup take four consecutive strips of the table for ONE
+// One wave = one (32-query strip = two 16-query sub-strips, head); the four waves of a workgroup take four consecutive strips of the table for ONE
 // head -- consecutive strips mostly belong to one sequence, so its waves read the same K/V rows (L1 hits) -- and every wave
 // is live whatever the sequence lengths.  No barriers: each wave turns its tiles through its own LDS slice.
 //
@@ -60,11 +61,14 @@ struct AttnArgs {
 //     buffer loads whose range ends with the sequence: the rows a partial tile reaches past it read 0 without touching
 //     memory (unchecked, 32-row tiles moved 1.4x the algorithmic bytes at the LLeQA length mix);
 //   * v_mfma_f32_16x16x4_f32 rather than 32x32x2: tiles cut at 16 waste 24 % fewer MFMA cycles on padding at that mix,
-//     and a wave needs 72 VGPRs instead of 128 -> 7 waves per SIMD hide each other's load -> LDS -> MFMA -> softmax chain.
+//     and a wave needs 72 VGPRs per 16 queries instead of 128 per 32.
 // Layouts (16x16x4): A lane l -> row l%16, k-slot l/16; B lane l -> col l%16, k-slot l/16; C reg r -> row 4(l/16)+r, col l%16.
 //   S^T step i pairs dim 16*(l/16) + i of key row l%16 with the same dim of query l%16;
 //   O^T step i takes register i of S^T (key 4(l/16) + i of the tile) against V[that key][16 t + l%16].
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void attn_varlen_kernel(AttnArgs a) {
+// NQ = 16-query sub-strips per wave.  NQ = 2: every K/V tile a wave loads serves 32 queries -- half the re-reads of the
+// sequence's K/V rows through the load path (the kernel's bound, see above) for 112 instead of 72 VGPRs.
+template <int NQ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7 : 4, 8))) void attn_varlen_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 16 * ATT_LDT];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int grp = blockIdx.x / a.H;
@@ -100,20 +104,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         }
     };
 
-    float qf[16];
-    load_tile(q0, 0, qf);
-    float m = -INFINITY, l = 0.0f;   // running max (base-2 domain) and sum of this lane's query
-    f32x4 o[4];
+    const bool second = NQ == 2 && q0 + 16 < L;   // wave-uniform: the strip's second 16 queries exist
+    float qf[NQ][16];
+    float m[NQ], l[NQ];   // running max (base-2 domain) and sum of this lane's query
+    f32x4 o[NQ][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NQ; ++u) {
+        if (u == 0 || second) load_tile(q0 + 16 * u, 0, qf[u]);
+        m[u] = -INFINITY; l[u] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int j0 = 0; j0 < L; j0 += 16) {
         float kf[16];
         load_tile(j0, hid * 4, kf);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[i], s, 0, 0, 0);
-        // s[g] = <q_{q0+r}, k_j>, j = j0 + 4 kg + g
         float v[4][4];   // [dim tile][step]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -121,44 +126,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[t][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_v + 64 * t, so, 0));
         }
-        if (j0 + 16 > L) {   // last, partial tile: keys past the sequence (read as zeros) drop out
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (j0 + 4 * kg + g >= L) s[g] = -INFINITY;
+        for (int u = 0; u < NQ; ++u) {
+            if (u == 1 && !second) break;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[u][i], s, 0, 0, 0);
+            // s[g] = <q_{q0+16u+r}, k_j>, j = j0 + 4 kg + g
+            if (j0 + 16 > L) {   // last, partial tile: keys past the sequence (read as zeros) drop out
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (j0 + 4 * kg + g >= L) s[g] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            mx = xgroup_max(mx);
+            const float mnew = fmaxf(m[u], mx * a.scale_log2e);   // finite: key j0 < L is in this tile
+            const float alpha = __builtin_amdgcn_exp2f(m[u] - mnew);   // first tile: exp2(-inf) = 0
+            float psum = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                s[g] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[g], a.scale_log2e, -mnew));
+                psum += s[g];
+            }
+            psum = xgroup_sum(psum);
+            l[u] = l[u] * alpha + psum;
+            m[u] = mnew;
+            if (j0 > 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[u][t] *= alpha;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t][i], s[i], o[u][t], 0, 0, 0);
         }
-        float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-        mx = xgroup_max(mx);
-        const float mnew = fmaxf(m, mx * a.scale_log2e);   // finite: key j0 < L is in this tile
-        const float alpha = __builtin_amdgcn_exp2f(m - mnew);   // first tile: exp2(-inf) = 0
-        float psum = 0.0f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            s[g] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[g], a.scale_log2e, -mnew));
-            psum += s[g];
-        }
-        psum = xgroup_sum(psum);
-        l = l * alpha + psum;
-        m = mnew;
-        if (j0 > 0) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) o[t] *= alpha;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t][i], s[i], o[t], 0, 0, 0);
     }
-    // o[t][g] = O[query r][16 t + 4 kg + g] -> rows through the LDS slice -> whole 256-B rows out
-    const float inv = 1.0f / l;
+    // o[u][t][g] = O[query 16 u + r][16 t + 4 kg + g] -> rows through the LDS slice -> whole 256-B rows out
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-        *reinterpret_cast<float4*>(my + r * ATT_LDT + 16 * t + 4 * kg) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
-    float* const op = a.out + (size_t)(tok0 + q0) * a.ldo + h * 64 + r * 4;
+    for (int u = 0; u < NQ; ++u) {
+        if (u == 1 && !second) break;
+        const float inv = 1.0f / l[u];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 4 * i + kg;
-        const float4 t4 = *reinterpret_cast<const float4*>(my + row * ATT_LDT + r * 4);
-        if (q0 + row < L) *reinterpret_cast<float4*>(op + (size_t)row * a.ldo) = t4;
+        for (int t = 0; t < 4; ++t)
+            *reinterpret_cast<float4*>(my + r * ATT_LDT + 16 * t + 4 * kg) =
+                make_float4(o[u][t][0] * inv, o[u][t][1] * inv, o[u][t][2] * inv, o[u][t][3] * inv);
+        float* const op = a.out + (size_t)(tok0 + q0 + 16 * u) * a.ldo + h * 64 + r * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * i + kg;
+            const float4 t4 = *reinterpret_cast<const float4*>(my + row * ATT_LDT + r * 4);
+            if (q0 + 16 * u + row < L) *reinterpret_cast<float4*>(op + (size_t)row * a.ldo) = t4;
+        }
     }
 }
 
@@ -261,7 +279,7 @@ extern "C" int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strip
     AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(strips), n_strips, H, out, ldo, scale * 1.4426950408889634f};
     const long long grid = (long long)((n_strips + 3) / 4) * H;
     if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
-    attn_varlen_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
+    attn_varlen_kernel<FZ_ATTN_NQ><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

@@ -499,19 +499,19 @@ def f64_to_f32(src: torch.Tensor) -> torch.Tensor:
 # encoder side: packed (padding-free) token rows
 # ---------------------------------------------------------------------------------------
 def attn_strips(lengths, cu_rows=None):
-    """HOST helper: the strip table fz_attn_varlen_f32 walks -- one (first row, length, first query, 0) entry per 16 queries
+    """HOST helper: the strip table fz_attn_varlen_f32 walks -- one (first row, length, first query, 0) entry per 32 queries
     of every sequence, longest sequences first.  Returns (strips int32 [n_strips, 4] numpy, cu_rows int32 [B+1] numpy)."""
     import numpy as np
     lengths = np.asarray(lengths, dtype=np.int64)
     if cu_rows is None:
         cu_rows = np.zeros(len(lengths) + 1, dtype=np.int64)
         np.cumsum(lengths, out=cu_rows[1:])
-    per = (lengths + 15) // 16
+    per = (lengths + 31) // 32
     order = np.argsort(-lengths, kind="stable")
     seq = np.repeat(order, per[order])
     first = np.zeros(len(order) + 1, dtype=np.int64)
     np.cumsum(per[order], out=first[1:])
-    q0 = (np.arange(len(seq)) - np.repeat(first[:-1], per[order])) * 16
+    q0 = (np.arange(len(seq)) - np.repeat(first[:-1], per[order])) * 32
     strips = np.stack([cu_rows[seq], lengths[seq], q0, np.zeros_like(q0)], 1).astype(np.int32)
     return np.ascontiguousarray(strips), cu_rows.astype(np.int32)
 

@@ -186,7 +186,7 @@ int fz_gold_ranks_f32(const float* const* T_h, const int32_t* pos, const float* 
 /* Self-attention of a BERT/CamemBERT layer for ragged sequences without padding: for every sequence and head,
  * out = softmax(q k^T * scale) v in fp32 (MFMA products, online softmax over 16-key tiles), scale > 0.  qkv [T][ld] = fused
  * projection rows (q | k | v, each H*head_dim wide); strips [n_strips][4] int32 (device): (first row of the sequence, its
- * length, first query row of this strip of <= 16 queries, 0) -- one entry per 16 queries of every sequence, the strips of a
+ * length, first query row of this strip of <= 32 queries, 0) -- one entry per 32 queries of every sequence, the strips of a
  * sequence adjacent, sequences in any order (longest first balances best).  head_dim must be 64; sequence length <= 16384.
  * out [T][ldo], H*head_dim wide. */
 int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
