@@ -793,3 +793,33 @@ def test_ops_reject_mismatched_shapes_before_launch(ops):
         ops.topk_merge(z(2, 3, 5), torch.zeros((2, 3, 4), dtype=torch.int64, device="cuda"))
     with pytest.raises(ValueError):
         ops.dot_scores(z(3, 8), z(5, 8), out=z(3, 6))
+
+
+def test_full_size_encoder_kernels(ops):
+    """The encoder-side kernels at the bench's shape (1024 queries, 12 heads, ~37 k packed rows): attention against a float64
+    torch reference on a sample of sequences (1e-5 relative to the largest output), residual+LayerNorm and mean pooling against
+    torch on every row."""
+    rng = np.random.default_rng(11)
+    lens = rng.integers(8, 65, 1024)
+    T, H = int(lens.sum()), 12
+    g = torch.Generator(device="cuda").manual_seed(11)
+    qkv = torch.randn((T, 3 * H * 64), generator=g, device="cuda") * 1.2
+    strips, cu = ops.attn_strips(lens)
+    out = ops.attn_varlen(qkv, torch.from_numpy(strips).cuda(), H)
+    assert torch.isfinite(out).all()
+    for b in rng.choice(1024, size=40, replace=False).tolist() + [int(np.argmax(lens)), int(np.argmin(lens))]:
+        L = int(lens[b])
+        blk = qkv[cu[b]: cu[b] + L].double().view(L, 3, H, 64)
+        q, k, v = blk[:, 0].transpose(0, 1), blk[:, 1].transpose(0, 1), blk[:, 2].transpose(0, 1)
+        ref = (torch.softmax(q @ k.transpose(1, 2) / 8.0, -1) @ v).transpose(0, 1).reshape(L, H * 64)
+        assert (out[cu[b]: cu[b] + L].double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    x = out
+    res = torch.randn((T, 768), generator=g, device="cuda")
+    gamma, beta = torch.randn(768, generator=g, device="cuda"), torch.randn(768, generator=g, device="cuda")
+    y = ops.add_layernorm(x, res, gamma, beta, 1e-5)
+    ref = torch.nn.functional.layer_norm(x + res, (768,), gamma, beta, 1e-5)
+    assert (y - ref).abs().max().item() <= 2e-5
+    pooled = ops.segment_mean(y, torch.from_numpy(cu).cuda())
+    seg = torch.repeat_interleave(torch.arange(1024, device="cuda"), torch.from_numpy(lens).cuda())
+    ref_p = torch.zeros((1024, 768), device="cuda", dtype=torch.float64).index_add_(0, seg, y.double()) / torch.from_numpy(lens).cuda().double()[:, None]
+    assert (pooled.double() - ref_p).abs().max().item() <= 1e-5
