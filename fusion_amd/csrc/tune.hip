@@ -10,8 +10,8 @@
 // of the materialise-and-sort path.
 //
 // Mapping: grid (column chunks of 4096, queries); 256 threads x 16 columns; the chunk's S x 16 normalised scores and
-// 16 positions stay in registers for the whole sweep; per weight vector: S unfused mul+add per column, G compares,
-// wave reduction, one atomicAdd per wave and gold.
+// 16 positions stay in registers for the whole sweep; per weight vector: S unfused mul+add per column, one 64-bit compare
+// + scalar popcount per (column, gold), one atomicAdd per wave and gold.
 #include "common.h"
 
 namespace fz {
@@ -58,17 +58,25 @@ __global__ __launch_bounds__(256) void gold_ranks_kernel(TuneArgs a) {
         for (int s = 0; s < S; ++s) tg[s][g] = ok ? a.T[s][rowoff + col] : 0.f;
     }
 
+    // "j precedes g" as ONE 64-bit unsigned compare: (desc_key(fused_j), pos_j) < (desc_key(fused_g), pos_g), lexicographic.
+    // desc_key_f32 (common.h) is the sort kernel's order: larger score -> smaller key, -0 == +0, NaN first -- so the count
+    // is exactly the rank the materialise-and-sort path would give, ties by first-insertion position included.
+    // Docs in no list get the largest key (they precede nothing).  The per-(column, gold) work is one v_cmp + a scalar
+    // popcount; the counters live in SGPRs (one atomicAdd per wave and gold at the end, no wave reduction).
+    uint32_t lo[TUNE_COLS];
+#pragma unroll
+    for (int i = 0; i < TUNE_COLS; ++i) lo[i] = (uint32_t)pj[i];
     for (int w = 0; w < a.W; ++w) {
         float wv[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) wv[s] = a.weights[w * S + s];
-        float fg[TUNE_G];
+        uint64_t kg[TUNE_G];
 #pragma unroll
         for (int g = 0; g < TUNE_G; ++g) {
             float acc = 0.f;
 #pragma unroll
             for (int s = 0; s < S; ++s) { const float prod = tg[s][g] * wv[s]; acc = acc + prod; }
-            fg[g] = acc;
+            kg[g] = ((uint64_t)desc_key_f32(acc) << 32) | (uint32_t)pg[g];
         }
         int cnt[TUNE_G];
 #pragma unroll
@@ -78,22 +86,13 @@ __global__ __launch_bounds__(256) void gold_ranks_kernel(TuneArgs a) {
             float f = 0.f;
 #pragma unroll
             for (int s = 0; s < S; ++s) { const float prod = t[s][i] * wv[s]; f = f + prod; }   // hybrid.py:291,304 (NumPy 2: fp32)
-            const bool listed = pj[i] >= 0;
+            const uint64_t kj = pj[i] >= 0 ? (((uint64_t)desc_key_f32(f) << 32) | lo[i]) : ~0ull;
 #pragma unroll
-            for (int g = 0; g < TUNE_G; ++g) {
-                // NaN fused scores sort first in this build: a NaN beats every number
-                const bool fn = f != f, gn = fg[g] != fg[g];
-                const bool beats = (fn && !gn) || (!fn && !gn && f > fg[g]) || (((fn && gn) || f == fg[g]) && pj[i] < pg[g]);
-                cnt[g] += (listed && beats) ? 1 : 0;
-            }
+            for (int g = 0; g < TUNE_G; ++g) cnt[g] += __popcll(__ballot(kj < kg[g]));
         }
 #pragma unroll
-        for (int g = 0; g < TUNE_G; ++g) {
-            int c = cnt[g];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-            if (lane == 0 && c != 0 && pg[g] >= 0) atomicAdd(&a.out[((size_t)w * a.Q + q) * TUNE_G + g], c);
-        }
+        for (int g = 0; g < TUNE_G; ++g)
+            if (lane == 0 && cnt[g] != 0 && pg[g] >= 0) atomicAdd(&a.out[((size_t)w * a.Q + q) * TUNE_G + g], cnt[g]);
     }
 }
 
