@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Randomised soak of the HIP kernels against the CPU oracle / float64 torch: random shapes, lengths, ties, partial lists.
+Test infrastructure (it imports oracle/, and lives under tests/ for that reason; not collected by pytest): run on the GPU box, e.g.  python tests/fuzz_gpu.py --seconds 120 --seed 1
+Every case is bounded in size (host cost of the oracle) and checked with the tolerance the parity tests use."""
+import argparse, os, sys, time, traceback
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fusion_amd import ops
+from oracle import oracle
+
+NSF_TOL = {"min-max": 0.0, "z-score": 2e-6, "arctan": 1e-6, "percentile-rank": 0.0, "normal-curve-equivalent": 1e-4}
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def plane(a):
+    t = ops.alloc_plane(a.shape[0], a.shape[1], torch.from_numpy(a[:0]).dtype, "cuda")
+    t.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+    return t
+
+
+def rand_keys(rng, rows, n, dtype):
+    mode = rng.integers(0, 4)
+    if mode == 0:
+        k = rng.normal(0, 1, (rows, n))
+    elif mode == 1:
+        k = np.round(rng.normal(0, 1, (rows, n)), 1)                 # many ties
+    elif mode == 2:
+        k = np.maximum(0, rng.gamma(0.5, 4.0, (rows, n)) - 2)        # BM25-like: ~40 % exact zeros
+    else:
+        k = rng.integers(-3, 4, (rows, n)).astype(np.float64) * (2.0 ** rng.integers(-30, 30))
+    k = k.astype(dtype)
+    if n > 4 and rng.random() < 0.3:
+        k[rng.integers(0, rows), rng.integers(0, n)] = rng.choice([np.inf, -np.inf, np.nan, -0.0])
+    return k
+
+
+def systems(rng, S, Q, N, partial):
+    planes, ranks, orders, lens = [], [], [], np.zeros((S, Q), dtype=np.int32)
+    for s in range(S):
+        p = rand_keys(rng, Q, N, np.float32)
+        p[~np.isfinite(p)] = 0.0
+        o, _, r = oracle.sort_rows_desc(p, want_rank=True)
+        ln = np.full(Q, N, dtype=np.int32)
+        if partial:
+            ln = rng.integers(0, N + 1, Q).astype(np.int32)
+            for q in range(Q):
+                r[q][r[q] >= ln[q]] = -1
+                o[q, ln[q]:] = -1
+        planes.append(p); ranks.append(r.astype(np.int32)); orders.append(o.astype(np.int32)); lens[s] = ln
+    return planes, ranks, orders, lens
+
+
+def case_sort(rng):
+    f64 = rng.random() < 0.4
+    n = int(rng.integers(1, (ops.sort_max_n(torch.float64) if f64 else ops.sort_max_n()) + 1)) if rng.random() < 0.5 else int(rng.integers(1, 3000))
+    rows = int(rng.integers(1, 5))
+    k = rand_keys(rng, rows, n, np.float64 if f64 else np.float32)
+    row_len = rng.integers(0, n + 1, rows).astype(np.int32) if rng.random() < 0.3 else None
+    o, sk, r = ops.sort_rows_desc(plane(k), row_len=None if row_len is None else dev(row_len), want_rank=True)
+    eo, esk, er = oracle.sort_rows_desc(k, row_len=row_len, want_rank=True)
+    np.testing.assert_array_equal(o.cpu().numpy(), eo); np.testing.assert_array_equal(r.cpu().numpy(), er)
+    np.testing.assert_array_equal(sk.cpu().numpy(), esk)
+    return f"sort f{64 if f64 else 32} rows={rows} n={n} row_len={row_len is not None}"
+
+
+def case_placed(rng):
+    N, Q = int(rng.integers(1, 6000)), int(rng.integers(1, 4))
+    planes, ranks, orders, lens = systems(rng, 1, Q, N, rng.random() < 0.5)
+    f = rand_keys(rng, Q, N, np.float64)
+    f[ranks[0] < 0] = -np.inf
+    o, sk, _ = ops.sort_rows_desc(plane(f), init_rank=plane(ranks[0]), row_len=dev(lens[0]))
+    eo, esk = oracle.sort_rows_desc(f, init_order=orders[0], row_len=lens[0])[:2]
+    np.testing.assert_array_equal(o.cpu().numpy(), eo); np.testing.assert_array_equal(sk.cpu().numpy(), esk)
+    return f"placed sort Q={Q} N={N}"
+
+
+def case_fuse(rng):
+    S, Q = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    N = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 33000)]))
+    partial = rng.random() < 0.5
+    planes, ranks, orders, lens = systems(rng, S, Q, N, partial)
+    what = rng.choice(["rrf", "bcf", "none", "insertion"] + list(NSF_TOL))
+    if what in ("rrf", "bcf"):
+        got = ops.fuse_rank([plane(r) for r in ranks], dev(lens), what).cpu().numpy()
+        np.testing.assert_array_equal(got, oracle.fuse_rank(ranks, lens, what))
+    elif what == "none":
+        w = rng.dirichlet(np.ones(S))
+        got = ops.fuse_none([plane(p) for p in planes], [plane(r) for r in ranks], w).cpu().numpy()
+        np.testing.assert_array_equal(got, oracle.fuse_none(planes, ranks, w))
+    elif what == "insertion":
+        ins, U = ops.insertion_order([plane(o) for o in orders], dev(lens), N)
+        e_ins, e_U = oracle.insertion_order(orders, lens, N)
+        np.testing.assert_array_equal(U.cpu().numpy(), e_U)
+        g = ins.cpu().numpy()
+        for q in range(Q):
+            np.testing.assert_array_equal(g[q, : e_U[q]], e_ins[q, : e_U[q]])
+    else:
+        w = rng.dirichlet(np.ones(S))
+        distr = None
+        if what in ("percentile-rank", "normal-curve-equivalent"):
+            distr = [np.quantile(p.astype(np.float64), np.linspace(0, 1, min(101, N + 2))).astype(np.float32) for p in planes]
+        rk = ranks if partial else None
+        got = ops.fuse_nsf([plane(p) for p in planes], None if rk is None else [plane(r) for r in rk], w, what,
+                           None if distr is None else [dev(d) for d in distr]).cpu().numpy()
+        exp = oracle.fuse_nsf(planes, rk, w, what, distr)
+        fin = np.isfinite(exp)
+        np.testing.assert_array_equal(np.isfinite(got), fin)
+        np.testing.assert_array_equal(got[~fin], exp[~fin])
+        err = np.max(np.abs(got[fin] - exp[fin]), initial=0.0)
+        assert err <= NSF_TOL[what] * max(1.0, np.max(np.abs(exp[fin]), initial=0.0)), (what, err)
+    return f"fuse {what} S={S} Q={Q} N={N} partial={partial}"
+
+
+def case_topk(rng):
+    rows, n, k = int(rng.integers(1, 4)), int(rng.integers(1, 120000)), int(rng.integers(1, 1001))
+    s = np.round(rng.normal(0, 1, (rows, n)), int(rng.integers(1, 4))).astype(np.float32)
+    gs, gi = ops.topk_rows(plane(s), k, id_base=7)
+    es, ei = oracle.topk_rows(s, k, id_base=7)
+    np.testing.assert_array_equal(gs.cpu().numpy(), es); np.testing.assert_array_equal(gi.cpu().numpy(), ei)
+    return f"topk rows={rows} n={n} k={k}"
+
+
+def case_cos(rng):
+    Q, N, d = int(rng.integers(1, 300)), int(rng.integers(1, 3000)), int(rng.integers(1, 200) * 4)
+    A, B = rng.normal(0, 1, (Q, d)).astype(np.float32), rng.normal(0, 1, (N, d)).astype(np.float32)
+    got = ops.cos_scores(dev(A), dev(B)).cpu().numpy()
+    assert np.max(np.abs(got - oracle.cos_scores(A, B))) <= 2e-6
+    return f"cos Q={Q} N={N} d={d}"
+
+
+def case_attn(rng):
+    H = int(rng.integers(1, 13))
+    lens = rng.integers(1, int(rng.choice([20, 70, 600])), int(rng.integers(1, 12)))
+    T = int(lens.sum())
+    g = torch.Generator(device="cuda").manual_seed(int(rng.integers(0, 1 << 30)))
+    qkv = torch.randn((T, 3 * H * 64), generator=g, device="cuda") * float(rng.choice([0.3, 1.0, 3.0]))
+    strips, cu = ops.attn_strips(lens)
+    out = ops.attn_varlen(qkv, torch.from_numpy(strips).cuda(), H)
+    for b, L in enumerate(lens.tolist()):
+        blk = qkv[cu[b]: cu[b] + L].double().view(L, 3, H, 64)
+        q, k, v = blk[:, 0].transpose(0, 1), blk[:, 1].transpose(0, 1), blk[:, 2].transpose(0, 1)
+        ref = (torch.softmax(q @ k.transpose(1, 2) / 8.0, -1) @ v).transpose(0, 1).reshape(L, H * 64)
+        err = (out[cu[b]: cu[b] + L].double() - ref).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    return f"attn H={H} lens={lens.tolist()}"
+
+
+def case_layernorm(rng):
+    rows, d = int(rng.integers(1, 3000)), int(rng.integers(1, 1025) * 4)
+    g = torch.Generator(device="cuda").manual_seed(int(rng.integers(0, 1 << 30)))
+    x = torch.randn((rows, d), generator=g, device="cuda") * 2 + 0.5
+    res = torch.randn((rows, d), generator=g, device="cuda") if rng.random() < 0.5 else None
+    ga, be = torch.randn(d, generator=g, device="cuda"), torch.randn(d, generator=g, device="cuda")
+    y = ops.add_layernorm(x, res, ga, be, 1e-5)
+    ref = torch.nn.functional.layer_norm((x if res is None else x + res).double(), (d,), ga.double(), be.double(), 1e-5)
+    assert (y.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    return f"layernorm rows={rows} d={d} res={res is not None}"
+
+
+def case_maxsim(rng):
+    Q, N, Lq = int(rng.integers(1, 12)), int(rng.integers(1, 120)), int(rng.choice([32, 64, 128]))
+    lens = rng.integers(0, int(rng.choice([40, 200, 600])), N)
+    Doff = np.zeros(N + 1, dtype=np.int64); np.cumsum(lens, out=Doff[1:])
+    Dtok = rng.normal(0, 1, (max(int(Doff[-1]), 1), 128)).astype(np.float32)
+    Dtok /= np.linalg.norm(Dtok, axis=1, keepdims=True)
+    Dtok = Dtok.astype(np.float16)[: int(Doff[-1])] if Doff[-1] > 0 else np.zeros((0, 128), dtype=np.float16)
+    Qtok = rng.normal(0, 1, (Q, Lq, 128)).astype(np.float32)
+    Qtok /= np.linalg.norm(Qtok, axis=2, keepdims=True)
+    Qtok = Qtok.astype(np.float16)
+    if Dtok.shape[0] == 0:
+        return "maxsim skipped (all documents empty)"
+    got = ops.maxsim(dev(Qtok), dev(Dtok), dev(Doff), max_doc_len=int(max(lens.max(), 1))).cpu().numpy()
+    exp = oracle.maxsim(Qtok.astype(np.float32), Dtok.astype(np.float32), Doff)
+    assert np.max(np.abs(got - exp)) <= 1e-4 * max(1, Lq / 32)
+    return f"maxsim Q={Q} N={N} Lq={Lq} sumL={int(Doff[-1])}"
+
+
+CASES = [case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    oracle.build()
+    rng = np.random.default_rng(a.seed)
+    t0, n, counts, last = time.time(), 0, {}, time.time()
+    while time.time() - t0 < a.seconds:
+        f = CASES[int(rng.integers(0, len(CASES)))]
+        state = rng.bit_generator.state
+        try:
+            desc = f(rng)
+        except Exception:
+            print(f"FAILED {f.__name__} after {n} cases; rng state to reproduce:\n{state}", flush=True)
+            traceback.print_exc()
+            sys.exit(1)
+        counts[f.__name__] = counts.get(f.__name__, 0) + 1
+        n += 1
+        if time.time() - last > 20:
+            print(f"[{time.time() - t0:5.0f}s] {n} cases ok; last: {desc}", flush=True); last = time.time()
+    torch.cuda.synchronize()
+    print(f"OK: {n} random cases in {time.time() - t0:.0f} s (seed {a.seed}): {counts}")
+
+
+if __name__ == "__main__":
+    main()

@@ -823,3 +823,12 @@ def test_full_size_encoder_kernels(ops):
     seg = torch.repeat_interleave(torch.arange(1024, device="cuda"), torch.from_numpy(lens).cuda())
     ref_p = torch.zeros((1024, 768), device="cuda", dtype=torch.float64).index_add_(0, seg, y.double()) / torch.from_numpy(lens).cuda().double()[:, None]
     assert (pooled.double() - ref_p).abs().max().item() <= 1e-5
+
+
+def test_randomised_soak_short():
+    """15 s of tests/fuzz_gpu.py (random shapes / lengths / ties / partial lists for every kernel family against the oracle
+    or float64 torch); longer runs: python tests/fuzz_gpu.py --seconds 300 --seed N."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_gpu.py"), "--seconds", "15", "--seed", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK:" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
