@@ -180,7 +180,95 @@ def case_maxsim(rng):
     return f"maxsim Q={Q} N={N} Lq={Lq} sumL={int(Doff[-1])}"
 
 
-CASES = [case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim]
+def case_bm25(rng):
+    from fusion_amd.retrievers.bm25 import BM25
+    V = int(rng.integers(3, 400))
+    vocab = np.array([f"w{i}" for i in range(V)])
+    p = 1.0 / np.arange(1, V + 1); p /= p.sum()
+    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(0, 80)), p=p)) for _ in range(int(rng.integers(1, 400)))]
+    queries = [" ".join(rng.choice(vocab, size=int(rng.integers(0, 10)), p=p)) for _ in range(int(rng.integers(1, 12)))] + ["zzz w1 w1"]
+    if not any(d for d in docs):
+        docs[0] = "w0"
+    k1, b = float(rng.choice([0.9, 1.2, 2.5])), float(rng.choice([0.0, 0.2, 0.75, 1.0]))
+    got = BM25(docs, k1, b).scores(queries).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.BM25(docs, k1, b).scores(queries))
+    return f"bm25 docs={len(docs)} V={V} k1={k1} b={b}"
+
+
+def case_tune(rng):
+    from fusion_amd.planes import RankedSystem
+    from fusion_amd.retrievers.hybrid import Aggregator, run_evaluation, weight_grid
+    S, Q, N = int(rng.integers(2, 5)), int(rng.integers(1, 6)), int(rng.integers(2, 900))
+    norm = str(rng.choice(["min-max", "z-score", "arctan"]))
+    partial = rng.random() < 0.5
+    planes, ranks, orders, lens = systems(rng, S, Q, N, partial)
+    ids = np.arange(100, 100 + N)
+    names = ["bm25", "dpr", "splade", "colbert"][:S]
+    sysd = {}
+    for n, p, l in zip(names, planes, lens):
+        pl = plane(p)
+        od, _, rk = ops.sort_rows_desc(pl, want_rank=True)
+        Lq = torch.from_numpy(l).cuda()
+        full = bool((l == N).all())
+        if not full:
+            keep = torch.arange(N, device="cuda").unsqueeze(0) < Lq.unsqueeze(1)
+            rk = torch.where(rk < Lq.unsqueeze(1), rk, torch.full_like(rk, -1))
+            od = torch.where(keep, od, torch.full_like(od, -1))
+        sysd[n] = RankedSystem(scores=pl, order=od, rank=rk, lens=Lq, ids=ids, full=full)
+    labels = [rng.choice(ids, size=int(rng.integers(1, min(N, 11) + 1)), replace=False).tolist() for _ in range(Q)]
+    grid = weight_grid(names)
+    grid = [grid[i] for i in rng.choice(len(grid), size=min(6, len(grid)), replace=False)]
+    got = Aggregator.tune(sysd, norm, grid, labels, {})
+    for w, g in zip(grid, got):
+        fused = Aggregator.fuse(sysd, "nsf", norm, w, {}, as_device=True)
+        exp = run_evaluation(fused.predictions(1000), labels, print2console=False)
+        for k in exp:
+            assert abs(g[k] - float(exp[k])) <= 1e-12, (w, k, g[k], exp[k])
+    return f"tune S={S} Q={Q} N={N} {norm} partial={partial}"
+
+
+def case_topk_stream(rng):
+    rows, k = int(rng.integers(1, 4)), int(rng.integers(1, 1001))
+    chunks = [int(rng.integers(1, 40000)) for _ in range(int(rng.integers(2, 5)))]
+    s = np.round(rng.normal(0, 1, (rows, sum(chunks))), int(rng.integers(1, 4))).astype(np.float32)
+    c0 = chunks[0]
+    bs, bi = ops.topk_rows(plane(s[:, :c0]), k)
+    ov = None
+    for c in chunks[1:]:
+        if k + 7168 <= 35840:
+            bs, bi, ov = ops.topk_update(plane(s[:, c0:c0 + c]), c0, bs, bi, 7168, ov)
+        else:
+            t_s, t_i = ops.topk_rows(plane(s[:, c0:c0 + c]), k, id_base=c0)
+            bs, bi = ops.topk_merge(torch.stack([bs, t_s]), torch.stack([bi, t_i]))
+        c0 += c
+    es, ei = oracle.topk_rows(s, k)
+    if ov is not None and int(ov.item()) != 0:
+        return f"topk stream overflowed its candidate buffer (exact path would rerun) rows={rows} k={k}"
+    np.testing.assert_array_equal(bs.cpu().numpy(), es); np.testing.assert_array_equal(bi.cpu().numpy(), ei)
+    return f"topk stream rows={rows} k={k} chunks={chunks}"
+
+
+def case_segments(rng):
+    lens = rng.integers(0, 70, int(rng.integers(1, 30)))
+    d = int(rng.choice([rng.integers(1, 200) * 4, rng.integers(1, 3000)]))
+    g = torch.Generator(device="cuda").manual_seed(int(rng.integers(0, 1 << 30)))
+    x = torch.randn((int(lens.sum()) + 1, d), generator=g, device="cuda")[: int(lens.sum())] * 3
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device="cuda")
+    splade = rng.random() < 0.5
+    out = ops.segment_splade_max(x, cu) if splade else (ops.segment_mean(x, cu) if d % 4 == 0 else ops.segment_splade_max(x, cu))
+    splade = splade or d % 4 != 0
+    for b, L in enumerate(lens.tolist()):
+        seg = x[int(cu[b]): int(cu[b + 1])]
+        if L == 0:
+            ref = torch.zeros(d, device="cuda", dtype=torch.float64)
+        else:
+            ref = torch.log1p(torch.relu(seg)).amax(0).double() if splade else seg.double().mean(0)
+        assert (out[b].double() - ref).abs().max().item() <= 2e-6
+    return f"segments {'splade-max' if splade else 'mean'} lens={len(lens)} d={d}"
+
+
+CASES = [case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
+         case_topk_stream, case_segments]
 
 
 def main():
