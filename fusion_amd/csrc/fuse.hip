@@ -454,6 +454,55 @@ __global__ __launch_bounds__(256) void fuse_nsf_elem_kernel(NsfArgs a, const flo
     }
 }
 
+// The same, 4 columns per thread (16-B loads and stores); needs ld % 4 == 0 and 16-B aligned planes.  With the statistics in
+// hand the whole fusion is ONE flat streaming pass -- and for min-max on RANKED systems they are: min and max of a list sorted
+// by score are its last and first entries (minmax_from_order_kernel), no reduction over the row at all.
+template <int NORM>
+__global__ __launch_bounds__(256) void fuse_nsf_elem4_kernel(NsfArgs a, const float* __restrict__ stat_a,
+                                                             const float* __restrict__ stat_b, int Q, float* __restrict__ fused) {
+    const int q = blockIdx.y;
+    const size_t rowoff = (size_t)q * a.ld;
+    const int j0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (j0 >= a.N) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    bool present[4] = {false, false, false, false};
+    for (int s = 0; s < a.S; ++s) {
+        const float4 f = *reinterpret_cast<const float4*>(a.planes[s] + rowoff + j0);
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        int r[4] = {0, 0, 0, 0};
+        if (a.ranks[s]) { const int4 t = *reinterpret_cast<const int4*>(a.ranks[s] + rowoff + j0); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+        const float sa = stat_a ? stat_a[s * Q + q] : 0.f, sb = stat_b ? stat_b[s * Q + q] : 0.f, w = a.w[s];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (r[c] >= 0 && j0 + c < a.N) {
+                const float t = transform<NORM>(v[c], sa, sb, a.distr[s], a.P[s]);
+                const float prod = t * w;
+                acc[c] = acc[c] + prod;
+                present[c] = true;
+            }
+        }
+    }
+    // columns [N, ld) of the last float4 are padding of the plane: written, never read
+    *reinterpret_cast<float4*>(fused + rowoff + j0) = make_float4(present[0] ? acc[0] : -INFINITY, present[1] ? acc[1] : -INFINITY,
+                                                                 present[2] ? acc[2] : -INFINITY, present[3] ? acc[3] : -INFINITY);
+}
+
+// min / max of every ranked list from its ends: order[row][0] is the best-scored document, order[row][len-1] the worst
+// (stable descending sort, NaN first: a NaN anywhere makes both NaN, as torch.min / torch.max propagate it).
+__global__ void minmax_from_order_kernel(const float* __restrict__ scores, const int32_t* __restrict__ order, const int32_t* __restrict__ lens,
+                                         int rows, int N, int ld, float* __restrict__ mn, float* __restrict__ mx) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int len = lens ? lens[row] : N;
+    float lo = 0.f, hi = 0.f;
+    if (len > 0) {
+        hi = scores[(size_t)row * ld + order[(size_t)row * ld]];
+        lo = scores[(size_t)row * ld + order[(size_t)row * ld + len - 1]];
+        if (hi != hi) lo = hi;
+    }
+    mn[row] = lo; mx[row] = hi;
+}
+
 // -------------------------------------------------------------------------------------
 // 'none' passthrough in float64 and rank fusion in float64: flat elementwise kernels,
 // 4 columns per thread (16-B rank/score loads, 32-B stores).
@@ -693,8 +742,22 @@ extern "C" int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t
         a.P[s] = needs_distr ? P_h[s] : 0;
         a.w[s] = (float)w_h[s];
     }
-    dim3 grid((unsigned)((N + 255) / 256 < 64 ? (N + 255) / 256 : 64), (unsigned)Q);
     hipStream_t st = as_stream(stream);
+    bool vec = (ld % 4 == 0) && ((uintptr_t)fused % 16 == 0);
+    for (int s = 0; s < S; ++s) vec = vec && ((uintptr_t)a.planes[s] % 16 == 0) && (!a.ranks[s] || (uintptr_t)a.ranks[s] % 16 == 0);
+    if (vec) {
+        dim3 grid((unsigned)((N + 1023) / 1024), (unsigned)Q);
+        switch (norm) {
+            case FZ_NORM_MINMAX: fuse_nsf_elem4_kernel<FZ_NORM_MINMAX><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
+            case FZ_NORM_ZSCORE: fuse_nsf_elem4_kernel<FZ_NORM_ZSCORE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
+            case FZ_NORM_ARCTAN: fuse_nsf_elem4_kernel<FZ_NORM_ARCTAN><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
+            case FZ_NORM_PERCENTILE: fuse_nsf_elem4_kernel<FZ_NORM_PERCENTILE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
+            case FZ_NORM_NCE: fuse_nsf_elem4_kernel<FZ_NORM_NCE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
+        }
+        FZ_LAUNCH_CHECK();
+        return FZ_OK;
+    }
+    dim3 grid((unsigned)((N + 255) / 256 < 64 ? (N + 255) / 256 : 64), (unsigned)Q);
     switch (norm) {
         case FZ_NORM_MINMAX: fuse_nsf_elem_kernel<FZ_NORM_MINMAX><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
         case FZ_NORM_ZSCORE: fuse_nsf_elem_kernel<FZ_NORM_ZSCORE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
@@ -702,6 +765,16 @@ extern "C" int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t
         case FZ_NORM_PERCENTILE: fuse_nsf_elem_kernel<FZ_NORM_PERCENTILE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
         case FZ_NORM_NCE: fuse_nsf_elem_kernel<FZ_NORM_NCE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
     }
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+extern "C" int fz_minmax_from_order_f32(const float* scores, const int32_t* order, const int32_t* lens, int rows, int N, int ld,
+                                        float* mn, float* mx, void* stream) {
+    if (rows < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (rows == 0) return FZ_OK;
+    if (!scores || !order || !mn || !mx) return FZ_ERR_ARG;
+    minmax_from_order_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, as_stream(stream)>>>(scores, order, lens, rows, N, ld, mn, mx);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

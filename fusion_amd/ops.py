@@ -282,9 +282,34 @@ def row_stats(scores: torch.Tensor, rank: torch.Tensor | None, norm: str):
     return a, b
 
 
+def minmax_from_order(scores: torch.Tensor, order: torch.Tensor, lens: torch.Tensor | None, out=None):
+    """(min, max) of every ranked list read off its two ends (no reduction): scores / order [Q, N] planes, lens [Q] or None.
+    out: optional (mn, mx) fp32 tensors of Q entries to write into."""
+    _dev(scores, torch.float32, "minmax_from_order(scores)")
+    _dev(order, torch.int32, "minmax_from_order(order)")
+    _same_shape([scores, order], "minmax_from_order")
+    scores, order = harmonise([scores, order])
+    rows, N = scores.shape
+    if lens is not None:
+        _need(_dev(lens, torch.int32, "minmax_from_order(lens)").numel() == rows and lens.is_contiguous(), f"minmax_from_order: lens must hold {rows} lengths")
+    if out is not None:
+        mn, mx = out
+        _need(mn.numel() == rows and mx.numel() == rows and mn.is_contiguous() and mx.is_contiguous(), f"minmax_from_order(out): need two contiguous tensors of {rows}")
+        _dev(mn, torch.float32, "minmax_from_order(out)"); _dev(mx, torch.float32, "minmax_from_order(out)")
+    else:
+        mn = torch.empty(rows, dtype=torch.float32, device=scores.device)
+        mx = torch.empty(rows, dtype=torch.float32, device=scores.device)
+    check(_lib.lib().fz_minmax_from_order_f32(_ptr(scores), _ptr(order), _ptr(lens), rows, N, _ld(scores), _ptr(mn), _ptr(mx), _stream(scores)),
+          "fz_minmax_from_order_f32")
+    return mn, mx
+
+
 def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None, weights, norm: str,
-             distr: list[torch.Tensor] | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
-    """normalise -> weight -> sum in one HBM pass (hybrid.py:212-214,254-280,291,301-304)."""
+             distr: list[torch.Tensor] | None = None, out: torch.Tensor | None = None,
+             orders: list[torch.Tensor] | None = None, lens: torch.Tensor | None = None) -> torch.Tensor:
+    """normalise -> weight -> sum in one HBM pass (hybrid.py:212-214,254-280,291,301-304).
+    orders (+ lens [S, Q]): the systems' order planes, when they are ranked -- min-max then takes every list's minimum and
+    maximum from its two ends and the fusion is one flat streaming pass (same bits as the reducing kernel)."""
     for p in planes:
         _dev(p, torch.float32, "fuse_nsf(planes)")
     S = len(planes)
@@ -314,6 +339,17 @@ def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None
         dptr = _ptr_array(distr)
         P = (C.c_int32 * S)(*[int(d.numel()) for d in distr])
     lib = _lib.lib()
+    if norm == "min-max" and orders is not None and Q > 0 and N > 0:
+        _need(len(orders) == S, f"fuse_nsf: {S} planes but {len(orders)} order planes")
+        if lens is not None:
+            _need(tuple(lens.shape) == (S, Q), f"fuse_nsf(lens): expected shape {(S, Q)}, got {tuple(lens.shape)}")
+        sa = torch.empty(S * Q, dtype=torch.float32, device=dev)
+        sb = torch.empty(S * Q, dtype=torch.float32, device=dev)
+        for s in range(S):
+            minmax_from_order(planes[s], orders[s], None if lens is None else lens[s], out=(sa[s * Q:(s + 1) * Q], sb[s * Q:(s + 1) * Q]))
+        check(lib.fz_fuse_nsf_stats_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm],
+                                        dptr, P, _ptr(sa), _ptr(sb), _ptr(fused), _stream(planes[0])), "fz_fuse_nsf_stats_f32")
+        return fused
     rc = lib.fz_fuse_nsf_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm], dptr, P,
                              _ptr(fused), _stream(planes[0]))
     if rc == _lib.FZ_ERR_UNSUPPORTED:

@@ -196,7 +196,10 @@ class Aggregator:
             if normalization in ("percentile-rank", "normal-curve-equivalent"):
                 distr = [cls._table(percentile_distributions.get(n), dev) for n in names]
                 fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, distr)
-            elif normalization in ("min-max", "z-score", "arctan"):
+            elif normalization == "min-max":                # ranked systems: min / max are the two ends of every list, no row reduction
+                fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, orders=[s.order for s in S],
+                                     lens=torch.stack([s.lens for s in S]).contiguous())
+            elif normalization in ("z-score", "arctan"):
                 fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization)
             else:                                           # 'none' / unknown string: passthrough (hybrid.py:280)
                 fused = ops.fuse_none([s.scores for s in S], ranks, w)

@@ -127,6 +127,13 @@ int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* const* ranks_h,
 int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
                           int ld, int norm, const float* const* distr_h, const int32_t* P_h, const float* stat_a,
                           const float* stat_b, float* fused, void* stream);
+/* min / max of RANKED lists without a reduction: a list sorted by score has its maximum first and its minimum last.
+ * mn[row] = scores[row][order[row][len-1]], mx[row] = scores[row][order[row][0]], len = lens[row] (NULL = N); an empty list gives
+ * 0, 0; a NaN at the head makes both NaN (torch.min / torch.max propagate it, hybrid.py:254-258).  With these,
+ * fz_fuse_nsf_stats_f32 is a single flat streaming pass -- the fast form of min-max fusion for systems that come with their
+ * order plane. */
+int fz_minmax_from_order_f32(const float* scores, const int32_t* order, const int32_t* lens, int rows, int N, int ld,
+                             float* mn, float* mx, void* stream);
 /* 'none' / unknown normalisation: fused[q][j] = sum_s (double)score_s * w_s in fp64 (hybrid.py:280,291,304) */
 int fz_fuse_none_f64(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
                      int ld, double* fused, void* stream);

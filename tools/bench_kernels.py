@@ -40,7 +40,12 @@ def bench_nsf(Q=1024, N=27942, S=4):
     for norm in ("min-max", "z-score", "arctan"):
         ms = timeit(lambda: ops.fuse_nsf(planes, None, w, norm, out=out))
         emit(f"fuse_nsf_row_kernel<{norm}> S={S}", ms, (S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
-    ranks = [ops.sort_rows_desc(p, want_order=False, want_keys=False, want_rank=True)[2] for p in planes]
+    so = [ops.sort_rows_desc(p, want_order=True, want_keys=False, want_rank=True) for p in planes]
+    orders, ranks = [x[0] for x in so], [x[2] for x in so]
+    ms = timeit(lambda: ops.fuse_nsf(planes, None, w, "min-max", out=out, orders=orders))
+    emit(f"min-max from list ends + fuse_nsf_elem4_kernel S={S} (ranked systems)", ms, (S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
+    chk = ops.fuse_nsf(planes, None, w, "min-max")
+    assert torch.equal(chk, ops.fuse_nsf(planes, None, w, "min-max", orders=orders)), "fast min-max path differs from the reducing kernel"
     ms = timeit(lambda: ops.fuse_nsf(planes, ranks, w, "min-max", out=out))
     emit(f"fuse_nsf_row_kernel<min-max,+validity> S={S}", ms, (2 * S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
     lens = torch.full((S, Q), N, dtype=torch.int32, device="cuda")
