@@ -194,9 +194,11 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     for (int i = 0; i < VPL; ++i) {
         const int c = i * 64 + lane;
         if (c < nv) {
-            float4 t = reinterpret_cast<const float4*>(x + (size_t)row * ldx)[c];
+            typedef float f4v __attribute__((ext_vector_type(4)));   // both inputs are streamed once: non-temporal loads
+            const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(x + (size_t)row * ldx) + c);
+            float4 t = make_float4(tv.x, tv.y, tv.z, tv.w);
             if (res) {
-                const float4 u = reinterpret_cast<const float4*>(res + (size_t)row * ldr)[c];
+                const f4v u = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(res + (size_t)row * ldr) + c);
                 t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
             }
             v[i] = t;

@@ -148,6 +148,9 @@ __global__ __launch_bounds__(THREADS) void row_stats_kernel(const float* __restr
 // registers and accumulated into the fused registers.  HBM traffic = (S+1)*N*4 B per query
 // (+ S*N*4 when rank planes carry validity).
 // -------------------------------------------------------------------------------------
+// cache-policy operand of global_load_lds on gfx940+: 2 = nt (the planes are streamed exactly once)
+#define FZ_CPOL_NT 2
+
 struct NsfArgs {
     const float* planes[FZ_MAX_SYSTEMS];
     const int32_t* ranks[FZ_MAX_SYSTEMS];
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
 #pragma unroll
         for (int i = 0; i < E4; ++i) {
             const int j0 = 4 * (threadIdx.x + T * i);
-            if (j0 < N) __builtin_amdgcn_global_load_lds(x0 + j0, (__attribute__((address_space(3))) void*)(rowbuf + 4 * (threadIdx.x - lane + T * i)), 16, 0, 0);
+            if (j0 < N) __builtin_amdgcn_global_load_lds(x0 + j0, (__attribute__((address_space(3))) void*)(rowbuf + 4 * (threadIdx.x - lane + T * i)), 16, 0, FZ_CPOL_NT);
         }
     }
   for (int q = blockIdx.x; q < a.Q; q += gridDim.x) {
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
             const int j0 = 4 * (threadIdx.x + T * i);
             if (j0 < N) {
                 // LDS destination = wave-uniform base + lane*16: pass the address of lane 0's slot
-                __builtin_amdgcn_global_load_lds(x + j0, (__attribute__((address_space(3))) void*)(rowbuf + 4 * (threadIdx.x - lane + T * i)), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(x + j0, (__attribute__((address_space(3))) void*)(rowbuf + 4 * (threadIdx.x - lane + T * i)), 16, 0, FZ_CPOL_NT);
             }
         }
     };
@@ -467,10 +470,12 @@ __global__ __launch_bounds__(256) void fuse_nsf_elem4_kernel(NsfArgs a, const fl
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     bool present[4] = {false, false, false, false};
     for (int s = 0; s < a.S; ++s) {
-        const float4 f = *reinterpret_cast<const float4*>(a.planes[s] + rowoff + j0);
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        typedef int i4v __attribute__((ext_vector_type(4)));
+        const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.planes[s] + rowoff + j0));   // streamed once
         const float v[4] = {f.x, f.y, f.z, f.w};
         int r[4] = {0, 0, 0, 0};
-        if (a.ranks[s]) { const int4 t = *reinterpret_cast<const int4*>(a.ranks[s] + rowoff + j0); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+        if (a.ranks[s]) { const i4v t = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(a.ranks[s] + rowoff + j0)); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
         const float sa = stat_a ? stat_a[s * Q + q] : 0.f, sb = stat_b ? stat_b[s * Q + q] : 0.f, w = a.w[s];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -483,6 +488,7 @@ __global__ __launch_bounds__(256) void fuse_nsf_elem4_kernel(NsfArgs a, const fl
         }
     }
     // columns [N, ld) of the last float4 are padding of the plane: written, never read
+    // plain store: the fused plane is read straight back by the ordering sort
     *reinterpret_cast<float4*>(fused + rowoff + j0) = make_float4(present[0] ? acc[0] : -INFINITY, present[1] ? acc[1] : -INFINITY,
                                                                  present[2] ? acc[2] : -INFINITY, present[3] ? acc[3] : -INFINITY);
 }
@@ -527,9 +533,11 @@ __global__ __launch_bounds__(256) void fuse_none_kernel(ElemArgs a, double* __re
     for (int s = 0; s < a.S; ++s) {
         float v[4]; int r[4] = {0, 0, 0, 0};
         if (full) {
-            float4 f = *reinterpret_cast<const float4*>(a.planes[s] + rowoff + j0);
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            typedef int i4v __attribute__((ext_vector_type(4)));
+            const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.planes[s] + rowoff + j0));   // streamed once
             v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-            if (a.ranks[s]) { int4 t = *reinterpret_cast<const int4*>(a.ranks[s] + rowoff + j0); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+            if (a.ranks[s]) { const i4v t = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(a.ranks[s] + rowoff + j0)); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
         } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -558,8 +566,11 @@ __global__ __launch_bounds__(256) void fuse_rank_kernel(ElemArgs a, double* __re
     const bool full = VEC && (j0 + 3 < a.N);
     for (int s = 0; s < a.S; ++s) {
         int r[4];
-        if (full) { int4 t = *reinterpret_cast<const int4*>(a.ranks[s] + rowoff + j0); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
-        else {
+        if (full) {   // streamed once: non-temporal
+            typedef int i4v __attribute__((ext_vector_type(4)));
+            const i4v t = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(a.ranks[s] + rowoff + j0));
+            r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+        } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) r[c] = (j0 + c < a.N) ? a.ranks[s][rowoff + j0 + c] : -1;
         }
