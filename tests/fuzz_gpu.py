@@ -108,6 +108,10 @@ def case_fuse(rng):
         got = ops.fuse_nsf([plane(p) for p in planes], None if rk is None else [plane(r) for r in rk], w, what,
                            None if distr is None else [dev(d) for d in distr]).cpu().numpy()
         exp = oracle.fuse_nsf(planes, rk, w, what, distr)
+        if what == "min-max":   # ranked systems: statistics from the two ends of every list, same bits
+            fast = ops.fuse_nsf([plane(p) for p in planes], None if rk is None else [plane(r) for r in rk], w, what,
+                                orders=[plane(o) for o in orders], lens=dev(lens)).cpu().numpy()
+            np.testing.assert_array_equal(fast, got)
         fin = np.isfinite(exp)
         np.testing.assert_array_equal(np.isfinite(got), fin)
         np.testing.assert_array_equal(got[~fin], exp[~fin])
