@@ -51,6 +51,7 @@ _PROTOS = {
     "fz_row_stats_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "fz_fuse_nsf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "fz_fuse_nsf_stats_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fz_minmax_from_orders_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "fz_minmax_from_order_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "fz_fuse_none_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fz_insertion_order_workspace_bytes": (_sz, [_i, _i]),

@@ -780,6 +780,41 @@ extern "C" int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t
     return FZ_OK;
 }
 
+// all S systems of a fusion in one launch: thread (s, q)
+struct EndsArgs {
+    const float* planes[FZ_MAX_SYSTEMS];
+    const int32_t* orders[FZ_MAX_SYSTEMS];
+};
+__global__ void minmax_from_orders_kernel(EndsArgs e, const int32_t* __restrict__ lens, int S, int Q, int N, int ld,
+                                          float* __restrict__ mn, float* __restrict__ mx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * Q) return;
+    const int s = i / Q, row = i - s * Q;
+    const int len = lens ? lens[i] : N;
+    float lo = 0.f, hi = 0.f;
+    if (len > 0) {
+        hi = e.planes[s][(size_t)row * ld + e.orders[s][(size_t)row * ld]];
+        lo = e.planes[s][(size_t)row * ld + e.orders[s][(size_t)row * ld + len - 1]];
+        if (hi != hi) lo = hi;
+    }
+    mn[i] = lo; mx[i] = hi;
+}
+
+extern "C" int fz_minmax_from_orders_f32(const float* const* planes_h, const int32_t* const* orders_h, const int32_t* lens, int S, int Q,
+                                         int N, int ld, float* mn, float* mx, void* stream) {
+    if (!planes_h || !orders_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (Q == 0) return FZ_OK;
+    if (!mn || !mx) return FZ_ERR_ARG;
+    EndsArgs e{};
+    for (int s = 0; s < S; ++s) {
+        if (!planes_h[s] || !orders_h[s]) return FZ_ERR_ARG;
+        e.planes[s] = planes_h[s]; e.orders[s] = orders_h[s];
+    }
+    minmax_from_orders_kernel<<<(unsigned)((S * Q + 255) / 256), 256, 0, as_stream(stream)>>>(e, lens, S, Q, N, ld, mn, mx);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
 extern "C" int fz_minmax_from_order_f32(const float* scores, const int32_t* order, const int32_t* lens, int rows, int N, int ld,
                                         float* mn, float* mx, void* stream) {
     if (rows < 0 || N < 0 || ld < N) return FZ_ERR_ARG;

@@ -343,10 +343,23 @@ def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None
         _need(len(orders) == S, f"fuse_nsf: {S} planes but {len(orders)} order planes")
         if lens is not None:
             _need(tuple(lens.shape) == (S, Q), f"fuse_nsf(lens): expected shape {(S, Q)}, got {tuple(lens.shape)}")
+        for o_ in orders:
+            _dev(o_, torch.int32, "fuse_nsf(orders)")
+        _same_shape(list(planes) + list(orders), "fuse_nsf(orders)")
+        allp = harmonise(list(planes) + (list(ranks) if ranks else []) + list(orders))   # one row stride for every plane of the call
+        planes, orders = allp[:S], allp[len(allp) - S:]
+        ranks = allp[S:2 * S] if ranks else None
+        ld = _same_ld(*planes, *orders, *([r for r in ranks if r is not None] if ranks else []))
+        if out is None:
+            fused = torch.empty((max(Q, 1), ld), dtype=torch.float32, device=dev)[:Q, :N]
+        else:
+            _need(Q <= 1 or _ld(out) == ld, f"fuse_nsf(out): expected a [{Q}, {N}] plane with row stride {ld}")
+        if lens is not None:
+            lens = _dev(lens, torch.int32, "fuse_nsf(lens)").contiguous()
         sa = torch.empty(S * Q, dtype=torch.float32, device=dev)
         sb = torch.empty(S * Q, dtype=torch.float32, device=dev)
-        for s in range(S):
-            minmax_from_order(planes[s], orders[s], None if lens is None else lens[s], out=(sa[s * Q:(s + 1) * Q], sb[s * Q:(s + 1) * Q]))
+        check(lib.fz_minmax_from_orders_f32(_ptr_array(planes), _ptr_array(orders), _ptr(lens), S, Q, N, ld, _ptr(sa), _ptr(sb), _stream(planes[0])),
+              "fz_minmax_from_orders_f32")
         check(lib.fz_fuse_nsf_stats_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm],
                                         dptr, P, _ptr(sa), _ptr(sb), _ptr(fused), _stream(planes[0])), "fz_fuse_nsf_stats_f32")
         return fused

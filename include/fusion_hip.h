@@ -134,6 +134,10 @@ int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t* const* ra
  * order plane. */
 int fz_minmax_from_order_f32(const float* scores, const int32_t* order, const int32_t* lens, int rows, int N, int ld,
                              float* mn, float* mx, void* stream);
+/* The same for all S systems of a fusion in one launch: planes_h / orders_h HOST arrays of S device planes [Q][ld], lens [S][Q]
+ * (device, NULL = N), mn / mx [S][Q] -- the layout fz_fuse_nsf_stats_f32 takes. */
+int fz_minmax_from_orders_f32(const float* const* planes_h, const int32_t* const* orders_h, const int32_t* lens, int S, int Q, int N,
+                              int ld, float* mn, float* mx, void* stream);
 /* 'none' / unknown normalisation: fused[q][j] = sum_s (double)score_s * w_s in fp64 (hybrid.py:280,291,304) */
 int fz_fuse_none_f64(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
                      int ld, double* fused, void* stream);
