@@ -78,6 +78,55 @@ __device__ __forceinline__ float row16_sum(float v) {
 __device__ __forceinline__ void swap16(float& d, float& s) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(d), "+v"(s)); }
 __device__ __forceinline__ void swap32(float& d, float& s) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(d), "+v"(s)); }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {   // DPP moves 32-bit registers: the two halves of a double separately
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void swap16(double& d, double& s) {
+    float dl = __int_as_float(__double2loint(d)), dh = __int_as_float(__double2hiint(d));
+    float sl = __int_as_float(__double2loint(s)), sh = __int_as_float(__double2hiint(s));
+    swap16(dl, sl); swap16(dh, sh);
+    d = __hiloint2double(__float_as_int(dh), __float_as_int(dl));
+    s = __hiloint2double(__float_as_int(sh), __float_as_int(sl));
+}
+__device__ __forceinline__ void swap32(double& d, double& s) {
+    float dl = __int_as_float(__double2loint(d)), dh = __int_as_float(__double2hiint(d));
+    float sl = __int_as_float(__double2loint(s)), sh = __int_as_float(__double2hiint(s));
+    swap32(dl, sl); swap32(dh, sh);
+    d = __hiloint2double(__float_as_int(dh), __float_as_int(dl));
+    s = __hiloint2double(__float_as_int(sh), __float_as_int(sl));
+}
+// Whole-wave (64 lanes) reductions on the VALU: 4 DPP steps inside every 16-lane row (quad_perm xor 1, xor 2, half-row mirror,
+// row mirror: after each step the lanes of the group just closed hold the same value, so mirroring pairs distinct groups), then
+// the two permlane swaps across rows.  Every lane ends up with the result.  (The __shfl_xor forms compile to ds_bpermute: six
+// dependent LDS round trips per value.)
+template <typename T, typename F>
+__device__ __forceinline__ T wave_reduce_valu(T v, F op) {
+    if constexpr (sizeof(T) == 4) {
+        v = op(v, dpp_f32<0xB1>(v)); v = op(v, dpp_f32<0x4E>(v)); v = op(v, dpp_f32<0x141>(v)); v = op(v, dpp_f32<0x140>(v));
+    } else {
+        v = op(v, dpp_f64<0xB1>(v)); v = op(v, dpp_f64<0x4E>(v)); v = op(v, dpp_f64<0x141>(v)); v = op(v, dpp_f64<0x140>(v));
+    }
+    T o = v;
+    swap16(v, o);
+    v = op(v, o);
+    o = v;
+    swap32(v, o);
+    return op(v, o);
+}
+// the same over ONE 16-lane row only (every lane of the row gets its row's result)
+template <typename T, typename F>
+__device__ __forceinline__ T row16_reduce_valu(T v, F op) {
+    if constexpr (sizeof(T) == 4) {
+        v = op(v, dpp_f32<0xB1>(v)); v = op(v, dpp_f32<0x4E>(v)); v = op(v, dpp_f32<0x141>(v)); v = op(v, dpp_f32<0x140>(v));
+    } else {
+        v = op(v, dpp_f64<0xB1>(v)); v = op(v, dpp_f64<0x4E>(v)); v = op(v, dpp_f64<0x141>(v)); v = op(v, dpp_f64<0x140>(v));
+    }
+    return v;
+}
+
 // order-preserving bit transforms: larger float  <=>  SMALLER unsigned key (descending sort
 // becomes an ascending LSD radix sort).  -0.0 == +0.0; every NaN maps to key 0 (sorts first).
 __device__ __forceinline__ uint32_t desc_key_f32(float f) {

@@ -193,18 +193,17 @@ __device__ __forceinline__ void block_minmax_nan(float& mn, float& mx, float& na
     constexpr int NW = THREADS / 64;
     static_assert(NW <= 16, "final combine uses 16 lanes");
     float* r = red + parity * 3 * NW;
-    mn = wave_reduce_min(mn); mx = wave_reduce_max(mx); nanflag = wave_reduce_max(nanflag);
+    auto fmin_ = [](float x, float y) { return fminf(x, y); };
+    auto fmax_ = [](float x, float y) { return fmaxf(x, y); };
+    mn = wave_reduce_valu(mn, fmin_); mx = wave_reduce_valu(mx, fmax_); nanflag = wave_reduce_valu(nanflag, fmax_);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) { r[w] = mn; r[NW + w] = mx; r[2 * NW + w] = nanflag; }
     lds_barrier();
-    // every wave folds the NW partials with its own lanes (lane L takes partial L): 3 LDS reads + 4 shuffle steps per
+    // every wave folds the NW partials with its own lanes (lane L takes partial L): 3 LDS reads + 4 DPP steps per
     // thread instead of 3*NW reads and 3*NW min/max
     const int L = lane & 15;
     mn = L < NW ? r[L] : INFINITY; mx = L < NW ? r[NW + L] : -INFINITY; nanflag = L < NW ? r[2 * NW + L] : 0.f;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); nanflag = fmaxf(nanflag, __shfl_xor(nanflag, o, 64));
-    }
+    mn = row16_reduce_valu(mn, fmin_); mx = row16_reduce_valu(mx, fmax_); nanflag = row16_reduce_valu(nanflag, fmax_);
 }
 template <int THREADS, int NV>
 __device__ __forceinline__ void block_sum_n_nodrain(double (&v)[NV], double* red /* 2 x NV*THREADS/64 */, int parity) {
@@ -346,7 +345,7 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
             float x0c = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[0][0])));
             if (!(x0c == x0c) || fabsf(x0c) == INFINITY) x0c = 0.f;
             const double x0 = (double)x0c;
-            double s1 = 0.0, s2 = 0.0;
+            double s1 = 0.0, s2 = 0.0;   // fp64 throughout: fp32 per-thread partials (0.164 -> 0.152 ms) cost the 2e-6 parity on short lists
 #pragma unroll
             for (int i = 0; i < E4; ++i)
 #pragma unroll
@@ -356,7 +355,8 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
                     s1 += d; s2 += d * d;
                 }
             double cnt = (double)__popcll(ok);
-            s1 = wave_reduce_sum(s1); s2 = wave_reduce_sum(s2); cnt = wave_reduce_sum(cnt);
+            auto add_ = [](double x, double y) { return x + y; };
+            s1 = wave_reduce_valu(s1, add_); s2 = wave_reduce_valu(s2, add_); cnt = wave_reduce_valu(cnt, add_);
             {
                 constexpr int NW = T / 64;
                 double* r = red_d + red_parity * 3 * NW;
@@ -372,9 +372,7 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
                 // parallel-variance update; lane 0's result is broadcast, so every thread of every wave uses the same bits
                 const int L = lane & 15;
                 double n = L < NW ? r[L] : 0.0, mean = L < NW ? r[NW + L] : 0.0, M2 = L < NW ? r[2 * NW + L] : 0.0;
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    const double nb = __shfl_down(n, o, 64), mb = __shfl_down(mean, o, 64), m2b = __shfl_down(M2, o, 64);
+                auto merge_step = [&](double nb, double mb, double m2b) {
                     const double nn = n + nb;
                     if (nb > 0.0) {
                         const double delta = mb - mean, f = nb / nn;
@@ -382,7 +380,13 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
                         M2 = M2 + m2b + delta * delta * (n * f);
                         n = nn;
                     }
-                }
+                };
+                // lane L += lane L + o, o = 8, 4, 2, 1, inside the 16-lane row: DPP row_shl (lanes shifted in from past the row read 0
+                // and only reach lanes that lane 0 never depends on)
+                merge_step(dpp_f64<0x108>(n), dpp_f64<0x108>(mean), dpp_f64<0x108>(M2));
+                merge_step(dpp_f64<0x104>(n), dpp_f64<0x104>(mean), dpp_f64<0x104>(M2));
+                merge_step(dpp_f64<0x102>(n), dpp_f64<0x102>(mean), dpp_f64<0x102>(M2));
+                merge_step(dpp_f64<0x101>(n), dpp_f64<0x101>(mean), dpp_f64<0x101>(M2));
                 auto bcast = [](double x) -> double {
                     const long long b = __double_as_longlong(x);
                     const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
