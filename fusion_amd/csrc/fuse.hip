@@ -497,6 +497,116 @@ __global__ __launch_bounds__(256) void fuse_nsf_elem4_kernel(NsfArgs a, const fl
                                                                  present[2] ? acc[2] : -INFINITY, present[3] ? acc[3] : -INFINITY);
 }
 
+// percentile-rank / normal-curve-equivalent fusion with the quantile tables in LDS.  Neither needs row statistics, so this
+// is a flat pass; what costs is the nearest-entry search: ~log2(P) dependent reads per score -- from global memory (the row
+// kernel's path) 1.2 ms at P = 1001, and the NCE's double-precision erfinv per score another 6.5 ms.  Here every persistent
+// workgroup loads the S tables into LDS once and, for NCE, tabulates the value of every table INDEX next to them (the
+// transform depends on the score only through the index of its nearest entry), then streams (row, 1024-column) items.
+// Same search, same float expressions: bit-identical results.
+struct TableArgs {
+    int off[FZ_MAX_SYSTEMS];   // start of system s's table in the LDS array
+    int total;                 // sum of P
+};
+
+__device__ __forceinline__ int nearest_entry_lds(const float* __restrict__ tab, int P, float s) {
+    // first argmin_k |tab_k - s| on an ASCENDING table (hybrid.py:272-275), as percentile_rank() above
+    int lo = -1, hi = P;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tab[mid] <= s) lo = mid; else hi = mid;
+    }
+    int best;
+    float bd;
+    if (lo < 0) { best = 0; bd = fabsf(tab[0] - s); }
+    else {
+        best = lo; bd = fabsf(tab[lo] - s);
+        if (lo + 1 < P) { const float dh = fabsf(tab[lo + 1] - s); if (dh < bd) { best = lo + 1; bd = dh; } }
+    }
+    while (best > 0 && fabsf(tab[best - 1] - s) == bd) --best;
+    if (s != s) best = 0;
+    return best;
+}
+
+// TPB: NCE runs 1024-thread workgroups -- the double-precision erfinv of the tabulation is the expensive part, and a
+// workgroup four times as large means a quarter of the entries per thread and a quarter of the workgroups repeating them.
+template <bool NCE, int TPB>
+__global__ __launch_bounds__(TPB) void fuse_nsf_table_kernel(NsfArgs a, TableArgs t, int Q, float* __restrict__ fused) {
+    extern __shared__ __attribute__((aligned(16))) float tabs[];   // [total] quantiles (+ [total] NCE values per index)
+    for (int s = 0; s < a.S; ++s)
+        for (int k = threadIdx.x; k < a.P[s]; k += TPB) {
+            tabs[t.off[s] + k] = a.distr[s][k];
+            if (NCE) {   // transform<FZ_NORM_NCE> as a function of the index
+                const float pr = (float)k / (float)a.P[s];
+                const float p = pr / 100.0f;
+                const float y = 2.0f * p - 1.0f;
+                const float z = (float)(erfinv((double)y) * 1.4142135623730951);
+                tabs[t.total + t.off[s] + k] = z * 21.06f + 50.0f;
+            }
+        }
+    __syncthreads();
+    const int chunks = (a.N + 4 * TPB - 1) / (4 * TPB);
+    const long long items = (long long)Q * chunks;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int q = (int)(it / chunks), c = (int)(it - (long long)q * chunks);
+        const size_t rowoff = (size_t)q * a.ld;
+        const int j0 = 4 * (c * TPB + threadIdx.x);
+        if (j0 >= a.N) continue;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        bool present[4] = {false, false, false, false};
+        for (int s = 0; s < a.S; ++s) {
+            const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.planes[s] + rowoff + j0));   // streamed once
+            const float v[4] = {f.x, f.y, f.z, f.w};
+            int r[4] = {0, 0, 0, 0};
+            if (a.ranks[s]) { const i4v rr = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(a.ranks[s] + rowoff + j0)); r[0] = rr.x; r[1] = rr.y; r[2] = rr.z; r[3] = rr.w; }
+            const float* tab = tabs + t.off[s];
+            const int P = a.P[s];
+            const float w = a.w[s];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (r[e] >= 0 && j0 + e < a.N) {
+                    const int k = nearest_entry_lds(tab, P, v[e]);
+                    const float tr = NCE ? tabs[t.total + t.off[s] + k] : (float)k / (float)P;
+                    const float prod = tr * w;
+                    acc[e] = acc[e] + prod;
+                    present[e] = true;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(fused + rowoff + j0) = make_float4(present[0] ? acc[0] : -INFINITY, present[1] ? acc[1] : -INFINITY,
+                                                                     present[2] ? acc[2] : -INFINITY, present[3] ? acc[3] : -INFINITY);
+    }
+}
+
+// returns 1 when the LDS-table kernel cannot take the call (tables too long for LDS, planes not 16-B aligned)
+static int launch_nsf_tables(const NsfArgs& a, bool nce, int Q, float* fused, hipStream_t st) {
+    TableArgs t{};
+    int total = 0;
+    bool vec = (a.ld % 4 == 0) && ((uintptr_t)fused % 16 == 0);
+    for (int s = 0; s < a.S; ++s) {
+        t.off[s] = total;
+        total += a.P[s];
+        vec = vec && ((uintptr_t)a.planes[s] % 16 == 0) && (!a.ranks[s] || (uintptr_t)a.ranks[s] % 16 == 0);
+    }
+    t.total = total;
+    const size_t lds = (size_t)total * 4 * (nce ? 2 : 1);
+    if (!vec || lds > 64 * 1024) return 1;
+    const int tpb = nce ? 1024 : 256;
+    const int per_cu = (lds <= 16 * 1024 ? 8 : (lds <= 32 * 1024 ? 4 : 2)) * 256 / tpb;   // workgroups per CU by LDS and wave slots
+    const long long items = (long long)Q * ((a.N + 4 * tpb - 1) / (4 * tpb));
+    const long long want = 256LL * (per_cu < 1 ? 1 : per_cu);
+    const unsigned grid = (unsigned)(items < want ? items : want);
+    if (nce) {
+        if (hipFuncSetAttribute((const void*)fuse_nsf_table_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        fuse_nsf_table_kernel<true, 1024><<<grid, 1024, lds, st>>>(a, t, Q, fused);
+    } else {
+        if (hipFuncSetAttribute((const void*)fuse_nsf_table_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        fuse_nsf_table_kernel<false, 256><<<grid, 256, lds, st>>>(a, t, Q, fused);
+    }
+    return 0;
+}
+
 // min / max of every ranked list from its ends: order[row][0] is the best-scored document, order[row][len-1] the worst
 // (stable descending sort, NaN first: a NaN anywhere makes both NaN, as torch.min / torch.max propagate it).
 __global__ void minmax_from_order_kernel(const float* __restrict__ scores, const int32_t* __restrict__ order, const int32_t* __restrict__ lens,
@@ -728,8 +838,14 @@ extern "C" int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* cons
         case FZ_NORM_MINMAX: too_long = launch_nsf<FZ_NORM_MINMAX>(a, Q, fused, st); break;
         case FZ_NORM_ZSCORE: too_long = launch_nsf<FZ_NORM_ZSCORE>(a, Q, fused, st); break;
         case FZ_NORM_ARCTAN: too_long = launch_nsf<FZ_NORM_ARCTAN>(a, Q, fused, st); break;
-        case FZ_NORM_PERCENTILE: too_long = launch_nsf<FZ_NORM_PERCENTILE>(a, Q, fused, st); break;
-        case FZ_NORM_NCE: too_long = launch_nsf<FZ_NORM_NCE>(a, Q, fused, st); break;
+        case FZ_NORM_PERCENTILE:
+            too_long = launch_nsf_tables(a, false, Q, fused, st);
+            if (too_long) too_long = launch_nsf<FZ_NORM_PERCENTILE>(a, Q, fused, st);
+            break;
+        case FZ_NORM_NCE:
+            too_long = launch_nsf_tables(a, true, Q, fused, st);
+            if (too_long) too_long = launch_nsf<FZ_NORM_NCE>(a, Q, fused, st);
+            break;
     }
     if (too_long) return FZ_ERR_UNSUPPORTED;  // N > 32768: use fz_row_stats_f32 + fz_fuse_nsf_stats_f32
     FZ_LAUNCH_CHECK();
