@@ -54,6 +54,12 @@ def bench_nsf(Q=1024, N=27942, S=4):
         emit(f"fuse_rank_kernel<{m}> S={S}", ms, (S * 4 + 8) * Q * N, HBM, "GB/s", Q=Q, N=N)
     ms = timeit(lambda: ops.fuse_none(planes, None, w))
     emit(f"fuse_none_kernel S={S}", ms, (S * 4 + 8) * Q * N, HBM, "GB/s", Q=Q, N=N)
+    for P in (1001,):   # hybrid.py:391-397: quantile tables of 1001 points
+        distr = [torch.quantile(p[:8].flatten()[:1000000].double(), torch.linspace(0, 1, P, device="cuda", dtype=torch.float64)).float().contiguous()
+                 for p in planes]
+        for norm in ("percentile-rank", "normal-curve-equivalent"):
+            ms = timeit(lambda: ops.fuse_nsf(planes, None, w, norm, distr, out=out))
+            emit(f"fuse_nsf_table_kernel<{norm}> S={S} P={P}", ms, (S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
     ms = timeit(lambda: ops.row_stats(planes[0], None, "z-score"))
     emit("row_stats_kernel<z-score>", ms, Q * N * 4, HBM, "GB/s", Q=Q, N=N)
 
