@@ -612,6 +612,8 @@ def _segment_reduce(fn: str, x: torch.Tensor, cu_rows: torch.Tensor) -> torch.Te
     _dev(x, torch.float32, f"{fn}(x)")
     _dev(cu_rows, torch.int32, f"{fn}(cu_rows)")
     B, d = cu_rows.numel() - 1, x.shape[1]
+    if x.shape[0] == 0:     # every sequence empty (an empty tensor has no data pointer to hand over): zeros by definition
+        return torch.zeros((max(B, 0), d), dtype=torch.float32, device=x.device)
     out = torch.empty((max(B, 0), d), dtype=torch.float32, device=x.device)
     check(getattr(_lib.lib(), fn)(_ptr(x), x.stride(0) if x.shape[0] > 1 else d, _ptr(cu_rows), B, d, _ptr(out), d, _stream(x)), fn)
     return out

@@ -176,8 +176,10 @@ def case_maxsim(rng):
     Qtok = rng.normal(0, 1, (Q, Lq, 128)).astype(np.float32)
     Qtok /= np.linalg.norm(Qtok, axis=2, keepdims=True)
     Qtok = Qtok.astype(np.float16)
-    if Dtok.shape[0] == 0:
-        return "maxsim skipped (all documents empty)"
+    if Dtok.shape[0] == 0:   # every document empty: all scores 0
+        got = ops.maxsim(dev(Qtok), torch.zeros((0, 128), dtype=torch.float16, device="cuda"), dev(Doff), max_doc_len=1).cpu().numpy()
+        assert got.shape == (Q, N) and not got.any()
+        return "maxsim with every document empty"
     got = ops.maxsim(dev(Qtok), dev(Dtok), dev(Doff), max_doc_len=int(max(lens.max(), 1))).cpu().numpy()
     exp = oracle.maxsim(Qtok.astype(np.float32), Dtok.astype(np.float32), Doff)
     assert np.max(np.abs(got - exp)) <= 1e-4 * max(1, Lq / 32)

@@ -832,3 +832,15 @@ def test_randomised_soak_short():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_gpu.py"), "--seconds", "15", "--seed", "3"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK:" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_all_empty_inputs_have_defined_results(ops):
+    """Empty tensors carry no data pointer: the all-empty cases are answered before any pointer is needed."""
+    cu = torch.zeros(4, dtype=torch.int32, device="cuda")                      # three empty sequences
+    x = torch.zeros((0, 768), device="cuda")
+    assert not ops.segment_mean(x, cu).any() and ops.segment_mean(x, cu).shape == (3, 768)
+    assert not ops.segment_splade_max(x, cu).any()
+    Qtok = torch.zeros((2, 32, 128), dtype=torch.float16, device="cuda")
+    Doff = torch.zeros(5, dtype=torch.int64, device="cuda")                    # four empty documents
+    s = ops.maxsim(Qtok, torch.zeros((0, 128), dtype=torch.float16, device="cuda"), Doff, max_doc_len=1)
+    assert s.shape == (2, 4) and not s.any()
