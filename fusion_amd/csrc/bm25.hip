@@ -105,8 +105,9 @@ __global__ void bm25_doc_norms_kernel(const int32_t* __restrict__ doc_len, int N
 using namespace fz;
 
 extern "C" int fz_bm25_doc_norms_f64(const int32_t* doc_len, int N, double avgdl, double k1, double b, double* out, void* stream) {
-    if (!doc_len || !out || N < 0) return FZ_ERR_ARG;
-    if (N == 0) return FZ_OK;
+    if (N < 0) return FZ_ERR_ARG;
+    if (N == 0) return FZ_OK;                      // empty tensors carry null pointers
+    if (!doc_len || !out) return FZ_ERR_ARG;
     bm25_doc_norms_kernel<<<(N + 255) / 256, 256, 0, as_stream(stream)>>>(doc_len, N, avgdl, k1, b, out);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
@@ -115,9 +116,9 @@ extern "C" int fz_bm25_doc_norms_f64(const int32_t* doc_len, int N, double avgdl
 extern "C" int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf,
                                   const int32_t* doc_len, const double* doc_norm, double avgdl, double k1, double b, const int64_t* qoff,
                                   const int32_t* qterms, int Q, int N, double* scores, int lds, void* stream) {
-    if (!toff || !idf || !doc_len || !qoff || !scores || Q < 0 || N < 0 || lds < N) return FZ_ERR_ARG;
-    if (Q == 0) return FZ_OK;
-    if (N == 0) return FZ_OK;
+    if (Q < 0 || N < 0 || lds < N) return FZ_ERR_ARG;
+    if (Q == 0 || N == 0) return FZ_OK;           // empty tensors carry null pointers
+    if (!toff || !idf || !doc_len || !qoff || !scores) return FZ_ERR_ARG;
     Bm25Args a{toff, pdoc, ptf, idf, doc_len, doc_norm, avgdl, k1, b, qoff, qterms, N, scores, lds};
     constexpr size_t lds_bytes = (size_t)BM25_SLICE * sizeof(double);
     static bool attr_set = false;

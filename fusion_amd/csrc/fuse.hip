@@ -772,8 +772,9 @@ using namespace fz;
 // =====================================================================================
 extern "C" int fz_row_stats_f32(const float* scores, const int32_t* rank, int rows, int N, int ld, int norm, float* stat_a,
                                 float* stat_b, void* stream) {
-    if (!scores || !stat_a || !stat_b || rows < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
-    if (rows == 0) return FZ_OK;
+    if (rows < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (rows == 0) return FZ_OK;                   // empty tensors carry null pointers
+    if (!scores || !stat_a || !stat_b) return FZ_ERR_ARG;
     row_stats_kernel<512><<<rows, 512, 0, as_stream(stream)>>>(scores, rank, N, ld, norm, stat_a, stat_b);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
@@ -815,9 +816,10 @@ static int launch_nsf(const NsfArgs& a, int Q, float* fused, hipStream_t st) {
 extern "C" int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q,
                                int N, int ld, int norm, const float* const* distr_h, const int32_t* P_h, float* fused,
                                void* stream) {
-    if (!planes_h || !w_h || !fused || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (!planes_h || !w_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
     if (norm == FZ_NORM_NONE) return FZ_ERR_ARG;  // float64 passthrough lives in fz_fuse_none_f64
     if (norm < FZ_NORM_MINMAX || norm > FZ_NORM_NCE) return FZ_ERR_ARG;
+    if (!fused && Q != 0 && N != 0) return FZ_ERR_ARG;   // empty tensors carry null pointers
     const bool needs_distr = (norm == FZ_NORM_PERCENTILE || norm == FZ_NORM_NCE);
     if (needs_distr && (!distr_h || !P_h)) return FZ_ERR_ARG;
     if (Q == 0 || N == 0) return FZ_OK;
@@ -856,8 +858,10 @@ extern "C" int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* cons
 extern "C" int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S,
                                      int Q, int N, int ld, int norm, const float* const* distr_h, const int32_t* P_h,
                                      const float* stat_a, const float* stat_b, float* fused, void* stream) {
-    if (!planes_h || !w_h || !fused || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (!planes_h || !w_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
     if (norm < FZ_NORM_MINMAX || norm > FZ_NORM_NCE) return FZ_ERR_ARG;
+    if (Q == 0 || N == 0) return FZ_OK;                 // empty tensors carry null pointers
+    if (!fused) return FZ_ERR_ARG;
     const bool needs_stats = (norm == FZ_NORM_MINMAX || norm == FZ_NORM_ZSCORE);
     const bool needs_distr = (norm == FZ_NORM_PERCENTILE || norm == FZ_NORM_NCE);
     if (needs_stats && (!stat_a || !stat_b)) return FZ_ERR_ARG;
@@ -956,8 +960,9 @@ static bool elem_aligned(const ElemArgs& a, const void* fused, bool planes) {
 
 extern "C" int fz_fuse_none_f64(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q,
                                 int N, int ld, double* fused, void* stream) {
-    if (!planes_h || !w_h || !fused || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
-    if (Q == 0 || N == 0) return FZ_OK;
+    if (!planes_h || !w_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (Q == 0 || N == 0) return FZ_OK;                 // empty tensors carry null pointers
+    if (!fused) return FZ_ERR_ARG;
     ElemArgs a{};
     a.S = S; a.N = N; a.ld = ld; a.Q = Q;
     for (int s = 0; s < S; ++s) {
@@ -1000,7 +1005,8 @@ extern "C" size_t fz_insertion_order_workspace_bytes(int Q, int N) {
 extern "C" int fz_insertion_order(const int32_t* const* orders_h, const int32_t* lens, int S, int Q, int N, int ld,
                                   int32_t* ins_order, int32_t* U, void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
-    if (!orders_h || !lens || !ins_order || !U || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (!orders_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (Q != 0 && (!lens || !ins_order || !U)) return FZ_ERR_ARG;   // empty tensors carry null pointers
     if (N > 1048576) return FZ_ERR_UNSUPPORTED;
     if (Q == 0) return FZ_OK;
     InsArgs a{};

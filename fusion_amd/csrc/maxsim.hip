@@ -224,7 +224,8 @@ using namespace fz;
 
 extern "C" int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* Doff, int64_t sumL, int max_doc_len, int Q, int Lq, int N,
                              int dim, float* scores, int lds, void* stream) {
-    if (!Qtok || !Doff || !scores || Q < 0 || N < 0 || Lq <= 0 || lds < N) return FZ_ERR_ARG;
+    if (Q < 0 || N < 0 || Lq <= 0 || lds < N) return FZ_ERR_ARG;
+    if ((Q != 0 && N != 0) && (!Qtok || !Doff || !scores)) return FZ_ERR_ARG;   // empty tensors carry null pointers
     if (!Dtok && sumL != 0) return FZ_ERR_ARG;   // an empty token matrix (every document empty) has no pointer to give
     if (dim != MS_DIM) return FZ_ERR_UNSUPPORTED;
     if (Lq % 32 != 0 || (MS_BLOCKS_PER_WAVE % (Lq / 32)) != 0) return FZ_ERR_UNSUPPORTED;  // Lq in {32, 64, 128}

@@ -185,8 +185,9 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void dot_scores_kernel(GemmArgs g)
 using namespace fz;
 
 extern "C" int fz_normalize_rows_f32(const float* X, int rows, int d, int ldx, float* Y, int ldy, void* stream) {
-    if (!X || !Y || rows < 0 || d <= 0 || ldx < d || ldy < d) return FZ_ERR_ARG;
-    if (rows == 0) return FZ_OK;
+    if (rows < 0 || d <= 0 || ldx < d || ldy < d) return FZ_ERR_ARG;
+    if (rows == 0) return FZ_OK;                   // empty tensors carry null pointers
+    if (!X || !Y) return FZ_ERR_ARG;
     const int vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0);
     normalize_rows_kernel<<<(rows + 3) / 4, 256, 0, as_stream(stream)>>>(X, rows, d, ldx, Y, ldy, vec);
     FZ_LAUNCH_CHECK();
@@ -195,8 +196,9 @@ extern "C" int fz_normalize_rows_f32(const float* X, int rows, int d, int ldx, f
 
 extern "C" int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int ldd, int Q, int N, int d, float* scores, int lds,
                                  void* stream) {
-    if (!Qn || !Dn || !scores || Q < 0 || N < 0 || d <= 0 || ldq < d || ldd < d || lds < N) return FZ_ERR_ARG;
-    if (Q == 0 || N == 0) return FZ_OK;
+    if (Q < 0 || N < 0 || d <= 0 || ldq < d || ldd < d || lds < N) return FZ_ERR_ARG;
+    if (Q == 0 || N == 0) return FZ_OK;           // empty tensors carry null pointers
+    if (!Qn || !Dn || !scores) return FZ_ERR_ARG;
     // 16-byte vector staging: the Python binding pads embeddings to a multiple of 4 floats
     if ((d % 4) || (ldq % 4) || (ldd % 4) || ((uintptr_t)Qn % 16) || ((uintptr_t)Dn % 16)) return FZ_ERR_UNSUPPORTED;
     GemmArgs g{};

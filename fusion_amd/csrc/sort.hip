@@ -582,10 +582,10 @@ extern "C" size_t fz_topk_update_workspace_bytes(int rows, int k, int cap) {
 extern "C" int fz_topk_update_f32(const float* scores, int rows, int n, int ld, int64_t id_base, const float* run_scores,
                                   const int64_t* run_ids, int k, int cap, float* new_scores, int64_t* new_ids, int32_t* overflow,
                                   void* workspace, size_t workspace_bytes, void* stream) {
-    if (!scores || !run_scores || !run_ids || !new_scores || !new_ids || !overflow || rows < 0 || n < 0 || ld < n || k <= 0 || cap <= 0)
-        return FZ_ERR_ARG;
+    if (rows < 0 || n < 0 || ld < n || k <= 0 || cap <= 0) return FZ_ERR_ARG;
     if ((long)k + cap > 35840) return FZ_ERR_UNSUPPORTED;
-    if (rows == 0) return FZ_OK;
+    if (rows == 0) return FZ_OK;                   // empty tensors carry null pointers
+    if (!run_scores || !run_ids || !new_scores || !new_ids || !overflow || (!scores && n > 0)) return FZ_ERR_ARG;
     if (!workspace || workspace_bytes < fz_topk_update_workspace_bytes(rows, k, cap)) return FZ_ERR_WORKSPACE;
     hipStream_t st = as_stream(stream);
     char* ws = reinterpret_cast<char*>(workspace);
@@ -606,7 +606,8 @@ extern "C" int fz_topk_update_f32(const float* scores, int rows, int n, int ld, 
 
 extern "C" int fz_topk_merge(const float* in_scores, const int64_t* in_ids, int G, int rows, int k, float* out_scores,
                              int64_t* out_ids, void* stream) {
-    if (!in_scores || !in_ids || !out_scores || !out_ids || G <= 0 || rows < 0 || k <= 0) return FZ_ERR_ARG;
+    if (G <= 0 || rows < 0 || k <= 0) return FZ_ERR_ARG;
+    if (rows != 0 && (!in_scores || !in_ids || !out_scores || !out_ids)) return FZ_ERR_ARG;   // empty tensors carry null pointers
     if ((long)G * k > 35840) return FZ_ERR_UNSUPPORTED;
     if (rows == 0) return FZ_OK;
     SortArgs a{};

@@ -104,8 +104,9 @@ extern "C" int fz_tune_max_gold(void) { return TUNE_G; }
 
 extern "C" int fz_gold_ranks_f32(const float* const* T_h, const int32_t* pos, const float* weights, const int32_t* gold, int S, int W,
                                  int Q, int N, int ld, int32_t* out_ranks, void* stream) {
-    if (!T_h || !pos || !weights || !gold || !out_ranks || S <= 0 || S > FZ_MAX_SYSTEMS || W < 0 || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
-    if (W == 0 || Q == 0 || N == 0) return FZ_OK;
+    if (!T_h || S <= 0 || S > FZ_MAX_SYSTEMS || W < 0 || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (W == 0 || Q == 0 || N == 0) return FZ_OK;   // empty tensors carry null pointers
+    if (!pos || !weights || !gold || !out_ranks) return FZ_ERR_ARG;
     TuneArgs a{};
     for (int s = 0; s < S; ++s) { if (!T_h[s]) return FZ_ERR_ARG; a.T[s] = T_h[s]; }
     a.pos = pos; a.weights = weights; a.gold = gold; a.out = out_ranks; a.S = S; a.W = W; a.Q = Q; a.N = N; a.ld = ld;

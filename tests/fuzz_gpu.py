@@ -273,7 +273,28 @@ def case_segments(rng):
     return f"segments {'splade-max' if splade else 'mean'} lens={len(lens)} d={d}"
 
 
-CASES = [case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
+def case_empty(rng):
+    """Zero-sized batches: every op returns an empty (or all-default) result without touching a pointer."""
+    n = int(rng.integers(1, 500))
+    z = lambda *sh, dt=torch.float32: torch.zeros(sh, dtype=dt, device="cuda")
+    o, sk, r = ops.sort_rows_desc(z(0, n), want_rank=True)
+    assert o.shape == (0, n) and r.shape == (0, n)
+    lens = torch.zeros((2, 0), dtype=torch.int32, device="cuda")
+    assert ops.fuse_rank([z(0, n, dt=torch.int32), z(0, n, dt=torch.int32)], lens, "rrf").shape == (0, n)
+    for norm in ("min-max", "z-score", "arctan"):
+        assert ops.fuse_nsf([z(0, n), z(0, n)], None, [0.5, 0.5], norm).shape == (0, n)
+    assert ops.fuse_none([z(0, n)], None, [1.0]).shape == (0, n)
+    assert ops.cos_scores(z(0, 8), z(n, 8)).shape == (0, n)
+    assert ops.cos_scores(z(3, 8), z(0, 8)).shape == (3, 0)
+    s_, i_ = ops.topk_rows(z(0, n), min(n, 5))
+    assert s_.shape[0] == 0
+    strips, cu = ops.attn_strips(np.zeros(0, dtype=np.int64))
+    assert ops.attn_varlen(z(0, 3 * 64), torch.from_numpy(strips).cuda().view(-1, 4), 1).shape == (0, 64)
+    assert ops.add_layernorm(z(0, 64), None, z(64), z(64), 1e-5).shape == (0, 64)
+    return f"empty batches n={n}"
+
+
+CASES = [case_empty, case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
          case_topk_stream, case_segments]
 
 
