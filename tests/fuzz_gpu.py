@@ -273,6 +273,48 @@ def case_segments(rng):
     return f"segments {'splade-max' if splade else 'mean'} lens={len(lens)} d={d}"
 
 
+def case_lists(rng):
+    """The reference's interchange type end to end: Aggregator.fuse on python ranked lists vs the oracle's fuse_lists."""
+    from fusion_amd.retrievers.hybrid import Aggregator
+    S, Q, N = int(rng.integers(1, 5)), int(rng.integers(1, 4)), int(rng.integers(1, 250))
+    names = ["bm25", "dpr", "splade", "colbert"][:S]
+    ids = rng.choice(100000, size=N, replace=False)
+    lists = {}
+    for n in names:
+        per_q = []
+        for _ in range(Q):
+            k = int(rng.integers(0, N + 1)) if rng.random() < 0.5 else N
+            sub = rng.choice(N, size=k, replace=False)
+            sc = rand_keys(rng, 1, max(k, 1), np.float32)[0][:k]
+            sc[~np.isfinite(sc)] = 0.0
+            o = np.argsort(-sc, kind="stable")
+            per_q.append([{"corpus_id": int(ids[sub[j]]), "score": float(sc[j])} for j in o])
+        lists[n] = per_q
+    if all(len(l) == 0 for n in names for l in lists[n]):
+        return "lists skipped (all empty)"
+    method = str(rng.choice(["rrf", "bcf", "nsf"]))
+    norm = str(rng.choice(["none", "min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent"])) if method == "nsf" else "none"
+    w = {n: float(x) for n, x in zip(names, rng.dirichlet(np.ones(S)))}
+    distr = {n: np.sort(rng.normal(0, 1, int(rng.integers(2, 200)))).astype(np.float32) for n in names}
+    got = Aggregator.fuse(lists, method=method, normalization=norm, linear_weights=w, percentile_distributions=distr)
+    exp = oracle.fuse_lists(lists, method, norm, w, distr)
+    exact = method in ("rrf", "bcf") or norm in ("none", "min-max", "percentile-rank")
+    tol = {"z-score": 2e-6, "arctan": 1e-6, "normal-curve-equivalent": 1e-4}.get(norm, 0.0)
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        assert len(g) == len(e)
+        if exact:
+            assert [x["corpus_id"] for x in g] == [x["corpus_id"] for x in e]
+            np.testing.assert_array_equal(np.array([float(x["score"]) for x in g]), np.array([float(x["score"]) for x in e]))
+        else:
+            ed = {x["corpus_id"]: float(x["score"]) for x in e}
+            assert sorted(ed) == sorted(x["corpus_id"] for x in g)
+            for x in g:
+                a, b = float(x["score"]), ed[x["corpus_id"]]
+                assert (np.isnan(a) and np.isnan(b)) or a == b or abs(a - b) <= tol * max(1.0, abs(b)), (norm, a, b)
+    return f"lists {method}/{norm} S={S} Q={Q} N={N}"
+
+
 def case_empty(rng):
     """Zero-sized batches: every op returns an empty (or all-default) result without touching a pointer."""
     n = int(rng.integers(1, 500))
@@ -294,7 +336,7 @@ def case_empty(rng):
     return f"empty batches n={n}"
 
 
-CASES = [case_empty, case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
+CASES = [case_lists, case_empty, case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
          case_topk_stream, case_segments]
 
 
