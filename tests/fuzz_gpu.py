@@ -315,6 +315,32 @@ def case_lists(rng):
     return f"lists {method}/{norm} S={S} Q={Q} N={N}"
 
 
+_ENC = {}
+
+
+def case_encoder(rng):
+    """Padding-free forward (HIP attention / residual+LayerNorm / pooling on packed rows) vs the HF module on padded batches."""
+    from fusion_amd import encoders
+    if not _ENC:
+        cfg = dict(encoders.TINY, hidden_size=128, num_attention_heads=2, intermediate_size=256)
+        torch.manual_seed(0)
+        _ENC["dpr"] = encoders.DenseEncoder(encoders._backbone(cfg), encoders.HashTokenizer(cfg["vocab_size"]), "cuda")
+        _ENC["cfg"] = cfg
+    enc, cfg = _ENC["dpr"], _ENC["cfg"]
+    n, Lmax = int(rng.integers(1, 40)), int(rng.integers(1, 128))
+    lens = rng.integers(1, Lmax + 1, n)
+    ids = np.full((n, Lmax), cfg["pad_token_id"], dtype=np.int64)
+    for i, L in enumerate(lens):
+        ids[i, :L] = rng.integers(7, cfg["vocab_size"], size=L)
+    I = torch.from_numpy(ids).cuda()
+    M = (torch.arange(Lmax, device="cuda")[None, :] < torch.from_numpy(lens).cuda()[:, None]).long()
+    a = enc.encode_ids(I, M)
+    b = enc.encode_ids_packed(I, lens)
+    err = (a - b).abs().max().item()
+    assert b.shape == a.shape and err <= 5e-5, err
+    return f"encoder n={n} Lmax={Lmax} err={err:.1e}"
+
+
 def case_empty(rng):
     """Zero-sized batches: every op returns an empty (or all-default) result without touching a pointer."""
     n = int(rng.integers(1, 500))
@@ -336,7 +362,7 @@ def case_empty(rng):
     return f"empty batches n={n}"
 
 
-CASES = [case_lists, case_empty, case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
+CASES = [case_encoder, case_lists, case_empty, case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
          case_topk_stream, case_segments]
 
 
