@@ -49,6 +49,8 @@ def parse():
                    help="packed: padding-free token rows, HIP attention/LayerNorm/pooling kernels between the hipBLASLt GEMMs; fused: lean torch forward, "
                         "linears over all length buckets' tokens at once; hf: the HF module per length bucket")
     p.add_argument("--overlap-bm25", action="store_true", help="run the BM25 branch on a second stream next to the encoder (measured: no gain, the encoder saturates the GPU)")
+    p.add_argument("--no-gemm-tuning", action="store_true",
+                   help="leave the encoder's fp32 Linears to the library heuristics instead of PyTorch TunableOp (fusion_amd/tuned/gemm_gfx950.csv)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--mmarco-docs", type=int, default=8841823)
     p.add_argument("--topk", type=int, default=1000)
@@ -92,6 +94,8 @@ def build_lleqa(args, dev, rank):
     # encoder + query tokens (LLeQA questions: ~15-40 word pieces, padded to the batch maximum <= 64)
     if not args.no_encode:
         enc = encoders.random_init("dpr", device=dev, size=args.encoder_size, seed=0)
+        if not args.no_gemm_tuning and args.encode_mode == "packed":
+            encoders.enable_gemm_tuning()      # TunableOp picks the hipBLASLt / rocBLAS solution per Linear shape (same fp32 arithmetic)
         d = enc.dim
         L = 64
         qlen = rng.integers(8, L + 1, Q)

@@ -114,6 +114,8 @@ def bench_sharded(args, dev, rank, world, dist):
     rng = np.random.default_rng(5)
     if not args.no_encode:
         enc = encoders.random_init("dpr", device=dev, size=args.encoder_size, seed=0)
+        if not getattr(args, "no_gemm_tuning", False):
+            encoders.enable_gemm_tuning()
         L = 64
         qlen = rng.integers(8, L + 1, Q)
         ids = rng.integers(7, enc.backbone.config.vocab_size - 1, (Q, L))

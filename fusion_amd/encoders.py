@@ -15,6 +15,7 @@ With real checkpoints on disk, `from_pretrained()` loads them through transforme
 from __future__ import annotations
 
 import hashlib
+import os
 
 import torch
 import torch.nn as nn
@@ -178,12 +179,34 @@ class FusedBertForward:
         return out
 
 
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_gfx950.csv")
+
+
+def enable_gemm_tuning(results_file: str | None = TUNED_GEMMS, max_duration_ms: int = 30) -> None:
+    """Let PyTorch's TunableOp pick the hipBLASLt / rocBLAS solution of every fp32 Linear shape (process-wide switch).
+    The library heuristics leave 10 % on the table at the encoder's shapes (M = 37 k packed rows: QKV 1.03 -> 0.91 ms, out
+    0.37 -> 0.31, FFN 1.27 / 1.30 -> 1.20 / 1.15; same fp32-MFMA arithmetic).  Results recorded in `results_file` (this image's
+    library versions; TunableOp ignores the file if its validators differ) are reused; a shape that is not in it is tuned on
+    first use (a fraction of a second per shape) -- PackedBertForward pads its row count to a multiple of 512 while tuning is
+    on, so batches of similar size share their entries.  New results go to a scratch file, never into the package."""
+    import tempfile
+    import torch.cuda.tunable as tn
+    tn.enable(True)
+    tn.tuning_enable(True)
+    tn.set_max_tuning_duration(int(max_duration_ms))
+    tn.set_filename(os.path.join(tempfile.gettempdir(), f"fusion_amd_tunableop_{os.getpid()}.csv"))
+    if results_file and os.path.exists(results_file):
+        tn.read_file(results_file)
+
+
 class PackedBertForward(FusedBertForward):
     """The same forward with NO padding anywhere: token rows of all sequences are packed back to back ([T, hidden], T = the
     real token count -- 9 % fewer rows than eight length buckets at the LLeQA query-length mix), the Linears run on the
     packed rows, and the parts that need sequence boundaries are the library's HIP kernels (include/fusion_hip.h):
     fz_attn_varlen_f32 (attention straight from the fused-QKV rows, no gather/scatter, no mask), fz_add_layernorm_f32
     (residual + LayerNorm in one pass) and fz_segment_mean_f32 (mean Pooling).  head_dim must be 64 (BERT-base family)."""
+
+    ROW_GRANULE = 512
 
     @staticmethod
     def supports(config) -> bool:
@@ -214,19 +237,27 @@ class PackedBertForward(FusedBertForward):
         host = np.concatenate([np.repeat(np.arange(n, dtype=np.int64) * Lmax, lengths) + cols, cols + (self.pad_idx + 1)])
         meta = torch.from_numpy(host).to(dev, non_blocking=True)                       # one upload: gather indices + position ids
         ids = input_ids.reshape(-1)[meta[:T]]
-        x = self.word[ids]
-        x += self.pos[meta[T:]]
-        x += self.type0
+        # while GEMM tuning is on, the row count is padded to a multiple of ROW_GRANULE (zero rows: every op between the GEMMs is
+        # row-wise, so they never touch a real row) -- tuned solutions are keyed by the exact shape
+        Tp = -(-T // self.ROW_GRANULE) * self.ROW_GRANULE if torch.cuda.tunable.is_enabled() else T
+        x = torch.zeros((Tp, self.word.shape[1]), dtype=torch.float32, device=dev) if Tp != T else None
+        if x is None:
+            x = self.word[ids]
+        else:
+            x[:T] = self.word[ids]
+        x[:T] += self.pos[meta[T:]]
+        x[:T] += self.type0
         x = ops.add_layernorm(x, None, *self.emb_ln)
+        ctx = torch.zeros_like(x)                 # attention writes the real rows of this buffer in every layer
         for ly in self.layers:
             qkv = F.linear(x, ly["wqkv"], ly["bqkv"])
             if mark: mark("encode")
-            ctx = ops.attn_varlen(qkv, strips_d, H)
+            ops.attn_varlen(qkv, strips_d, H, out=ctx)
             if mark: mark("encode_attn")
             x = ops.add_layernorm(F.linear(ctx, ly["wo"], ly["bo"]), x, *ly["ln1"])
             h = F.gelu(F.linear(x, ly["w1"], ly["b1"]))
             x = ops.add_layernorm(F.linear(h, ly["w2"], ly["b2"]), x, *ly["ln2"])
-        return x, cu_d
+        return x[:T], cu_d
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, lengths, n_buckets: int = 0, mark=None) -> torch.Tensor:

@@ -715,6 +715,15 @@ def test_packed_encoder_matches_hf_forward():
     for i, t in enumerate(texts):
         ids1, m1 = enc.tokenizer([t], enc.max_doc_length)
         assert (enc.encode_ids(ids1.cuda(), m1.cuda())[0] - e[i]).abs().max().item() <= 5e-5
+    # with GEMM tuning on, the packed row count is padded to a multiple of 512 (tuned solutions are keyed by shape): same result
+    import torch.cuda.tunable as tn
+    real = tn.is_enabled
+    try:
+        tn.is_enabled = lambda: True          # the padding path only; no tuning is triggered
+        c = enc.encode_ids_packed(I, lens)
+    finally:
+        tn.is_enabled = real
+    assert (c - b).abs().max().item() <= 1e-6
     with pytest.raises(ValueError):
         encoders.random_init("dpr", "cuda", size="tiny").encode_ids_packed(I[:, :32] % 500, np.minimum(lens, 32))   # head_dim 16
 
