@@ -217,7 +217,7 @@ def measured_traffic(stage, st):
         return None
     key = {"dpr_score": "fz::dot_scores_kernel<true>(fz::GemmArgs)", "dpr_rank": "fz::sort_rows_kernel<1024, 28, 1>(fz::SortArgs)",
            "bm25_rank": "fz::sort_rows_kernel<1024, 28, 2>(fz::SortArgs)", "final_order": "fz::sort_rows_kernel<1024, 28, 2>(fz::SortArgs)",
-           "fuse_rrf": "fz::fuse_rank_kernel<true>(fz::ElemArgs, double*)", "encode_attn": "fz::attn_varlen_kernel(fz::AttnArgs)"}.get(stage)
+           "fuse_rrf": "fz::fuse_rank_kernel<true>(fz::ElemArgs, double*)", "encode_attn": "fz::attn_varlen_kernel<2>(fz::AttnArgs)"}.get(stage)
     return t.get(key, {}).get("hbm_bytes_corrected")
 
 
