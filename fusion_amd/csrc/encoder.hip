@@ -233,6 +233,60 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     }
 }
 
+// Embedding sum + LayerNorm of a BERT/RoBERTa embedding block for packed rows: out[t] = LN(word[ids[t]] + pos[pos_ids[t]] + type0)
+// (token type 0 everywhere: single-segment inputs).  One wave per row, one pass; VPL float4 per lane.
+template <int VPL>
+__global__ __launch_bounds__(256) void embed_layernorm_kernel(const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type0,
+                                                              const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_ids,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int rows,
+                                                              int d, float* __restrict__ out, int ldo) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nv = d >> 2;
+    const float4* w = reinterpret_cast<const float4*>(word + (size_t)ids[row] * d);
+    const float4* p = reinterpret_cast<const float4*>(pos + (size_t)pos_ids[row] * d);
+    const float4* ty = reinterpret_cast<const float4*>(type0);
+    float4 v[VPL];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            const float4 a = w[c], b = p[c], t = ty[c];
+            float4 x;   // (word + type) + position: the order of the HF embedding modules
+            x.x = (a.x + t.x) + b.x; x.y = (a.y + t.y) + b.y; x.z = (a.z + t.z) + b.z; x.w = (a.w + t.w) + b.w;
+            v[i] = x;
+            sum += (x.x + x.y) + (x.z + x.w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_reduce_sum(sum) / (float)d;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_reduce_sum(sq) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[c], b = reinterpret_cast<const float4*>(beta)[c];
+            float4 y;
+            y.x = (v[i].x - mean) * rstd * g.x + b.x;
+            y.y = (v[i].y - mean) * rstd * g.y + b.y;
+            y.z = (v[i].z - mean) * rstd * g.z + b.z;
+            y.w = (v[i].w - mean) * rstd * g.w + b.w;
+            reinterpret_cast<float4*>(out + (size_t)row * ldo)[c] = y;
+        }
+    }
+}
+
 // Per-sequence column reductions over packed rows; one workgroup per (sequence, 1024-column slab).
 //   MODE 0: out[b] = mean of rows [cu[b], cu[b+1])                     (sentence-transformers Pooling(mean))
 //   MODE 1: out[b] = log1p(relu(max of the rows))  = max_t log1p(relu(x_t)), log1p o relu being monotone
@@ -301,6 +355,24 @@ extern "C" int fz_add_layernorm_f32(const float* x, int ldx, const float* res, i
         add_layernorm_kernel<4><<<grid, 256, 0, s>>>(x, ldx, res, ldr, gamma, beta, eps, rows, d, out, ldo);
     else
         add_layernorm_kernel<16><<<grid, 256, 0, s>>>(x, ldx, res, ldr, gamma, beta, eps, rows, d, out, ldo);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+extern "C" int fz_embed_layernorm_f32(const float* word, const float* pos, const float* type0, const int64_t* ids, const int64_t* pos_ids,
+                                      const float* gamma, const float* beta, float eps, int rows, int d, float* out, int ldo, void* stream) {
+    if (rows < 0 || d <= 0) return FZ_ERR_ARG;
+    if (rows == 0) return FZ_OK;
+    if (!word || !pos || !type0 || !ids || !pos_ids || !gamma || !beta || !out || ldo < d) return FZ_ERR_ARG;
+    if ((d & 3) || (ldo & 3) || d > 4096 || !aligned16(word) || !aligned16(pos) || !aligned16(type0) || !aligned16(gamma) || !aligned16(beta) ||
+        !aligned16(out))
+        return FZ_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    hipStream_t s = as_stream(stream);
+    if (d <= 1024)
+        embed_layernorm_kernel<4><<<grid, 256, 0, s>>>(word, pos, type0, ids, pos_ids, gamma, beta, eps, rows, d, out, ldo);
+    else
+        embed_layernorm_kernel<16><<<grid, 256, 0, s>>>(word, pos, type0, ids, pos_ids, gamma, beta, eps, rows, d, out, ldo);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

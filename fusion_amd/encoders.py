@@ -241,13 +241,8 @@ class PackedBertForward(FusedBertForward):
         # row-wise, so they never touch a real row) -- tuned solutions are keyed by the exact shape
         Tp = -(-T // self.ROW_GRANULE) * self.ROW_GRANULE if torch.cuda.tunable.is_enabled() else T
         x = torch.zeros((Tp, self.word.shape[1]), dtype=torch.float32, device=dev) if Tp != T else None
-        if x is None:
-            x = self.word[ids]
-        else:
-            x[:T] = self.word[ids]
-        x[:T] += self.pos[meta[T:]]
-        x[:T] += self.type0
-        x = ops.add_layernorm(x, None, *self.emb_ln)
+        # embedding gather + position + type + LayerNorm in one pass over the packed rows
+        x = ops.embed_layernorm(self.word, self.pos, self.type0, ids, meta[T:], *self.emb_ln, out=x)
         ctx = torch.zeros_like(x)                 # attention writes the real rows of this buffer in every layer
         for ly in self.layers:
             qkv = F.linear(x, ly["wqkv"], ly["bqkv"])

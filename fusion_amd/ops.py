@@ -608,6 +608,25 @@ def add_layernorm(x: torch.Tensor, res: torch.Tensor | None, gamma: torch.Tensor
     return out
 
 
+def embed_layernorm(word: torch.Tensor, pos: torch.Tensor, type0: torch.Tensor, ids: torch.Tensor, pos_ids: torch.Tensor,
+                    gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor | None = None) -> torch.Tensor:
+    """LayerNorm(word[ids] + pos[pos_ids] + type0) for packed rows, one pass; out may be a [>= rows, d] buffer (first rows written)."""
+    for t_, w_ in ((word, "word"), (pos, "pos"), (type0, "type0"), (gamma, "gamma"), (beta, "beta")):
+        _need(_dev(t_, torch.float32, f"embed_layernorm({w_})").is_contiguous(), f"embed_layernorm({w_}) must be contiguous")
+    _dev(ids, torch.int64, "embed_layernorm(ids)"); _dev(pos_ids, torch.int64, "embed_layernorm(pos_ids)")
+    rows, d = ids.numel(), word.shape[1]
+    _need(pos_ids.numel() == rows and ids.is_contiguous() and pos_ids.is_contiguous(), "embed_layernorm: ids and pos_ids must be contiguous and equally long")
+    _need(pos.shape[1] == d and type0.numel() == d and gamma.numel() == d and beta.numel() == d, f"embed_layernorm: tables and parameters must be {d} wide")
+    if out is None:
+        out = torch.empty((rows, d), dtype=torch.float32, device=word.device)
+    else:
+        _dev(out, torch.float32, "embed_layernorm(out)")
+        _need(out.dim() == 2 and out.shape[0] >= rows and out.shape[1] == d, f"embed_layernorm(out): need a [>= {rows}, {d}] buffer")
+    check(_lib.lib().fz_embed_layernorm_f32(_ptr(word), _ptr(pos), _ptr(type0), _ptr(ids), _ptr(pos_ids), _ptr(gamma), _ptr(beta), float(eps), rows, d,
+                                            _ptr(out), out.stride(0) if out.shape[0] > 1 else d, _stream(word)), "fz_embed_layernorm_f32")
+    return out
+
+
 def _segment_reduce(fn: str, x: torch.Tensor, cu_rows: torch.Tensor) -> torch.Tensor:
     _dev(x, torch.float32, f"{fn}(x)")
     _dev(cu_rows, torch.int32, f"{fn}(cu_rows)")

@@ -206,6 +206,11 @@ int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strips, int n_st
  * res nullable.  d % 4 == 0, d <= 4096. */
 int fz_add_layernorm_f32(const float* x, int ldx, const float* res, int ldr, const float* gamma, const float* beta, float eps,
                          int rows, int d, float* out, int ldo, void* stream);
+/* The embedding block of a BERT/RoBERTa encoder on packed rows: out[t] = LayerNorm(word[ids[t]] + pos[pos_ids[t]] + type0) * gamma + beta.
+ * word [V][d], pos [Pmax][d], type0 [d] (token type 0 everywhere); ids / pos_ids [rows] int64 (device), the caller guarantees they
+ * index inside the tables.  d % 4 == 0, d <= 4096. */
+int fz_embed_layernorm_f32(const float* word, const float* pos, const float* type0, const int64_t* ids, const int64_t* pos_ids,
+                           const float* gamma, const float* beta, float eps, int rows, int d, float* out, int ldo, void* stream);
 /* mean Pooling (sentence_transformers Pooling(mean)): out[b] = mean of rows [cu_rows[b], cu_rows[b+1]) of x; zeros for an
  * empty sequence.  cu_rows [B+1] int32 (device). */
 int fz_segment_mean_f32(const float* x, int ldx, const int32_t* cu_rows, int B, int d, float* out, int ldo, void* stream);

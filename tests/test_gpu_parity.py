@@ -853,3 +853,17 @@ def test_all_empty_inputs_have_defined_results(ops):
     Doff = torch.zeros(5, dtype=torch.int64, device="cuda")                    # four empty documents
     s = ops.maxsim(Qtok, torch.zeros((0, 128), dtype=torch.float16, device="cuda"), Doff, max_doc_len=1)
     assert s.shape == (2, 4) and not s.any()
+
+
+def test_embed_layernorm_vs_torch(ops):
+    g = torch.Generator(device="cuda").manual_seed(8)
+    V, P, d, rows = 500, 70, 768, 333
+    word, pos = torch.randn((V, d), generator=g, device="cuda"), torch.randn((P, d), generator=g, device="cuda")
+    type0, gamma, beta = (torch.randn(d, generator=g, device="cuda") for _ in range(3))
+    ids = torch.randint(0, V, (rows,), generator=g, device="cuda")
+    pid = torch.randint(0, P, (rows,), generator=g, device="cuda")
+    buf = torch.zeros((rows + 7, d), device="cuda")
+    out = ops.embed_layernorm(word, pos, type0, ids, pid, gamma, beta, 1e-5, out=buf)
+    ref = torch.nn.functional.layer_norm((word[ids] + type0 + pos[pid]).double(), (d,), gamma.double(), beta.double(), 1e-5)
+    assert out is buf and not buf[rows:].any()                     # rows past the batch are left alone
+    assert (buf[:rows].double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
