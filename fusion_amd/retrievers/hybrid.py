@@ -432,6 +432,8 @@ def main(args):
     from .. import encoders
     sep = f"#{'-' * 40}#"
     os.makedirs(args.output_dir, exist_ok=True)
+    if os.environ.get("FUSION_AMD_TUNE_GEMMS") == "1":   # opt-in: process-wide PyTorch switch (see encoders.enable_gemm_tuning)
+        encoders.enable_gemm_tuning()
     args.eval_type = ("in" if args.models_domain == "legal" else "out") + "domain"
     print("Loading corpus and queries...")
     corpus, queries, pos_pids = load_data(args)
