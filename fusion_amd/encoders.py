@@ -202,9 +202,10 @@ def enable_gemm_tuning(results_file: str | None = TUNED_GEMMS, max_duration_ms: 
 class PackedBertForward(FusedBertForward):
     """The same forward with NO padding anywhere: token rows of all sequences are packed back to back ([T, hidden], T = the
     real token count -- 9 % fewer rows than eight length buckets at the LLeQA query-length mix), the Linears run on the
-    packed rows, and the parts that need sequence boundaries are the library's HIP kernels (include/fusion_hip.h):
-    fz_attn_varlen_f32 (attention straight from the fused-QKV rows, no gather/scatter, no mask), fz_add_layernorm_f32
-    (residual + LayerNorm in one pass) and fz_segment_mean_f32 (mean Pooling).  head_dim must be 64 (BERT-base family)."""
+    packed rows, and everything between them is the library's HIP kernels (include/fusion_hip.h): fz_embed_layernorm_f32
+    (embedding gather + sum + LayerNorm), fz_attn_varlen_f32 (attention straight from the fused-QKV rows, no gather/scatter,
+    no mask), fz_add_layernorm_f32 (residual + LayerNorm in one pass) and fz_segment_mean_f32 (mean Pooling); GELU is torch's.
+    head_dim must be 64 (BERT-base family)."""
 
     ROW_GRANULE = 512
 
