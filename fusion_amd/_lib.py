@@ -68,6 +68,7 @@ _PROTOS = {
     "fz_gold_ranks_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fz_attn_varlen_f32": (_i, [_vp, _i, _vp, _i, _i, _i, C.c_float, _vp, _i, _vp]),
     "fz_add_layernorm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, C.c_float, _i, _i, _vp, _i, _vp]),
+    "fz_gelu_f32": (_i, [_vp, _vp, _sz, _vp]),
     "fz_embed_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i, _i, _vp, _i, _vp]),
     "fz_segment_mean_f32": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     "fz_segment_splade_max_f32": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp]),

@@ -233,6 +233,21 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     }
 }
 
+// erf-GELU of the FFN activations (BERT / CamemBERT "gelu"): y = 0.5 x (1 + erf(x / sqrt 2)), the expression and float precision of
+// torch.nn.functional.gelu.  The input is streamed exactly once (non-temporal loads); the output feeds the next GEMM (plain stores).
+__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(x) + i);
+        float4 o;
+        o.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752440f));
+        o.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752440f));
+        o.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752440f));
+        o.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752440f));
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
 // Embedding sum + LayerNorm of a BERT/RoBERTa embedding block for packed rows: out[t] = LN(word[ids[t]] + pos[pos_ids[t]] + type0)
 // (token type 0 everywhere: single-segment inputs).  One wave per row, one pass; VPL float4 per lane.
 template <int VPL>
@@ -355,6 +370,17 @@ extern "C" int fz_add_layernorm_f32(const float* x, int ldx, const float* res, i
         add_layernorm_kernel<4><<<grid, 256, 0, s>>>(x, ldx, res, ldr, gamma, beta, eps, rows, d, out, ldo);
     else
         add_layernorm_kernel<16><<<grid, 256, 0, s>>>(x, ldx, res, ldr, gamma, beta, eps, rows, d, out, ldo);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+extern "C" int fz_gelu_f32(const float* x, float* y, size_t count, void* stream) {
+    if (count == 0) return FZ_OK;
+    if (!x || !y) return FZ_ERR_ARG;
+    if ((count & 3) || !aligned16(x) || !aligned16(y)) return FZ_ERR_UNSUPPORTED;
+    const size_t n4 = count >> 2;
+    const size_t blocks = (n4 + 255) / 256;
+    gelu_kernel<<<(unsigned)(blocks < 256 * 32 ? blocks : 256 * 32), 256, 0, as_stream(stream)>>>(x, y, n4);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

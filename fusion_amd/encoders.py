@@ -119,6 +119,8 @@ class FusedBertForward:
         self.emb_ln = (emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps)
         self.pad_idx = emb.padding_idx if getattr(emb, "padding_idx", None) is not None else backbone.config.pad_token_id
         self.heads = backbone.config.num_attention_heads
+        if getattr(backbone.config, "hidden_act", "gelu") != "gelu":
+            raise ValueError(f"{type(self).__name__}: hidden_act {backbone.config.hidden_act!r} is not the erf GELU this forward applies")
         self.layers = []
         for lyr in backbone.encoder.layer:
             a, o = lyr.attention.self, lyr.attention.output
@@ -204,14 +206,15 @@ class PackedBertForward(FusedBertForward):
     real token count -- 9 % fewer rows than eight length buckets at the LLeQA query-length mix), the Linears run on the
     packed rows, and everything between them is the library's HIP kernels (include/fusion_hip.h): fz_embed_layernorm_f32
     (embedding gather + sum + LayerNorm), fz_attn_varlen_f32 (attention straight from the fused-QKV rows, no gather/scatter,
-    no mask), fz_add_layernorm_f32 (residual + LayerNorm in one pass) and fz_segment_mean_f32 (mean Pooling); GELU is torch's.
+    no mask), fz_add_layernorm_f32 (residual + LayerNorm in one pass), fz_gelu_f32 (the FFN's erf GELU, in place) and fz_segment_mean_f32 (mean Pooling).
     head_dim must be 64 (BERT-base family)."""
 
     ROW_GRANULE = 512
 
     @staticmethod
     def supports(config) -> bool:
-        return config.hidden_size == 64 * config.num_attention_heads
+        # 64-wide heads (the attention kernel) and the exact erf GELU (fz_gelu_f32): the BERT-base / CamemBERT family
+        return config.hidden_size == 64 * config.num_attention_heads and getattr(config, "hidden_act", "gelu") == "gelu"
 
     @torch.no_grad()
     def hidden(self, input_ids: torch.Tensor, lengths, mark=None):
@@ -251,7 +254,7 @@ class PackedBertForward(FusedBertForward):
             ops.attn_varlen(qkv, strips_d, H, out=ctx)
             if mark: mark("encode_attn")
             x = ops.add_layernorm(F.linear(ctx, ly["wo"], ly["bo"]), x, *ly["ln1"])
-            h = F.gelu(F.linear(x, ly["w1"], ly["b1"]))
+            h = ops.gelu_(F.linear(x, ly["w1"], ly["b1"]))          # in place, non-temporal loads
             x = ops.add_layernorm(F.linear(h, ly["w2"], ly["b2"]), x, *ly["ln2"])
         return x[:T], cu_d
 

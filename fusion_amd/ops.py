@@ -608,6 +608,14 @@ def add_layernorm(x: torch.Tensor, res: torch.Tensor | None, gamma: torch.Tensor
     return out
 
 
+def gelu_(x: torch.Tensor) -> torch.Tensor:
+    """In-place erf-GELU of a contiguous fp32 tensor (torch.nn.functional.gelu's expression)."""
+    _dev(x, torch.float32, "gelu_(x)")
+    _need(x.is_contiguous() and x.numel() % 4 == 0, "gelu_: contiguous tensor with a multiple of 4 elements")
+    check(_lib.lib().fz_gelu_f32(_ptr(x), _ptr(x), x.numel(), _stream(x)), "fz_gelu_f32")
+    return x
+
+
 def embed_layernorm(word: torch.Tensor, pos: torch.Tensor, type0: torch.Tensor, ids: torch.Tensor, pos_ids: torch.Tensor,
                     gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor | None = None) -> torch.Tensor:
     """LayerNorm(word[ids] + pos[pos_ids] + type0) for packed rows, one pass; out may be a [>= rows, d] buffer (first rows written)."""

@@ -206,6 +206,9 @@ int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strips, int n_st
  * res nullable.  d % 4 == 0, d <= 4096. */
 int fz_add_layernorm_f32(const float* x, int ldx, const float* res, int ldr, const float* gamma, const float* beta, float eps,
                          int rows, int d, float* out, int ldo, void* stream);
+/* y = 0.5 x (1 + erf(x / sqrt 2)) elementwise (the exact "gelu" of BERT / CamemBERT, torch.nn.functional.gelu), count floats,
+ * count % 4 == 0, 16-byte aligned; y may alias x. */
+int fz_gelu_f32(const float* x, float* y, size_t count, void* stream);
 /* The embedding block of a BERT/RoBERTa encoder on packed rows: out[t] = LayerNorm(word[ids[t]] + pos[pos_ids[t]] + type0) * gamma + beta.
  * word [V][d], pos [Pmax][d], type0 [d] (token type 0 everywhere); ids / pos_ids [rows] int64 (device), the caller guarantees they
  * index inside the tables.  d % 4 == 0, d <= 4096. */

@@ -867,3 +867,12 @@ def test_embed_layernorm_vs_torch(ops):
     ref = torch.nn.functional.layer_norm((word[ids] + type0 + pos[pid]).double(), (d,), gamma.double(), beta.double(), 1e-5)
     assert out is buf and not buf[rows:].any()                     # rows past the batch are left alone
     assert (buf[:rows].double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_gelu_matches_torch(ops):
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn((1234, 3072), generator=g, device="cuda") * 3
+    ref = torch.nn.functional.gelu(x)
+    y = ops.gelu_(x.clone())
+    assert (y - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())   # same float expression; erff may differ in the last ulp
+    assert ops.gelu_(torch.zeros((0, 8), device="cuda")).numel() == 0
