@@ -193,6 +193,7 @@ def enable_gemm_tuning(results_file: str | None = TUNED_GEMMS, max_duration_ms: 
     on, so batches of similar size share their entries.  New results go to a scratch file, never into the package."""
     import tempfile
     import torch.cuda.tunable as tn
+    torch.cuda.init()            # the recorded results are validated against the live device / library versions
     tn.enable(True)
     tn.tuning_enable(True)
     tn.set_max_tuning_duration(int(max_duration_ms))
