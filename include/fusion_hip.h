@@ -202,14 +202,16 @@ int fz_gold_ranks_f32(const float* const* T_h, const int32_t* pos, const float* 
  * out [T][ldo], H*head_dim wide. */
 int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
                        float* out, int ldo, void* stream);
-/* out = LayerNorm(x + res) * gamma + beta over the last dimension d (biased variance, as torch.nn.LayerNorm);
+/* Inside the model forward of model.encode(...) (hybrid.py:101-102): every BERT sub-layer ends with
+ * out = LayerNorm(x + res) * gamma + beta over the last dimension d (biased variance, as torch.nn.LayerNorm);
  * res nullable.  d % 4 == 0, d <= 4096. */
 int fz_add_layernorm_f32(const float* x, int ldx, const float* res, int ldr, const float* gamma, const float* beta, float eps,
                          int rows, int d, float* out, int ldo, void* stream);
-/* y = 0.5 x (1 + erf(x / sqrt 2)) elementwise (the exact "gelu" of BERT / CamemBERT, torch.nn.functional.gelu), count floats,
+/* The FFN activation of the same forward (hybrid.py:101-102):
+ * y = 0.5 x (1 + erf(x / sqrt 2)) elementwise (the exact "gelu" of BERT / CamemBERT, torch.nn.functional.gelu), count floats,
  * count % 4 == 0, 16-byte aligned; y may alias x. */
 int fz_gelu_f32(const float* x, float* y, size_t count, void* stream);
-/* The embedding block of a BERT/RoBERTa encoder on packed rows: out[t] = LayerNorm(word[ids[t]] + pos[pos_ids[t]] + type0) * gamma + beta.
+/* The embedding block of the same forward (hybrid.py:101-102) on packed rows: out[t] = LayerNorm(word[ids[t]] + pos[pos_ids[t]] + type0) * gamma + beta.
  * word [V][d], pos [Pmax][d], type0 [d] (token type 0 everywhere); ids / pos_ids [rows] int64 (device), the caller guarantees they
  * index inside the tables.  d % 4 == 0, d <= 4096. */
 int fz_embed_layernorm_f32(const float* word, const float* pos, const float* type0, const int64_t* ids, const int64_t* pos_ids,
