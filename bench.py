@@ -368,7 +368,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if not args.no_encode else "f32", "data": "synthetic",
             "config": {"workload": f"LLeQA-shaped BM25+DPR RRF hybrid: Q={Q} queries/GPU x N={N} articles, d={d}; "
-                                   f"{'CamemBERT-base-shaped fp32 query encoder (random init) + ' if not args.no_encode else 'NO encoder + '}"
+                                   f"{'CamemBERT-base-shaped fp32 query encoder (random init; ' + st.get('encode_mode', '') + ' forward' + ('' if args.no_gemm_tuning or st.get('encode_mode') != 'packed' else ', hipBLASLt solutions recorded with TunableOp') + ') + ' if not args.no_encode else 'NO encoder + '}"
                                    "fp32-MFMA cos-sim + BM25(f64) + full stable ranking + RRF(f64) + final order",
                        "queries_per_gpu": Q, "corpus": N, "dim": d, "fusion": "rrf", "systems": ["bm25", "dpr"],
                        "encode_in_step": not args.no_encode, "parallelism": f"query-sharded x{world}, corpus replicated"},
