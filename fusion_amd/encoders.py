@@ -506,6 +506,15 @@ class CrossEncoder(_Base):
     def predict(self, pairs: list[tuple[str, str]], batch_size: int = 64) -> torch.Tensor:
         out = torch.empty(len(pairs), dtype=torch.float32, device=self._device)
         texts = [q + " </s> " + d for q, d in pairs]    # HashTokenizer has no pair API: the separator is an ordinary token
+        base = getattr(self.model, self.model.base_model_prefix)
+        fwd = self._packed_forward(base) if hasattr(self.model, "classifier") else None
+        if fwd is not None:
+            # padding-free forward; the classification head reads the first token (<s>) of every pair: features[:, 0, :]
+            for idx, ids, lens in _token_batches(self, texts, self.max_length, batch_size):
+                x, cu_d = fwd.hidden(ids.to(self._device, non_blocking=True), lens)
+                first = x.index_select(0, cu_d[:-1].long())
+                out[torch.tensor(idx, device=self._device)] = self.model.classifier(first.unsqueeze(1)).reshape(-1).float()
+            return out
         for idx, ids, mask in self._batches(texts, batch_size, self.max_length):
             logits = self.model(input_ids=ids, attention_mask=mask).logits
             out[torch.tensor(idx, device=self._device)] = logits[:, 0].float()

@@ -876,3 +876,23 @@ def test_gelu_matches_torch(ops):
     y = ops.gelu_(x.clone())
     assert (y - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())   # same float expression; erff may differ in the last ulp
     assert ops.gelu_(torch.zeros((0, 8), device="cuda")).numel() == 0
+
+
+def test_packed_cross_encoder_matches_padded_forward():
+    """monoBERT rerank scores on the padding-free forward == the HF sequence classifier on padded batches (1e-4 abs)."""
+    from fusion_amd import encoders
+    from transformers import CamembertConfig, CamembertForSequenceClassification
+    cfg = dict(encoders.TINY, hidden_size=128, num_attention_heads=2, intermediate_size=256)
+    torch.manual_seed(2)
+    tok = encoders.HashTokenizer(cfg["vocab_size"])
+    ce = encoders.CrossEncoder(CamembertForSequenceClassification(CamembertConfig(num_labels=1, **cfg)), tok, "cuda")
+    rng = np.random.default_rng(2)
+    pairs = [(" ".join(f"q{rng.integers(0, 30)}" for _ in range(int(rng.integers(1, 12)))),
+              " ".join(f"d{rng.integers(0, 60)}" for _ in range(int(rng.integers(1, 100))))) for _ in range(21)]
+    ce.packed_tokens = 300
+    got = ce.predict(pairs, batch_size=4)
+    assert ce._packed is not None and got.shape == (21,)
+    for i, (q, d) in enumerate(pairs):
+        ids1, m1 = tok([q + " </s> " + d], ce.max_length)
+        ref = ce.model(input_ids=ids1.cuda(), attention_mask=m1.cuda()).logits[0, 0]
+        assert abs(float(ref) - float(got[i])) <= 1e-4
