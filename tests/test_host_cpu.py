@@ -259,3 +259,32 @@ def test_corpus_cache_and_cross_encoder(tmp_path):
     assert sorted(x["corpus_id"] for x in out[0]) == [7, 8] and out[0][0]["score"] >= out[0][1]["score"] and out[1][0]["corpus_id"] == 9
     with pytest.raises(NotImplementedError):
         Ranker.cross_encoder_search(["q"], [{1: "d"}], "maastrichtlawtech/monobert-legal-french")
+
+
+def test_attn_strip_table_and_token_batches():
+    """Host helpers of the padding-free encoder: the strip table covers every query row exactly once, longest sequences first;
+    sub-batches are cut by token budget and cover every sentence exactly once."""
+    from fusion_amd import encoders, ops
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 200, 57)
+    strips, cu = ops.attn_strips(lens)
+    assert strips.dtype == np.int32 and strips.shape[1] == 4 and cu.dtype == np.int32 and cu[-1] == lens.sum()
+    covered = np.zeros(int(lens.sum()), dtype=np.int64)
+    for first, L, q0, _ in strips:
+        assert 0 <= q0 < L and q0 % 32 == 0
+        covered[first + q0: first + min(q0 + 32, L)] += 1
+    assert (covered == 1).all()                                   # every token row is a query of exactly one strip
+    assert (np.diff(strips[:, 1]) <= 0).all()                      # longest sequences first
+    assert ops.attn_strips(np.zeros(0, dtype=np.int64))[0].shape == (0, 4)
+
+    enc = encoders.random_init("dpr", device="cpu", size="tiny")
+    enc.packed_tokens = 64
+    texts = [" ".join("w%d" % rng.integers(0, 50) for _ in range(int(k))) for k in rng.integers(1, 40, 33)]
+    seen = []
+    for idx, ids, ln in encoders._token_batches(enc, texts, enc.max_doc_length, 4):
+        assert ids.shape[0] == len(idx) == len(ln) and ids.shape[1] == ln.max()
+        seen += idx
+    assert sorted(seen) == list(range(len(texts)))
+    assert encoders.PackedBertForward.supports(type("C", (), dict(hidden_size=768, num_attention_heads=12, hidden_act="gelu")))
+    assert not encoders.PackedBertForward.supports(type("C", (), dict(hidden_size=64, num_attention_heads=4, hidden_act="gelu")))
+    assert not encoders.PackedBertForward.supports(type("C", (), dict(hidden_size=768, num_attention_heads=12, hidden_act="gelu_new")))
