@@ -64,7 +64,7 @@ struct AttnArgs {
 //     and a wave needs 72 VGPRs per 16 queries instead of 128 per 32.
 // Layouts (16x16x4): A lane l -> row l%16, k-slot l/16; B lane l -> col l%16, k-slot l/16; C reg r -> row 4(l/16)+r, col l%16.
 //   S^T step i pairs dim 16*(l/16) + i of key row l%16 with the same dim of query l%16;
-//   O^T step i takes register i of S^T (key 4(l/16) + i of the tile) against V[that key][16 t + l%16].
+//   O^T step i takes register i of S^T (key 4(l/16) + i of the tile) against V[that key][4 (l%16) + t] (output tile t = dims 4 r + t).
 // NQ = 16-query sub-strips per wave.  NQ = 2: every K/V tile a wave loads serves 32 queries -- half the re-reads of the
 // sequence's K/V rows through the load path (the kernel's bound, see above) for 112 instead of 72 VGPRs.
 template <int NQ>
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7
     const int voff_t = kg * ldb + r * 16;                 // tile load: lane = (row kg of 4, float4 r of 16) per instruction
     float* const wr = my + kg * ATT_LDT + r * 4;
     const float* const rd = my + r * ATT_LDT + kg * 16;
-    const int voff_v = (4 * kg) * ldb + r * 4;
+    const int voff_v = (4 * kg) * ldb + r * 16;
 
     auto load_tile = [&](int row0, int col_bytes, float (&f)[16]) {   // rows row0..row0+15 -> f[i] = [row r][16 kg + i]
         i32x4 raw[4];
@@ -119,13 +119,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7
     for (int j0 = 0; j0 < L; j0 += 16) {
         float kf[16];
         load_tile(j0, hid * 4, kf);
-        float v[4][4];   // [dim tile][step]
+        // V: one 16-byte load per key and lane -- lane (r, kg) takes dims 4r..4r+3 of key 4 kg + i, i.e. output tile t holds the
+        // dims 4 r + t (any assignment of dims to MFMA rows is as good as another; this one reads whole 256-B head rows)
+        f32x4 v[4];      // [step]; component t feeds dim tile t
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int so = (j0 + i) * ldb + 2 * hid * 4;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[t][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_v + 64 * t, so, 0));
-        }
+        for (int i = 0; i < 4; ++i)
+            v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_v, (j0 + i) * ldb + 2 * hid * 4, 0));
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             if (u == 1 && !second) break;
@@ -158,18 +157,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) o[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t][i], s[i], o[u][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) o[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[i][t], s[i], o[u][t], 0, 0, 0);
         }
     }
-    // o[u][t][g] = O[query 16 u + r][16 t + 4 kg + g] -> rows through the LDS slice -> whole 256-B rows out
+    // o[u][t][g] = O[query 16 u + r][16 kg + 4 g + t] -> rows through the LDS slice -> whole 256-B rows out
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
         if (u == 1 && !second) break;
         const float inv = 1.0f / l[u];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            *reinterpret_cast<float4*>(my + r * ATT_LDT + 16 * t + 4 * kg) =
-                make_float4(o[u][t][0] * inv, o[u][t][1] * inv, o[u][t][2] * inv, o[u][t][3] * inv);
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(my + r * ATT_LDT + 16 * kg + 4 * g) =
+                make_float4(o[u][0][g] * inv, o[u][1][g] * inv, o[u][2][g] * inv, o[u][3][g] * inv);
         float* const op = a.out + (size_t)(tok0 + q0 + 16 * u) * a.ldo + h * 64 + r * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
