@@ -71,10 +71,17 @@ template <int NQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7 : 4, 8))) void attn_varlen_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 16 * ATT_LDT];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#ifdef FZ_ABL_ATTN_HEADS4   // ablation: a workgroup = one strip x four consecutive heads (1 KiB contiguous per row)
+    const int hgroups = (a.H + 3) >> 2;
+    const int strip = blockIdx.x / hgroups;
+    const int h = (blockIdx.x - strip * hgroups) * 4 + wave;
+    if (h >= a.H) return;
+#else
     const int grp = blockIdx.x / a.H;
     const int h = blockIdx.x - grp * a.H;
     const int strip = grp * 4 + wave;
     if (strip >= a.n_strips) return;
+#endif
     const int4 st = a.strips[strip];
     const int tok0 = st.x, L = st.y, q0 = st.z;
     if (q0 >= L) return;
@@ -347,7 +354,11 @@ extern "C" int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strip
     if ((ld & 3) || (ldo & 3) || !aligned16(qkv) || !aligned16(out) || !aligned16(strips)) return FZ_ERR_UNSUPPORTED;
     if ((long long)ld * 4 * 16384 > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;   // in-sequence byte offsets are 32-bit
     AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(strips), n_strips, H, out, ldo, scale * 1.4426950408889634f};
+#ifdef FZ_ABL_ATTN_HEADS4
+    const long long grid = (long long)n_strips * ((H + 3) / 4);
+#else
     const long long grid = (long long)((n_strips + 3) / 4) * H;
+#endif
     if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
     attn_varlen_kernel<FZ_ATTN_NQ><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
     FZ_LAUNCH_CHECK();
