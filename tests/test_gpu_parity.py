@@ -894,5 +894,6 @@ def test_packed_cross_encoder_matches_padded_forward():
     assert ce._packed is not None and got.shape == (21,)
     for i, (q, d) in enumerate(pairs):
         ids1, m1 = tok([q + " </s> " + d], ce.max_length)
-        ref = ce.model(input_ids=ids1.cuda(), attention_mask=m1.cuda()).logits[0, 0]
+        with torch.no_grad():
+            ref = ce.model(input_ids=ids1.cuda(), attention_mask=m1.cuda()).logits[0, 0]
         assert abs(float(ref) - float(got[i])) <= 1e-4
