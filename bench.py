@@ -2,7 +2,8 @@
 """bench.py -- queries/sec end-to-end (encode + score + fuse) on synthetic LLeQA-shaped batches.
 
 One "step" = one pass of the hot path over one batch of Q synthetic queries, inputs resident in HBM:
-    1. encode      query token ids -> CamemBERT-base-shaped encoder (random init, fp32, PyTorch-ROCm) -> mean pool
+    1. encode      query token ids -> CamemBERT-base-shaped encoder (random init, fp32; padding-free forward: PyTorch-ROCm
+                   hipBLASLt Linears + this repo's HIP embedding / attention / GELU / LayerNorm / pooling kernels) -> mean pool
     2. dpr score   normalise + fp32-MFMA cos-sim GEMM against the resident corpus embeddings   [Q, N]
     3. dpr rank    stable descending row sort -> order + rank planes
     4. bm25 score  float64 BM25 of the same batch against a resident synthetic index            [Q, N]
