@@ -5,12 +5,14 @@
  * file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and
  * there only as the checker / the timed CPU baseline, never as the product path.
  *
- * Parity status: PINNED for fuse (rrf/bcf/nsf x every normalisation), BM25 and Metrics
- * against golden vectors produced by the reference's own classes (oracle/gen_golden.py
- * -> tests/golden/). UNPINNED for cos-sim scoring and MaxSim: their arithmetic lives in
- * sentence-transformers==2.2.2 / colbert-ai@main, absent from /root/reference; the
- * published algorithm is restated (see each function) and checked against analytic
- * known answers only.
+ * Parity status: PINNED for fuse (rrf/bcf/nsf x every normalisation), BM25, Metrics,
+ * cosine / dot-product scoring, top-k search and SPLADE pooling against golden vectors
+ * produced by the reference's own in-tree classes (oracle/gen_golden.py -> tests/golden/;
+ * scoring and search through splade/base.py:186-251, the in-tree mirror of the
+ * sentence-transformers calls at hybrid.py:103). UNPINNED for MaxSim only: its arithmetic
+ * lives in colbert-ai@main, absent from /root/reference and from the image; the published
+ * late-interaction formula is restated and checked against analytic known answers and an
+ * fp32 torch restatement.
  *
  * Data model (shared with include/fusion_hip.h): the reference's
  *   RankedLists = list[Q] of list[<=N] of {'corpus_id','score'}  (hybrid.py:66-75)
@@ -372,6 +374,47 @@ int fzo_fuse_none_f64(const float* const* planes, const int32_t* const* ranks, c
                 acc = acc + prod;
             }
             fused[(size_t)q * ld + j] = present ? acc : -INFINITY;
+        }
+    }
+    return FZO_OK;
+}
+
+/* General weight-and-sum with the reference's NumPy-2 scalar promotion (hybrid.py:291,304), for the cases the two
+ * entries above do not cover:
+ *   - a transformed score is np.float32; `score * w` is float32 when w is a Python float (weak scalar) or np.float32,
+ *     float64 when w is np.float64 -- which is what the weight grid of the tuning loop produces (np.arange,
+ *     hybrid.py:405-409): the tuning loop fuses in float64, the equal-weights path (`1/len(results)`, :448) in float32;
+ *   - the per-document accumulator starts as Python 0.0 (weak), so it is float32 until the first float64 product is
+ *     added FOR THAT DOCUMENT and float64 from then on;
+ *   - 'none' keeps the raw Python-float scores: float64 planes, always wide.
+ * planes[s] is float32 (plane_f64[s] == 0) or float64; narrow[s] != 0 <=> w[s] is a weak / float32 weight AND the
+ * plane holds float32 values.  fl32(fl64(a) + fl64(b)) == fl32(a + b) for floats (double rounding is innocuous
+ * at 53 >= 2*24+2 bits), so the narrow steps are written on doubles. */
+int fzo_fuse_wsum_f64(const void* const* planes, const int32_t* plane_f64, const int32_t* const* ranks, const double* w,
+                      const int32_t* narrow, int S, int Q, int N, int ld, double* fused) {
+    if (!planes || !w || !fused || !narrow || !plane_f64 || S <= 0 || Q < 0 || N < 0 || ld < N) return FZO_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int q = 0; q < Q; ++q) {
+        for (int j = 0; j < N; ++j) {
+            volatile double acc = 0.0;
+            int present = 0, wide = 0;
+            size_t off = (size_t)q * ld + j;
+            for (int s = 0; s < S; ++s) {
+                if (ranks && ranks[s] && ranks[s][off] < 0) continue;
+                present = 1;
+                volatile double prod;
+                if (narrow[s] && !plane_f64[s]) {
+                    volatile float p32 = ((const float*)planes[s])[off] * (float)w[s];
+                    prod = (double)p32;
+                } else {
+                    double v = plane_f64[s] ? ((const double*)planes[s])[off] : (double)((const float*)planes[s])[off];
+                    prod = v * w[s];
+                    wide = 1;
+                }
+                acc = acc + prod;
+                if (!wide) { volatile float a32 = (float)acc; acc = (double)a32; }
+            }
+            fused[off] = present ? acc : -INFINITY;
         }
     }
     return FZO_OK;

@@ -6,8 +6,19 @@ sees the reference, only the small fixtures this script writes to tests/golden/.
 
 What is imported from the reference (unmodified, no bytecode written):
   * src.retrievers.hybrid.Aggregator   (hybrid.py:166-307)  -- fuse / transform_scores
+  * src.retrievers.hybrid.run_evaluation (hybrid.py:24-42)  -- the metric set of the tuning loop
   * src.retrievers.bm25.BM25           (bm25.py:129-156)    -- search_all
   * src.utils.metrics.Metrics          (metrics.py:25-162)  -- compute_all_metrics
+  * src.retrievers.splade.base.BaseModel (splade/base.py:186-251) -- compute_batchwise_similarity, search
+    (the in-tree mirror of sentence-transformers' util.cos_sim / util.semantic_search used at hybrid.py:103)
+  * src.retrievers.splade.splade.SPLADE (splade/splade.py:88-99) -- forward (max / sum pooling)
+
+The splade package does not import as shipped: `transformers.file_utils.default_cache_path` and
+`transformers.optimization.AdamW` left transformers 5, and `splade/__init__.py` exports neither `BaseModel` nor
+`MmarcoReader` although `splade.py:11` imports them from it.  The harness sets those four NAMES (a path string,
+torch's AdamW, the reference's own BaseModel class, a placeholder for the training-only reader); the methods are
+then called UNBOUND on a SimpleNamespace carrying the attributes they read (`similarity`, `encode`, `model`,
+`pooling`, `relu`, `pruning_topk`), so no checkpoint is needed and no arithmetic goes through a placeholder.
 
 Absent third-party modules that those files import at module top but never touch
 on the functions we call (dotenv, ir_datasets, seaborn, wandb, spacy) are replaced
@@ -52,6 +63,27 @@ def load_reference():
     from src.retrievers.bm25 import BM25
     from src.utils.metrics import Metrics
     return Aggregator, BM25, Metrics
+
+
+def load_reference_splade():
+    """splade/base.py + splade/splade.py, unmodified; see the module docstring for the four harness-side names."""
+    import torch
+    import transformers.file_utils as fu
+    import transformers.optimization as opt
+    if not hasattr(fu, "default_cache_path"):
+        fu.default_cache_path = os.path.join(os.path.expanduser("~"), ".cache", "huggingface")   # base.py:12, a path only
+    if not hasattr(opt, "AdamW"):
+        opt.AdamW = torch.optim.AdamW                                                              # splade.py:9, training only
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import src.retrievers.splade as pkg
+    from src.retrievers.splade.base import BaseModel
+    if not hasattr(pkg, "BaseModel"):
+        pkg.BaseModel = BaseModel               # splade.py:11 `from . import BaseModel, MmarcoReader`
+    if not hasattr(pkg, "MmarcoReader"):
+        pkg.MmarcoReader = object               # training-only data reader
+    from src.retrievers.splade.splade import SPLADE
+    return BaseModel, SPLADE
 
 
 # --------------------------------------------------------------------------------------
@@ -248,7 +280,7 @@ def gen_bm25(BM25):
         out["params"].append([k1, b])
         out["results"].append([[[int(x["corpus_id"]), float(x["score"])] for x in r] for r in res])
         if k1 == 2.5:
-            out["idf"] = {w: float(v) for w, v in m.idf.items()}
+            out["idf"] = {w: float(m.idf[w]) for w in sorted(m.idf)}   # sorted: the vocabulary is a set (hash-seed order)
             out["avgdl"] = float(m.avgdl)
     # KAT-8 of SURVEY.md
     kdocs = ["chat noir dormir", "chien noir courir courir", "loi article code civil", "chat chien"]
@@ -274,14 +306,282 @@ def gen_metrics(Metrics):
         json.dump({"cases": cases, "kat9": {k: float(v) for k, v in kat9.items()}}, f)
 
 
+# --------------------------------------------------------------------------------------
+# round 2: scoring / search / SPLADE pooling pinned on the reference's in-tree splade package,
+# the weight-grid loop, the score-distribution analysis, a full LLeQA row, unsorted lists
+# --------------------------------------------------------------------------------------
+def _fake_model(BaseModel, similarity, Qe=None, De=None):
+    """The attributes BaseModel.compute_batchwise_similarity / search read from `self`."""
+    from types import SimpleNamespace
+    m = SimpleNamespace(similarity=similarity)
+    m.compute_batchwise_similarity = lambda q_embs, d_embs: BaseModel.compute_batchwise_similarity(m, q_embs, d_embs)
+    m.encode = lambda texts, query_mode, batch_size: (Qe if query_mode else De)
+    return m
+
+
+def gen_similarity(BaseModel):
+    """compute_batchwise_similarity (splade/base.py:186-197), cos_sim and dot_score."""
+    import torch
+    torch.set_num_threads(1)   # one summation order, whatever box regenerates the fixtures
+    rng = np.random.default_rng(2024)
+    # DPR-shaped: un-normalised Gaussians, d = 768
+    Qe = rng.normal(0, 1, (8, 768)).astype(np.float32)
+    De = rng.normal(0, 1, (300, 768)).astype(np.float32)
+    De[17] = De[3]                      # a duplicated document: exactly equal scores
+    De[40] = 2.5 * De[41]               # cosine is scale invariant, the dot product is not
+    out = {"Qe": Qe, "De": De}
+    for sim in ("cos_sim", "dot_score"):
+        m = _fake_model(BaseModel, sim)
+        out[sim] = BaseModel.compute_batchwise_similarity(m, torch.from_numpy(Qe), torch.from_numpy(De)).numpy()
+    np.savez_compressed(os.path.join(OUT, "sim_dpr_Q8_N300_d768.npz"), **out)
+    # SPLADE-shaped: V = 32,005, sparse non-negative activations (log1p(relu) outputs), stored as COO triplets
+    Q, N, V = 4, 257, 32005
+
+    def sparse_rows(rows, nnz_lo, nnz_hi):
+        r, c, v = [], [], []
+        for i in range(rows):
+            k = int(rng.integers(nnz_lo, nnz_hi))
+            cols = rng.choice(V, size=k, replace=False)
+            r += [i] * k; c += cols.tolist(); v += rng.gamma(2.0, 0.4, k).astype(np.float32).tolist()
+        return np.array(r, np.int32), np.array(c, np.int32), np.array(v, np.float32)
+    qr, qc, qv = sparse_rows(Q, 20, 60)
+    dr, dc, dv = sparse_rows(N, 60, 240)
+    Qs = np.zeros((Q, V), np.float32); Qs[qr, qc] = qv
+    Ds = np.zeros((N, V), np.float32); Ds[dr, dc] = dv
+    out = {"shape": np.array([Q, N, V]), "q_row": qr, "q_col": qc, "q_val": qv, "d_row": dr, "d_col": dc, "d_val": dv}
+    for sim in ("cos_sim", "dot_score"):
+        m = _fake_model(BaseModel, sim)
+        out[sim] = BaseModel.compute_batchwise_similarity(m, torch.from_numpy(Qs), torch.from_numpy(Ds)).numpy()
+    np.savez_compressed(os.path.join(OUT, "sim_splade_Q4_N257_V32005.npz"), **out)
+
+
+def gen_search(BaseModel):
+    """BaseModel.search (splade/base.py:199-251): chunked mm -> topk(sorted=False) -> heap -> sorted, with a stand-in
+    `encode` that returns seeded embeddings.  Same algorithm as util.semantic_search (hybrid.py:103) and the chunked
+    evaluator (src/utils/sentence_transformers.py:346-364)."""
+    import torch
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(77)
+    Q, N, d = 6, 1000, 64
+    Qe = rng.normal(0, 1, (Q, d)).astype(np.float32)
+    De = rng.normal(0, 1, (N, d)).astype(np.float32)
+    for a, b in [(20, 500), (21, 501), (22, 999), (700, 3)]:
+        De[b] = De[a]                   # exact duplicates: tied scores inside a list
+    De[123] = 0.0                       # a zero vector: F.normalize's eps clamp -> score exactly 0
+    out = {"Qe": Qe, "De": De}
+    cfgs = [("k10_qc4_dc300", 10, 4, 300), ("kN_qc100_dc500000", N, 100, 500000), ("k37_qc2_dc128", 37, 2, 128),
+            ("k1000_qc3_dc333", 1000, 3, 333)]
+    for sim in ("cos_sim", "dot_score"):
+        m = _fake_model(BaseModel, sim, torch.from_numpy(Qe), torch.from_numpy(De))
+        for name, k, qc, dc in cfgs:
+            res = BaseModel.search(m, ["q"] * Q, ["d"] * N, batch_size=32, query_chunk_size=qc, doc_chunk_size=dc, topk=k)
+            out[f"ids__{sim}__{name}"] = np.array([[x["doc_id"] for x in r] for r in res], dtype=np.int64)
+            out[f"scores__{sim}__{name}"] = np.array([[x["score"] for x in r] for r in res], dtype=np.float32)
+    out["configs"] = np.array([f"{n}:{k}:{qc}:{dc}" for n, k, qc, dc in cfgs])
+    np.savez_compressed(os.path.join(OUT, "search_Q6_N1000_d64.npz"), **out)
+
+
+def gen_splade_pool(SPLADE):
+    """SPLADE.forward (splade/splade.py:88-99) on seeded MLM logits, 'max' (the hybrid path's default) and 'sum'."""
+    import torch
+    from types import SimpleNamespace
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(5)
+    B, L, V = 5, 24, 509
+    logits = rng.normal(0, 2.0, (B, L, V)).astype(np.float32)
+    logits[0, 3, :40] = 0.0
+    logits[1, :, 7] = -1.0              # a vocabulary entry that never activates
+    lens = np.array([24, 9, 1, 17, 2], dtype=np.int32)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    out = {"logits": logits, "lens": lens}
+    for pooling in ("max", "sum"):
+        fake = SimpleNamespace(model=lambda input_ids, attention_mask: SimpleNamespace(logits=torch.from_numpy(logits)),
+                               pooling=pooling, relu=torch.nn.ReLU(), pruning_topk=None)
+        out[pooling] = SPLADE.forward(fake, torch.zeros((B, L), dtype=torch.long), torch.from_numpy(mask)).numpy()
+    np.savez_compressed(os.path.join(OUT, "splade_pool_B5_L24_V509.npz"), **out)
+
+
+def _lattice(names, step=0.05):
+    """hybrid.py:405-409, evaluated with the same numpy calls."""
+    import itertools
+    return [{n: w for n, w in zip(names, comb)} for comb in itertools.product(np.arange(0, 1 + step, step), repeat=len(names))
+            if np.isclose(sum(comb), 1.0)]
+
+
+def gen_tune(Aggregator):
+    """The weight-grid loop of hybrid.py:404-426: per weight vector Aggregator.fuse(deepcopy(results)) -> run_evaluation."""
+    import copy
+    from src.retrievers.hybrid import run_evaluation
+    for seed, S, Q, N, variant in [(20, 2, 4, 257, "ties"), (21, 3, 4, 257, "colbert_first")]:
+        rng = np.random.default_rng(seed)
+        systems, ids, lists = make_case(rng, S, Q, N, variant)
+        # gold labels: 1-4 ids per query, mostly taken from the head of a mixture ranking so that the metrics move with
+        # the weights; one label is never retrieved by any system (absent id), one query has a duplicated label
+        labels = []
+        for q in range(Q):
+            pool = [x["corpus_id"] for s in systems for x in lists[s][q][:40]]
+            g = rng.choice(pool, size=int(rng.integers(1, 5)), replace=False).tolist()
+            labels.append([int(x) for x in g])
+        labels[1].append(10 ** 7)
+        labels[2].append(labels[2][0])
+        distr = {}
+        for s in systems:
+            pool = np.array([x["score"] for q in range(Q) for x in lists[s][q]], dtype=np.float64)
+            distr[s] = np.quantile(pool, np.linspace(0, 1, 101))
+        combos = _lattice(systems)
+        in_ids, in_sc, in_len = pack_lists(systems, lists, Q)
+        blob = {"systems": np.array(systems), "in_ids": in_ids, "in_scores": in_sc, "in_len": in_len,
+                "labels": np.array([",".join(str(x) for x in g) for g in labels]),
+                "weights": np.array([[w[s] for s in systems] for w in combos], dtype=np.float64)}
+        for s in systems:
+            blob[f"distr_{s}"] = distr[s]
+        names = None
+        for norm in ["min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent", "none"]:
+            rows = []
+            for w in combos:
+                fused = Aggregator.fuse(copy.deepcopy(lists), method="nsf", normalization=norm, percentile_distributions=distr, linear_weights=w)
+                perf = run_evaluation(predictions=[[x["corpus_id"] for x in r] for r in fused], labels=labels, print2console=False)
+                names = names or list(perf.keys())
+                assert list(perf.keys()) == names
+                rows.append([float(perf[k]) for k in names])
+            blob[f"metrics__{norm}"] = np.array(rows, dtype=np.float64)
+        blob["metric_names"] = np.array(names)
+        np.savez_compressed(os.path.join(OUT, f"tune_seed{seed}_S{S}_Q{Q}_N{N}_{variant}.npz"), **blob)
+
+
+def gen_analysis(Aggregator):
+    """The score-distribution analysis of hybrid.py:363-402, which lives inside main() and cannot be called: the
+    per-(query, system) transform IS the reference's Aggregator.transform_scores(convert2dict(...)); the three table
+    recipes around it are re-stated here with the same pandas operations (rows of {'system','score'} dicts ->
+    DataFrame; per system drop zeros and the two smallest distinct scores; quantiles at linspace(0,1,n+1); labelled
+    scores of the positives and of random.seed(42)-sampled negatives, 0 where a system does not list the document)."""
+    import random
+    import pandas as pd
+    rng = np.random.default_rng(31)
+    S, Q, N = 3, 3, 120
+    systems, ids, lists = make_case(rng, S, Q, N, "colbert_first")   # colbert lists are 0.6 N long
+    corpus_ids = sorted(int(i) for i in ids)
+    max_pid = max(corpus_ids)
+    pos_pids = [[int(x) for x in rng.choice(corpus_ids, size=int(rng.integers(1, 4)), replace=False)] for _ in range(Q)]
+    random.seed(42)
+    neg_pids = [random.sample(list(set(range(1, max_pid + 1)) - set(x)), k=len(x)) for x in pos_pids]
+    in_ids, in_sc, in_len = pack_lists(systems, lists, Q)
+    blob = {"systems": np.array(systems), "in_ids": in_ids, "in_scores": in_sc, "in_len": in_len,
+            "corpus_ids": np.array(corpus_ids, dtype=np.int64),
+            "pos_pids": np.array([",".join(map(str, p)) for p in pos_pids]),
+            "neg_pids": np.array([",".join(map(str, p)) for p in neg_pids])}
+    raw_tables = None
+    for norm in ["none", "min-max", "z-score", "arctan", "percentile-rank"]:
+        distributions = {}
+        if norm == "percentile-rank":
+            distributions = {s: raw_tables[s] for s in systems}    # the reference reads the 'raw' tables back from CSV
+        all_scores, labeled = [], []
+        for i in range(Q):
+            transformed = {}
+            for s in systems:
+                transformed[s] = Aggregator.transform_scores(results=Aggregator.convert2dict(lists[s][i]), transformation=norm,
+                                                             percentile_distr=distributions.get(s))
+                all_scores.extend({"system": s, "score": v} for v in transformed[s].values())
+            for label, pids in (("positive", pos_pids[i]), ("negative", neg_pids[i])):
+                for pid in pids:
+                    labeled.append({"label": label, **{s: t.get(pid, 0) for s, t in transformed.items()}})
+        df = pd.DataFrame(all_scores, columns=["system", "score"])
+        for s in systems:
+            blob[f"scores__{norm}__{s}"] = df.loc[df["system"] == s, "score"].to_numpy(dtype=np.float64)
+        for n_pts in (10, 1000):
+            for s in systems:
+                g = df.loc[df["system"] == s, "score"]
+                two_smallest = g.drop_duplicates().nsmallest(2)
+                kept = g[(g != 0.0) & (~g.isin(two_smallest))]
+                blob[f"table__{norm}__{n_pts}__{s}"] = kept.quantile(np.linspace(0, 1, n_pts + 1)).to_numpy(dtype=np.float64)
+        if norm == "none":
+            raw_tables = {s: blob[f"table__none__1000__{s}"] for s in systems}
+        ldf = pd.DataFrame(labeled, columns=["label"] + systems)
+        blob[f"labeled_label__{norm}"] = ldf["label"].to_numpy().astype(str)
+        for s in systems:
+            blob[f"labeled__{norm}__{s}"] = ldf[s].to_numpy(dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "analysis_seed31_S3_Q3_N120.npz"), **blob)
+
+
+def gen_fullrow(Aggregator):
+    """One full LLeQA row (N = 27,942), S = 4, Q = 2: the z-score / arctan tolerances at the real list length."""
+    import copy
+    rng = np.random.default_rng(40)
+    S, Q, N = 4, 2, 27942
+    systems, ids, lists = make_case(rng, S, Q, N, "plain")
+    weights = {"bm25": 0.15, "dpr": 0.35, "splade": 0.3, "colbert": 0.2}
+    distr = {}
+    for s in systems:
+        pool = np.array([x["score"] for q in range(Q) for x in lists[s][q]], dtype=np.float64)
+        distr[s] = np.quantile(pool, np.linspace(0, 1, 1001))
+    in_ids, in_sc, in_len = pack_lists(systems, lists, Q)
+    blob = {"systems": np.array(systems), "in_ids": in_ids.astype(np.int32), "in_scores": in_sc.astype(np.float32), "in_len": in_len,
+            "weights": np.array([weights[s] for s in systems], dtype=np.float64)}
+    assert np.array_equal(blob["in_scores"].astype(np.float64), in_sc)     # the inputs are fp32 values: nothing is lost
+    for s in systems:
+        blob[f"distr_{s}"] = distr[s]
+    for method, norm in METHODS:
+        fused = Aggregator.fuse(copy.deepcopy(lists), method=method, normalization=norm, linear_weights=weights, percentile_distributions=distr)
+        o_ids, o_sc, o_len = pack_out(fused, Q)
+        key = f"{method}__{norm}"
+        blob[f"out_ids__{key}"] = o_ids.astype(np.int32)
+        f64 = method in ("rrf", "bcf") or norm == "none"
+        blob[f"out_scores__{key}"] = o_sc if f64 else o_sc.astype(np.float32)
+        if not f64:
+            assert np.array_equal(blob[f"out_scores__{key}"].astype(np.float64), o_sc, equal_nan=True)   # fp32 values (NumPy 2 promotion)
+        blob[f"out_len__{key}"] = o_len
+    np.savez_compressed(os.path.join(OUT, f"fuse_fullrow_seed40_S{S}_Q{Q}_N{N}.npz"), **blob)
+
+
+def gen_unsorted(Aggregator):
+    """Lists that are NOT sorted by score, and lists with duplicate ids, through the nsf normalisations: the reference
+    takes min / max / mean / std over the VALUES (hybrid.py:255-262), whatever the list order."""
+    import copy
+    L = lambda pairs: [{"corpus_id": i, "score": s} for i, s in pairs]
+    rng = np.random.default_rng(50)
+    out = {}
+    cases = {
+        "dup": {"s1": [L([(1, 5.0), (2, 4.0), (1, 1.0), (3, 4.5)])], "s2": [L([(3, 1.0), (2, .5), (4, .25)])]},
+        "unsorted": {"s1": [L([(1, 0.5), (2, 7.0), (3, -2.0), (4, 3.0)])], "s2": [L([(4, 1.0), (3, 9.0), (2, 2.0), (5, 0.0)])]},
+    }
+    n = 64
+    idp = rng.permutation(np.arange(1, n + 1))
+    cases["unsorted_rand"] = {
+        "a": [L([(int(i), float(np.float32(v))) for i, v in zip(idp, rng.normal(0, 3, n))]) for _ in range(2)],
+        "b": [L([(int(i), float(np.float32(v))) for i, v in zip(idp[::-1][: n // 2], rng.uniform(-1, 1, n // 2))]) for _ in range(2)],
+    }
+    for cname, lists in cases.items():
+        w = {s: x for s, x in zip(lists.keys(), (0.3, 0.7))}
+        out[cname] = {"lists": lists, "weights": w, "out": {}}
+        for norm in ["min-max", "z-score", "arctan", "none"]:
+            fused = Aggregator.fuse(copy.deepcopy(lists), method="nsf", normalization=norm, linear_weights=w, percentile_distributions={})
+            out[cname]["out"][norm] = [[{"corpus_id": int(x["corpus_id"]), "score": float(x["score"])} for x in r] for r in fused]
+        for m in ["rrf", "bcf"]:
+            fused = Aggregator.fuse(copy.deepcopy(lists), method=m)
+            out[cname]["out"][m] = [[{"corpus_id": int(x["corpus_id"]), "score": float(x["score"])} for x in r] for r in fused]
+    with open(os.path.join(OUT, "unsorted_fuse.json"), "w") as f:
+        json.dump(out, f)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    # splade first: transformers' lazy imports probe optional packages with importlib.util.find_spec, which chokes on
+    # the spec-less placeholder modules that load_reference() installs for hybrid.py / bm25.py
+    BaseModel, SPLADE = load_reference_splade()
     Aggregator, BM25, Metrics = load_reference()
     names = gen_fuse(Aggregator)
     gen_kat(Aggregator)
     gen_bm25(BM25)
     gen_metrics(Metrics)
-    print("wrote", len(names), "fuse fixtures + kat_fuse.json, bm25.json, metrics.json ->", os.path.normpath(OUT))
+    gen_similarity(BaseModel)
+    gen_search(BaseModel)
+    gen_splade_pool(SPLADE)
+    gen_tune(Aggregator)
+    gen_analysis(Aggregator)
+    gen_unsorted(Aggregator)
+    gen_fullrow(Aggregator)
+    print("wrote", len(names), "fuse fixtures + kat_fuse.json, bm25.json, metrics.json, sim_*.npz, search_*.npz, splade_pool_*.npz, "
+          "tune_*.npz, analysis_*.npz, unsorted_fuse.json, fuse_fullrow_*.npz ->", os.path.normpath(OUT))
 
 
 if __name__ == "__main__":

@@ -2,9 +2,10 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
 module; nothing under fusion_amd/ does.  Parity status is stated in fusion_oracle.c's
-header: fuse / BM25 / Metrics are PINNED on tests/golden (made by the reference's own
-classes via oracle/gen_golden.py); cos-sim and MaxSim are UNPINNED (third-party
-arithmetic absent from the reference tree).
+header: fuse / BM25 / Metrics / cos-sim + dot scoring / chunked top-k search / SPLADE pooling /
+the weight-grid loop / the score-distribution tables are PINNED on tests/golden (made by the
+reference's own classes via oracle/gen_golden.py); MaxSim is UNPINNED (colbert-ai is absent
+from the reference tree and from the image).
 
 Every function cites the reference lines it restates (paths relative to /root/reference).
 """
@@ -106,6 +107,24 @@ def maxsim(Qtok: np.ndarray, Dtok: np.ndarray, Doff: np.ndarray) -> np.ndarray:
     out = np.empty((Q, N), dtype=np.float32)
     _chk(lib().fzo_maxsim_f32(_p(Qtok), _p(Dtok), _p(Doff), Q, Lq, N, dim, _p(out), N), "maxsim")
     return out
+
+
+def search(Qe: np.ndarray, De: np.ndarray, k: int, similarity: str = "cos_sim"):
+    """BaseModel.search (splade/base.py:199-251) == util.semantic_search (hybrid.py:103): scores -> per-query top-k,
+    sorted by score descending.  Chunking does not change the result set; ties (implementation-defined in the
+    reference: unsorted topk + heap order) -> ascending document index.  Returns (scores [Q,k], ids [Q,k])."""
+    S = cos_scores(Qe, De) if similarity == "cos_sim" else dot_scores(Qe, De)
+    return topk_rows(S, min(k, S.shape[1]))
+
+
+def splade_pool(logits: np.ndarray, lens: np.ndarray, pooling: str = "max") -> np.ndarray:
+    """SPLADE.forward (splade/splade.py:88-99): amax (or sum) over the sequence of log1p(relu(logits * mask)).
+    logits [B,L,V] fp32, lens [B] = number of attended tokens per sequence (mask = position < len)."""
+    logits = np.asarray(logits, dtype=np.float32)
+    B, L, V = logits.shape
+    mask = (np.arange(L)[None, :] < np.asarray(lens)[:, None]).astype(np.float32)[:, :, None]
+    act = np.log1p(np.maximum(logits * mask, np.float32(0.0)), dtype=np.float32)
+    return act.sum(axis=1, dtype=np.float32) if pooling == "sum" else act.max(axis=1)
 
 
 # ---------------------------------------------------------------------------------------
@@ -221,11 +240,33 @@ def fuse_none(planes, ranks, weights) -> np.ndarray:
     return fused
 
 
+def is_wide_weight(w) -> bool:
+    """NumPy-2 promotion of `np.float32 score * w` (hybrid.py:291): float64 only for an np.float64 weight (a Python
+    float / int is a weak scalar, np.float32 / np.float16 stay float32).  np.float64 subclasses float: test it first."""
+    return isinstance(w, (np.float64, np.longdouble))
+
+
+def fuse_wsum(planes, ranks, weights, narrow) -> np.ndarray:
+    """Weight-and-sum with per-system promotion (see fzo_fuse_wsum_f64): planes fp32 or fp64, -> fp64."""
+    S = len(planes)
+    Q, N = planes[0].shape
+    planes = [np.ascontiguousarray(p, dtype=(np.float64 if p.dtype == np.float64 else np.float32)) for p in planes]
+    if ranks is not None:
+        ranks = [None if r is None else np.ascontiguousarray(r, dtype=np.int32) for r in ranks]
+    w = np.asarray([float(x) for x in weights], dtype=np.float64)
+    pf = np.array([p.dtype == np.float64 for p in planes], dtype=np.int32)
+    nr = np.array([bool(n) for n in narrow], dtype=np.int32)
+    fused = np.empty((Q, N), dtype=np.float64)
+    _chk(lib().fzo_fuse_wsum_f64(_ptr_array(planes), _p(pf), None if ranks is None else _ptr_array(ranks), _p(w), _p(nr),
+                                 S, Q, N, N, _p(fused)), "fuse_wsum")
+    return fused
+
+
 # ---------------------------------------------------------------------------------------
 # list-of-dict adapter: the reference's Aggregator.fuse signature (hybrid.py:170-220)
 # ---------------------------------------------------------------------------------------
 def lists_to_planes(ranked_lists: dict[str, list[list[dict]]]):
-    """RankedLists -> dense planes.  convert2dict (hybrid.py:222-233) collapses duplicate ids:
+    """RankedLists -> dense planes (+ the raw float64 scores).  convert2dict (hybrid.py:222-233) collapses duplicate ids:
     the FIRST position is kept, the LAST score wins; rank = position among unique ids."""
     systems = list(ranked_lists.keys())
     Q = len(ranked_lists[systems[0]])
@@ -243,6 +284,7 @@ def lists_to_planes(ranked_lists: dict[str, list[list[dict]]]):
         ids[v] = k
     S = len(systems)
     planes = [np.zeros((Q, N), dtype=np.float32) for _ in range(S)]
+    planes64 = [np.zeros((Q, N), dtype=np.float64) for _ in range(S)]   # the raw Python floats ('none' keeps them, hybrid.py:280)
     ranks = [np.full((Q, N), -1, dtype=np.int32) for _ in range(S)]
     orders = [np.full((Q, N), -1, dtype=np.int32) for _ in range(S)]
     lens = np.zeros((S, Q), dtype=np.int32)
@@ -253,32 +295,37 @@ def lists_to_planes(ranked_lists: dict[str, list[list[dict]]]):
                 d[x["corpus_id"]] = x["score"]  # python dict: first position kept, last value wins
             for r, (cid, sc) in enumerate(d.items()):
                 j = pos[cid]
-                planes[si][q, j] = np.float32(sc)
+                planes[si][q, j] = np.float32(sc)      # torch.tensor(list(values), dtype=float32), hybrid.py:255
+                planes64[si][q, j] = float(sc)
                 ranks[si][q, j] = r
                 orders[si][q, r] = j
             lens[si, q] = len(d)
-    return systems, ids, planes, ranks, orders, lens
+    return systems, ids, planes, ranks, orders, lens, planes64
 
 
 def fuse_lists(ranked_lists, method, normalization=None, linear_weights=None, percentile_distributions=None,
                return_topk: int = 1000):
     """Same signature and result type as the reference's Aggregator.fuse (hybrid.py:170-220)."""
-    systems, ids, planes, ranks, orders, lens = lists_to_planes(ranked_lists)
+    systems, ids, planes, ranks, orders, lens, raw64 = lists_to_planes(ranked_lists)
     Q, N = planes[0].shape
     if method in ("rrf", "bcf"):
         fused = fuse_rank(ranks, lens, method)
     elif method == "nsf":
         w = [linear_weights[s] for s in systems]  # KeyError if a system lacks a weight (hybrid.py:214)
         distr = [percentile_distributions.get(s) for s in systems]  # AttributeError on None (hybrid.py:213)
-        if normalization in ("min-max", "z-score", "arctan"):
-            fused = fuse_nsf(planes, ranks, w, normalization, None)
-        elif normalization in ("percentile-rank", "normal-curve-equivalent"):
-            fused = fuse_nsf(planes, ranks, w, normalization, distr)
-        else:
-            fused = fuse_none(planes, ranks, w)
+        wide = [is_wide_weight(x) for x in w]
+        if normalization in ("min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent"):
+            tabled = normalization in ("percentile-rank", "normal-curve-equivalent")
+            if not any(wide):
+                fused = fuse_nsf(planes, ranks, w, normalization, distr if tabled else None)
+            else:   # np.float64 weights (the tuning grid): transform in fp32, weight and sum with NumPy's promotion
+                T = [fuse_nsf([planes[i]], [ranks[i]], [1.0], normalization, [distr[i]] if tabled else None) for i in range(len(systems))]
+                fused = fuse_wsum(T, ranks, w, [not x for x in wide])
+        else:       # 'none' / unknown: the raw Python floats, float64 throughout (hybrid.py:280)
+            fused = fuse_wsum(raw64, ranks, w, [False] * len(systems))
     else:
         # hybrid.py:203-216: unknown method -> raw scores summed (no transform, no weights)
-        fused = fuse_none(planes, ranks, [1.0] * len(systems))
+        fused = fuse_wsum(raw64, ranks, [1.0] * len(systems), [False] * len(systems))
     ins, U = insertion_order(orders, lens, N)
     order, sk = sort_rows_desc(fused, init_order=ins, row_len=U)
     out = []
@@ -286,6 +333,43 @@ def fuse_lists(ranked_lists, method, normalization=None, linear_weights=None, pe
         out.append([{"corpus_id": ids[order[q, r]], "score": (float(sk[q, r]) if fused.dtype == np.float64 else np.float32(sk[q, r]))}
                     for r in range(U[q])])
     return out[:return_topk]  # slices QUERIES (hybrid.py:220)
+
+
+def tune_lists(ranked_lists, normalization, weight_combinations, labels, percentile_distributions=None):
+    """The weight-grid loop (hybrid.py:404-426): one full fuse + run_evaluation (hybrid.py:24-29) per weight vector."""
+    ev = Metrics(recall_at_k=[5, 10, 20, 50, 100, 200, 500, 1000], map_at_k=[10, 100], mrr_at_k=[10, 100], ndcg_at_k=[10, 100])
+    out = []
+    for w in weight_combinations:
+        fused = fuse_lists(ranked_lists, "nsf", normalization, w, percentile_distributions)
+        out.append(ev.compute_all_metrics(labels, [[x["corpus_id"] for x in r] for r in fused]))
+    return out
+
+
+def transform_lists(lists: list[list[dict]], normalization: str, distr=None) -> list[dict]:
+    """Aggregator.transform_scores(convert2dict(list)) per query (hybrid.py:378): {corpus_id: transformed score}."""
+    if normalization in (None, "none"):
+        return [{x["corpus_id"]: x["score"] for x in l} for l in lists]
+    out = []
+    for l in lists:
+        _, ids, planes, ranks, orders, lens, _raw = lists_to_planes({"s": [l]})
+        t = fuse_nsf(planes, ranks, [1.0], normalization, None if distr is None else [distr])   # fl32(t * 1) + 0 == t
+        out.append({ids[j]: t[0, j] for j in orders[0][0, : lens[0, 0]]})
+    return out
+
+
+def score_tables(ranked_lists, normalization, n_points, distributions=None):
+    """The quantile tables of hybrid.py:390-397: per system, all transformed scores of all queries, minus the zeros and
+    the two smallest distinct values, at the quantiles linspace(0, 1, n_points + 1) (float64, linear interpolation).
+    Returns ({system: all scores}, {system: table})."""
+    scores, tables = {}, {}
+    for s, lists in ranked_lists.items():
+        tr = transform_lists(lists, normalization, None if not distributions else distributions.get(s))
+        v = np.array([float(x) for t in tr for x in t.values()], dtype=np.float64)
+        scores[s] = v
+        two = np.unique(v)[:2]
+        kept = v[(v != 0.0) & ~np.isin(v, two)]
+        tables[s] = np.quantile(kept, np.linspace(0, 1, n_points + 1)) if kept.size else np.full(n_points + 1, np.nan)
+    return scores, tables
 
 
 # ---------------------------------------------------------------------------------------
