@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfusion_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 FZ_OK, FZ_ERR_ARG, FZ_ERR_UNSUPPORTED, FZ_ERR_HIP, FZ_ERR_WORKSPACE = 0, -1, -2, -3, -4
 NORMS = {"min-max": 1, "z-score": 2, "arctan": 3, "percentile-rank": 4, "normal-curve-equivalent": 5}
@@ -54,6 +54,7 @@ _PROTOS = {
     "fz_minmax_from_orders_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "fz_minmax_from_order_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "fz_fuse_none_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "fz_fuse_wsum_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fz_insertion_order_workspace_bytes": (_sz, [_i, _i]),
     "fz_insertion_order": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "fz_topk_max_k": (_i, []),
@@ -66,6 +67,7 @@ _PROTOS = {
     "fz_bm25_scores_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "fz_tune_max_gold": (_i, []),
     "fz_gold_ranks_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "fz_gold_ranks_f64w": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fz_attn_varlen_f32": (_i, [_vp, _i, _vp, _i, _i, _i, C.c_float, _vp, _i, _vp]),
     "fz_add_layernorm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, C.c_float, _i, _i, _vp, _i, _vp]),
     "fz_gelu_f32": (_i, [_vp, _vp, _sz, _vp]),

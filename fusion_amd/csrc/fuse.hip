@@ -3,6 +3,7 @@
 //   K3  fz_row_stats_f32      per-(system,query) min/max or mean/unbiased-std     (hybrid.py:255-263)
 //   K4  fz_fuse_nsf_f32       normalise -> weight -> sum, ONE pass over HBM         (hybrid.py:212-214,291,304)
 //       fz_fuse_none_f64      'none' passthrough, float64                          (hybrid.py:280,291,304)
+//       fz_fuse_wsum_f64      weight + sum with NumPy's scalar promotion (np.float64 grid weights, float64 planes)
 //   K5b fz_fuse_rank_f64      rrf / bcf from rank planes, float64                  (hybrid.py:248-252,304)
 //       fz_insertion_order    first-insertion order of the fused dict              (hybrid.py:301-304)
 //
@@ -628,41 +629,69 @@ __global__ void minmax_from_order_kernel(const float* __restrict__ scores, const
 // 4 columns per thread (16-B rank/score loads, 32-B stores).
 // -------------------------------------------------------------------------------------
 struct ElemArgs {
-    const float* planes[FZ_MAX_SYSTEMS];
+    const void* planes[FZ_MAX_SYSTEMS];   // float32 planes, or float64 where bit s of f64_mask is set (fuse_wsum only)
     const int32_t* ranks[FZ_MAX_SYSTEMS];
     double w[FZ_MAX_SYSTEMS];
     int S, N, ld, Q, method;
     const int32_t* lens;
+    unsigned f64_mask;      // plane s holds doubles (BM25 scores, raw Python floats of a host list)
+    unsigned narrow_mask;   // weight s is a weak / float32 scalar: fl32 product, and the sum stays fl32 until a wide product arrives
 };
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void fuse_none_kernel(ElemArgs a, double* __restrict__ fused) {
+// Weight-and-sum with NumPy-2's scalar promotion (hybrid.py:291,304) -> float64 plane.
+//   'none' / unknown normalisation: raw Python-float scores, float64 throughout (narrow_mask = 0);
+//   np.float64 weights (the tuning grid, hybrid.py:405-409): np.float32 score * np.float64 -> float64 products;
+//   the per-document accumulator (Python 0.0, weak) is float32 until ITS first float64 product, float64 after.
+// fl32(fl64(a) op fl64(b)) == fl32(a op b) for floats a, b (53 >= 2*24+2: double rounding is innocuous), so the narrow
+// steps are computed on doubles and rounded.  MIXED = some plane is float64 or some weight narrow (otherwise the plain
+// float32-planes / float64-arithmetic passthrough).
+template <bool VEC, bool MIXED>
+__global__ __launch_bounds__(256) void fuse_wsum_kernel(ElemArgs a, double* __restrict__ fused) {
     const int q = blockIdx.y;
     const size_t rowoff = (size_t)q * a.ld;
     const int j0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
     if (j0 >= a.N) return;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     bool present[4] = {false, false, false, false};
+    bool wide[4] = {false, false, false, false};
     const bool full = VEC && (j0 + 3 < a.N);
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    typedef int i4v __attribute__((ext_vector_type(4)));
     for (int s = 0; s < a.S; ++s) {
-        float v[4]; int r[4] = {0, 0, 0, 0};
-        if (full) {
-            typedef float f4v __attribute__((ext_vector_type(4)));
-            typedef int i4v __attribute__((ext_vector_type(4)));
-            const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.planes[s] + rowoff + j0));   // streamed once
-            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        double v[4]; int r[4] = {0, 0, 0, 0};
+        const bool p64 = MIXED && ((a.f64_mask >> s) & 1u);
+        const bool narrow = MIXED && !p64 && ((a.narrow_mask >> s) & 1u);
+        if (full) {   // streamed once: non-temporal
+            if (p64) {
+                const double* x = reinterpret_cast<const double*>(a.planes[s]) + rowoff + j0;
+                const d2v lo = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(x));
+                const d2v hi = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(x + 2));
+                v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+            } else {
+                const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(a.planes[s]) + rowoff + j0));
+                v[0] = (double)f.x; v[1] = (double)f.y; v[2] = (double)f.z; v[3] = (double)f.w;
+            }
             if (a.ranks[s]) { const i4v t = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(a.ranks[s] + rowoff + j0)); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
         } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                bool in = j0 + c < a.N;
-                v[c] = in ? a.planes[s][rowoff + j0 + c] : 0.f;
+                const bool in = j0 + c < a.N;
+                v[c] = !in ? 0.0 : (p64 ? reinterpret_cast<const double*>(a.planes[s])[rowoff + j0 + c]
+                                        : (double)reinterpret_cast<const float*>(a.planes[s])[rowoff + j0 + c]);
                 r[c] = in ? (a.ranks[s] ? a.ranks[s][rowoff + j0 + c] : 0) : -1;
             }
         }
+        const double w = narrow ? (double)(float)a.w[s] : a.w[s];   // weak scalar: np.float32(w)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (r[c] >= 0) { double prod = (double)v[c] * a.w[s]; acc[c] = acc[c] + prod; present[c] = true; }
+            if (r[c] >= 0) {
+                double prod = v[c] * w;
+                if (narrow) prod = (double)(float)prod; else wide[c] = true;
+                acc[c] = acc[c] + prod;
+                if (MIXED && !wide[c]) acc[c] = (double)(float)acc[c];
+                present[c] = true;
+            }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -958,6 +987,20 @@ static bool elem_aligned(const ElemArgs& a, const void* fused, bool planes) {
     return al;
 }
 
+static int launch_wsum(ElemArgs& a, double* fused, void* stream) {
+    dim3 grid((unsigned)((a.N + 1023) / 1024), (unsigned)a.Q);
+    bool al = (a.ld % 4 == 0) && ((uintptr_t)fused % 16 == 0);
+    for (int s = 0; s < a.S; ++s) al = al && ((uintptr_t)a.planes[s] % 16 == 0) && (!a.ranks[s] || (uintptr_t)a.ranks[s] % 16 == 0);
+    const bool mixed = a.f64_mask != 0u || a.narrow_mask != 0u;
+    hipStream_t st = as_stream(stream);
+    if (al && mixed) fuse_wsum_kernel<true, true><<<grid, 256, 0, st>>>(a, fused);
+    else if (al) fuse_wsum_kernel<true, false><<<grid, 256, 0, st>>>(a, fused);
+    else if (mixed) fuse_wsum_kernel<false, true><<<grid, 256, 0, st>>>(a, fused);
+    else fuse_wsum_kernel<false, false><<<grid, 256, 0, st>>>(a, fused);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
 extern "C" int fz_fuse_none_f64(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q,
                                 int N, int ld, double* fused, void* stream) {
     if (!planes_h || !w_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
@@ -971,11 +1014,25 @@ extern "C" int fz_fuse_none_f64(const float* const* planes_h, const int32_t* con
         a.ranks[s] = ranks_h ? ranks_h[s] : nullptr;
         a.w[s] = w_h[s];
     }
-    dim3 grid((unsigned)((N + 1023) / 1024), (unsigned)Q);
-    if (elem_aligned(a, fused, true)) fuse_none_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(a, fused);
-    else fuse_none_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(a, fused);
-    FZ_LAUNCH_CHECK();
-    return FZ_OK;
+    return launch_wsum(a, fused, stream);
+}
+
+extern "C" int fz_fuse_wsum_f64(const void* const* planes_h, const int32_t* plane_is_f64_h, const int32_t* const* ranks_h,
+                                const double* w_h, const int32_t* narrow_h, int S, int Q, int N, int ld, double* fused, void* stream) {
+    if (!planes_h || !w_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (Q == 0 || N == 0) return FZ_OK;                 // empty tensors carry null pointers
+    if (!fused) return FZ_ERR_ARG;
+    ElemArgs a{};
+    a.S = S; a.N = N; a.ld = ld; a.Q = Q;
+    for (int s = 0; s < S; ++s) {
+        if (!planes_h[s]) return FZ_ERR_ARG;
+        a.planes[s] = planes_h[s];
+        a.ranks[s] = ranks_h ? ranks_h[s] : nullptr;
+        a.w[s] = w_h[s];
+        if (plane_is_f64_h && plane_is_f64_h[s]) a.f64_mask |= 1u << s;
+        if (narrow_h && narrow_h[s]) a.narrow_mask |= 1u << s;
+    }
+    return launch_wsum(a, fused, stream);
 }
 
 extern "C" int fz_fuse_rank_f64(const int32_t* const* ranks_h, const int32_t* lens, int S, int Q, int N, int ld, int method,

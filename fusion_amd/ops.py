@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -403,6 +404,42 @@ def fuse_none(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | Non
     return fused
 
 
+def is_wide_weight(w) -> bool:
+    """NumPy-2 promotion of `np.float32 score * w` (hybrid.py:291): the product is float64 only for an np.float64 weight
+    -- which is what the tuning grid holds (np.arange, hybrid.py:405-409); a Python float / int is a weak scalar and
+    np.float32 / np.float16 keep float32.  (np.float64 subclasses float, so it is tested by its own type.)"""
+    return isinstance(w, (np.float64, np.longdouble))
+
+
+def fuse_wsum(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None, weights, narrow=None) -> torch.Tensor:
+    """Weight-and-sum -> float64 plane, with NumPy's scalar promotion (fz_fuse_wsum_f64): planes may be float32 or float64
+    (per system); narrow[s] = the weight is weak / float32 (fl32 product; the document's sum stays fl32 until its first
+    float64 product).  narrow=None: everything float64 (the 'none' passthrough, hybrid.py:280,291,304)."""
+    S = len(planes)
+    for p in planes:
+        _dev(p, None, "fuse_wsum(planes)")
+        if p.dtype not in (torch.float32, torch.float64):
+            raise TypeError(f"fuse_wsum(planes): expected float32 or float64, got {p.dtype}")
+    if ranks:
+        _need(len(ranks) == S, f"fuse_wsum: {S} planes but {len(ranks)} rank planes")
+        for r in ranks:
+            if r is not None:
+                _dev(r, torch.int32, "fuse_wsum(ranks)")
+    _same_shape(list(planes) + (list(ranks) if ranks else []), "fuse_wsum")
+    _need(len(weights) == S, f"fuse_wsum: {S} planes but {len(weights)} weights")
+    both = harmonise(list(planes) + (list(ranks) if ranks else []))
+    planes, ranks = both[:S], (both[S:] if ranks else None)
+    Q, N = planes[0].shape
+    ld = _same_ld(*planes, *([r for r in ranks if r is not None] if ranks else []))
+    fused = torch.empty((max(Q, 1), ld), dtype=torch.float64, device=planes[0].device)[:Q, :N]
+    w = (C.c_double * S)(*[float(x) for x in weights])
+    p64 = (C.c_int32 * S)(*[int(p.dtype == torch.float64) for p in planes])
+    nr = (C.c_int32 * S)(*[int(bool(n)) for n in (narrow if narrow is not None else [False] * S)])
+    check(_lib.lib().fz_fuse_wsum_f64(_ptr_array(planes), p64, None if ranks is None else _ptr_array(ranks), w, nr, S, Q, N, ld,
+                                      _ptr(fused), _stream(planes[0])), "fz_fuse_wsum_f64")
+    return fused
+
+
 def insertion_order(orders: list[torch.Tensor], lens: torch.Tensor, N: int):
     """First-insertion order of the fused dict (hybrid.py:301-304). Returns (ins_order [Q,N] int32, U [Q] int32)."""
     for o in orders:
@@ -426,11 +463,14 @@ def insertion_order(orders: list[torch.Tensor], lens: torch.Tensor, N: int):
 def gold_ranks(T: list[torch.Tensor], pos: torch.Tensor, weights: torch.Tensor, gold: torch.Tensor) -> torch.Tensor:
     """Fused ranks of the gold documents for every weight vector (N1, hybrid.py:404-426).
     T[s] [Q,N] normalised planes, pos [Q,N] int32 insertion positions (-1 absent), weights [W,S] fp32,
-    gold [Q,G] int32 corpus positions (-1 pad) -> ranks [W,Q,G] int32 (0 where gold is padding / unlisted: check pos)."""
+    gold [Q,G] int32 corpus positions (-1 pad) -> ranks [W,Q,G] int32 (0 where gold is padding / unlisted: check pos).
+    float64 weights select the float64 sweep (np.float64 grid weights: NumPy promotes the products and sums)."""
     for t in T:
         _dev(t, torch.float32, "gold_ranks(T)")
     _dev(pos, torch.int32, "gold_ranks(pos)")
-    _dev(weights, torch.float32, "gold_ranks(weights)")
+    _dev(weights, None, "gold_ranks(weights)")
+    if weights.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"gold_ranks(weights): expected float32 or float64, got {weights.dtype}")
     _dev(gold, torch.int32, "gold_ranks(gold)")
     lib = _lib.lib()
     G = int(lib.fz_tune_max_gold())
@@ -443,8 +483,9 @@ def gold_ranks(T: list[torch.Tensor], pos: torch.Tensor, weights: torch.Tensor, 
         raise ValueError(f"weights must be [W,{len(T)}] and gold [Q,{G}]")
     ld = _same_ld(*T, pos)
     out = torch.zeros((W, Q, G), dtype=torch.int32, device=T[0].device)
-    check(lib.fz_gold_ranks_f32(_ptr_array(T), _ptr(pos), _ptr(weights.contiguous()), _ptr(gold.contiguous()), S, W, Q, N, ld, _ptr(out),
-                                _stream(T[0])), "fz_gold_ranks_f32")
+    fn = lib.fz_gold_ranks_f64w if weights.dtype == torch.float64 else lib.fz_gold_ranks_f32
+    check(fn(_ptr_array(T), _ptr(pos), _ptr(weights.contiguous()), _ptr(gold.contiguous()), S, W, Q, N, ld, _ptr(out), _stream(T[0])),
+          "fz_gold_ranks")
     return out
 
 

@@ -24,6 +24,9 @@ class RankedSystem:
     sorted_scores: torch.Tensor | None = None   # [Q, N] scores in rank order (same dtype as the ranking keys)
     full: bool = True             # every list covers all N docs (lens == N)
     meta: dict = field(default_factory=dict)
+    scores64: torch.Tensor | None = None   # [Q, N] float64 plane when the raw scores are not float32 values (BM25's Python
+                                           # floats, host lists): the 'none' passthrough keeps them unrounded (hybrid.py:280)
+    score_sorted: bool = False    # every list is in descending order of its float32 scores (rankers: yes; host lists: checked)
 
     @property
     def Q(self) -> int:

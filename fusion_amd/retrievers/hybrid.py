@@ -63,7 +63,7 @@ def _rank_scores(scores: torch.Tensor, ids: np.ndarray, return_topk: int | None)
         rank = torch.where(rank < k, rank, torch.full_like(rank, -1))
         order = order.clone()
         order[:, k:] = -1
-    return RankedSystem(scores=scores, order=order, rank=rank, lens=lens, ids=ids, sorted_scores=sk, full=full)
+    return RankedSystem(scores=scores, order=order, rank=rank, lens=lens, ids=ids, sorted_scores=sk, full=full, score_sorted=True)
 
 
 class Ranker:
@@ -193,18 +193,24 @@ class Aggregator:
             if percentile_distributions is None:            # the reference calls .get() on it for every system (hybrid.py:213)
                 raise AttributeError("'NoneType' object has no attribute 'get'")
             w = [linear_weights[n] for n in names]          # KeyError when a system has no weight (hybrid.py:214)
-            if normalization in ("percentile-rank", "normal-curve-equivalent"):
-                distr = [cls._table(percentile_distributions.get(n), dev) for n in names]
-                fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, distr)
-            elif normalization == "min-max":                # ranked systems: min / max are the two ends of every list, no row reduction
-                fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, orders=[s.order for s in S],
-                                     lens=torch.stack([s.lens for s in S]).contiguous())
-            elif normalization in ("z-score", "arctan"):
-                fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization)
-            else:                                           # 'none' / unknown string: passthrough (hybrid.py:280)
-                fused = ops.fuse_none([s.scores for s in S], ranks, w)
+            wide = [ops.is_wide_weight(x) for x in w]       # np.float64 weights (the tuning grid): NumPy promotes to float64
+            if normalization in ("min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent"):
+                distr = None
+                if normalization in ("percentile-rank", "normal-curve-equivalent"):
+                    distr = [cls._table(percentile_distributions.get(n), dev) for n in names]
+                if any(wide):   # transform every system in float32 (weight 1: fl32(t * 1) == t), then weight + sum as NumPy does
+                    T = [ops.fuse_nsf([s.scores], [s.rank], [1.0], normalization, None if distr is None else [distr[i]]) for i, s in enumerate(S)]
+                    fused = ops.fuse_wsum(T, [s.rank for s in S], w, narrow=[not x for x in wide])
+                elif normalization == "min-max" and all(s.score_sorted for s in S):
+                    # score-sorted lists: min / max are the two ends of every list, no row reduction
+                    fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, orders=[s.order for s in S],
+                                         lens=torch.stack([s.lens for s in S]).contiguous())
+                else:           # the statistics are taken over the VALUES, whatever the list order (hybrid.py:255-262)
+                    fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, distr)
+            else:                                           # 'none' / unknown string: raw Python floats, float64 (hybrid.py:280)
+                fused = ops.fuse_wsum([s.scores if s.scores64 is None else s.scores64 for s in S], ranks, w)
         else:                                               # unknown method: raw scores are summed (hybrid.py:203-218)
-            fused = ops.fuse_none([s.scores for s in S], ranks, [1.0] * len(S))
+            fused = ops.fuse_wsum([s.scores if s.scores64 is None else s.scores64 for s in S], ranks, [1.0] * len(S))
 
         if all_full:
             # first-insertion order == system 0's ranking: its rank plane places every doc (coalesced, no gather)
@@ -229,8 +235,13 @@ class Aggregator:
         systems = cls._to_device(ranked_lists)
         names = list(systems.keys())
         S = [systems[n] for n in names]
-        if normalization not in ("min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent") or len(S) > 4:
+        # NumPy promotion (hybrid.py:291,304): the reference's grid (np.arange, :405-409) holds np.float64 weights -> float64
+        # products and sums; a grid of Python floats fuses in float32.  A grid that mixes the two kinds goes the generic way.
+        kinds = {ops.is_wide_weight(x) for w in weight_combinations for x in w.values()}
+        if (normalization not in ("min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent") or len(S) > 4
+                or len(kinds) > 1):
             return cls._tune_by_fusing(systems, normalization, weight_combinations, labels, percentile_distributions)
+        wide = kinds == {True}
         Q, N = S[0].Q, S[0].N
         dev = S[0].scores.device
         all_full = all(s.full for s in S)
@@ -254,7 +265,8 @@ class Aggregator:
             valid = r < U.unsqueeze(1)
             rows = torch.arange(Q, device=dev).unsqueeze(1).expand(Q, N)
             pos[rows[valid], ins.long()[valid]] = r[valid]
-        weights = torch.tensor([[np.float32(w[n]) for n in names] for w in weight_combinations], dtype=torch.float32, device=dev)  # KeyError as hybrid.py:214
+        weights = torch.tensor([[float(w[n]) for n in names] for w in weight_combinations],      # KeyError as hybrid.py:214
+                               dtype=torch.float64).to(torch.float64 if wide else torch.float32).to(dev)
         id2pos = {cid: j for j, cid in enumerate(S[0].ids.tolist())}
         gold_pos = [[id2pos.get(g, -1) for g in dict.fromkeys(gl)] for gl in labels]   # unique, order kept
         G = int(ops._lib.lib().fz_tune_max_gold())
@@ -323,23 +335,29 @@ class Aggregator:
         ld = ops.round_up(N, 64)
         out = {}
         for n in names:
-            sc = np.zeros((Q, ld), dtype=np.float32)
+            sc64 = np.zeros((Q, ld), dtype=np.float64)
             rk = np.full((Q, ld), -1, dtype=np.int32)
             od = np.full((Q, ld), -1, dtype=np.int32)
             ln = np.zeros(Q, dtype=np.int32)
+            is_sorted = True
             for q, lst in enumerate(ranked_lists[n]):
                 d = {}
                 for x in lst:            # convert2dict (hybrid.py:231): first position kept, last score wins
                     d[x["corpus_id"]] = x["score"]
                 if d:
                     j = np.fromiter((pos[c] for c in d.keys()), dtype=np.int64, count=len(d))
-                    sc[q, j] = np.fromiter(d.values(), dtype=np.float64, count=len(d)).astype(np.float32)
+                    v = np.fromiter(d.values(), dtype=np.float64, count=len(d))
+                    sc64[q, j] = v
                     rk[q, j] = np.arange(len(d), dtype=np.int32)
                     od[q, : len(d)] = j
+                    v32 = v.astype(np.float32)
+                    is_sorted = is_sorted and bool(np.all(v32[:-1] >= v32[1:]))   # False for NaN as well
                 ln[q] = len(d)
+            sc = sc64.astype(np.float32)     # torch.tensor(list(values), dtype=float32) of the normalisations (hybrid.py:255)
             t = lambda a: torch.from_numpy(a).to(dev)[:, :N]
+            exact32 = bool(np.array_equal(sc.astype(np.float64), sc64, equal_nan=True))
             out[n] = RankedSystem(scores=t(sc), order=t(od), rank=t(rk), lens=torch.from_numpy(ln).to(dev), ids=ids,
-                                  full=bool((ln == N).all()))
+                                  full=bool((ln == N).all()), scores64=None if exact32 else t(sc64), score_sorted=is_sorted)
         return out
 
     # -- the reference's small helpers, kept for API compatibility ---------------------------
@@ -496,7 +514,7 @@ def main(args):
     return run_evaluation(predictions=predictions, labels=pos_pids, args=args)
 
 
-def analyze_score_distributions(args, results: dict[str, RankedSystem], corpus: dict, pos_pids: list[list]):
+def analyze_score_distributions(args, results: dict[str, RankedSystem], corpus: dict, pos_pids: list[list], table_sizes=None):
     """hybrid.py:363-402: per-system transformed scores of every (query, document), quantile tables of 1k / 10k / 100k /
     |corpus| points (the input of the percentile-rank / NCE normalisations, hybrid.py:412,451) and the scores of the
     positives vs as many random negatives.  The transform runs once per system on the device (one fusion-kernel pass
@@ -512,25 +530,31 @@ def analyze_score_distributions(args, results: dict[str, RankedSystem], corpus: 
     random.seed(42)
     max_pid = max(corpus.keys())
     neg_pids = [random.sample(list(set(range(1, max_pid + 1)) - set(x)), k=len(x)) for x in pos_pids]   # hybrid.py:368
-    transformed = {}
+    transformed, in_list_order = {}, {}
     for n in names:
         rs = results[n]
         if args.normalization in ("min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent"):
             d = [Aggregator._table(distr.get(n), dev)] if n in distr else None
             t = ops.fuse_nsf([rs.scores], None if rs.full else [rs.rank], [1.0], args.normalization, d)
         else:
-            t = rs.scores                                                        # 'none': raw scores (hybrid.py:280)
+            t = rs.scores if rs.scores64 is None else rs.scores64                # 'none': the raw Python floats (hybrid.py:280)
+        lens = rs.lens.cpu().numpy()
+        by_rank = torch.gather(t, 1, rs.order.clamp(min=0).long()).cpu().numpy().astype(np.float64)   # [q, r] = score at list position r
+        in_list_order[n] = [by_rank[q, : lens[q]] for q in range(rs.Q)]
         t = t.cpu().numpy().astype(np.float64)
         listed = np.ones_like(t, dtype=bool) if rs.full else (rs.rank.cpu().numpy() >= 0)
         transformed[n] = (t, listed)
     ids = results[names[0]].ids
     id2pos = {c: j for j, c in enumerate(ids.tolist())}
-    # scores_{norm}_{eval}_{split}.csv: one row per (system, query, listed document)   (hybrid.py:379,387)
-    frames = [pd.DataFrame({"system": n, "score": t[l]}) for n, (t, l) in transformed.items()]
-    all_scores_df = pd.concat(frames, ignore_index=True)
+    # scores_{norm}_{eval}_{split}.csv: one row per (query, system, listed document), in the reference's order: query by query,
+    # system by system, each list from its head (hybrid.py:370-379,387)
+    Q = results[names[0]].Q
+    all_scores_df = pd.DataFrame({
+        "system": np.concatenate([np.repeat(n, len(in_list_order[n][q])) for q in range(Q) for n in names]) if Q else np.array([], dtype=str),
+        "score": np.concatenate([in_list_order[n][q] for q in range(Q) for n in names]) if Q else np.array([], dtype=np.float64)})
     all_scores_df.to_csv(join(args.output_dir, f"scores_{args.normalization}_{args.eval_type}_{args.data_split}.csv"), index=False)
     # quantile tables (hybrid.py:390-397): drop zeros and each system's two smallest distinct scores, then N+1 quantiles
-    for N in [1000, 10000, 100000, len(corpus)]:
+    for N in (table_sizes or [1000, 10000, 100000, len(corpus)]):
         cols = {}
         for n, (t, l) in transformed.items():
             v = t[l]

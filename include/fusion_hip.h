@@ -141,6 +141,15 @@ int fz_minmax_from_orders_f32(const float* const* planes_h, const int32_t* const
 /* 'none' / unknown normalisation: fused[q][j] = sum_s (double)score_s * w_s in fp64 (hybrid.py:280,291,304) */
 int fz_fuse_none_f64(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
                      int ld, double* fused, void* stream);
+/* Weight-and-sum with NumPy's scalar promotion, for what the two entries above do not cover (hybrid.py:291,304):
+ *   plane_is_f64_h[s] != 0: planes_h[s] is a float64 plane (BM25's Python-float scores, raw scores of a host list) --
+ *     the 'none' passthrough keeps them unrounded;
+ *   narrow_h[s] != 0: w_s is a weak (Python float) or float32 weight: fl32 product, and a document's sum stays fl32 until
+ *     its first float64 product; narrow_h[s] == 0: w_s is an np.float64 (the tuning grid, hybrid.py:405-409): float64.
+ * Inputs for the normalised modes are the per-system transformed planes (fz_fuse_nsf_f32 of one system, weight 1).
+ * Both arrays nullable (= all float32 planes, all wide: fz_fuse_none_f64). */
+int fz_fuse_wsum_f64(const void* const* planes_h, const int32_t* plane_is_f64_h, const int32_t* const* ranks_h,
+                     const double* w_h, const int32_t* narrow_h, int S, int Q, int N, int ld, double* fused, void* stream);
 
 /* ---- first-insertion order of the fused dict, hybrid.py:301-304 (tie-break, SURVEY KAT-1) */
 /* ins_order[q][0..U[q]) = docs in the order aggregate_scores first inserts them: system by system,
@@ -192,6 +201,10 @@ int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* 
 int fz_tune_max_gold(void);
 int fz_gold_ranks_f32(const float* const* T_h, const int32_t* pos, const float* weights, const int32_t* gold, int S, int W,
                       int Q, int N, int ld, int32_t* out_ranks, void* stream);
+/* The same with np.float64 weights [W][S] -- what the reference's own grid holds (np.arange, hybrid.py:405-409): float64
+ * products and sums (NumPy promotion of np.float32 * np.float64), ranks by the float64 fused score. */
+int fz_gold_ranks_f64w(const float* const* T_h, const int32_t* pos, const double* weights, const int32_t* gold, int S, int W,
+                       int Q, int N, int ld, int32_t* out_ranks, void* stream);
 
 /* ---- encoder side: the per-sequence parts of SentenceTransformer.encode (hybrid.py:97-102) on PACKED token rows -- */
 /* Self-attention of a BERT/CamemBERT layer for ragged sequences without padding: for every sequence and head,

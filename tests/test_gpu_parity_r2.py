@@ -1,0 +1,244 @@
+"""GPU parity against the round-2 reference fixtures (oracle/gen_golden.py): the HIP scoring / search / SPLADE-pooling
+kernels against outputs of the reference's own splade/base.py + splade.py, Aggregator.tune against the reference's
+weight-grid loop, analyze_score_distributions against the reference's analysis recipe, unsorted / duplicate-id lists.
+Everything goes through the C ABI (fusion_amd.ops / the drop-in classes)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from helpers import assert_ranked_close, load_lists, sparse_to_dense
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 2e-6     # |cosine error| of fp32 rows; raw dot products: relative to the largest score
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from fusion_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---- scoring: compute_batchwise_similarity (splade/base.py:186-197) --------------------------------------------------
+def test_cos_and_dot_match_reference_dpr(ops):
+    z = np.load(os.path.join(GOLDEN, "sim_dpr_Q8_N300_d768.npz"))
+    Qe, De = dev(z["Qe"]), dev(z["De"])
+    c = ops.cos_scores(Qe, De).cpu().numpy()
+    assert np.max(np.abs(c - z["cos_sim"])) <= COS_TOL
+    assert np.array_equal(c[:, 17], c[:, 3])                       # duplicated document: identical scores
+    assert np.max(np.abs(c[:, 40] - c[:, 41])) <= 1e-7             # cosine ignores the scale of a row
+    d = ops.dot_scores(Qe, De).cpu().numpy()
+    assert np.max(np.abs(d - z["dot_score"])) <= COS_TOL * np.max(np.abs(z["dot_score"]))
+
+
+def test_cos_and_dot_match_reference_splade(ops):
+    z = np.load(os.path.join(GOLDEN, "sim_splade_Q4_N257_V32005.npz"))
+    Q, N, V = (int(x) for x in z["shape"])
+    Qs, Ds = dev(sparse_to_dense(z, "q", Q, V)), dev(sparse_to_dense(z, "d", N, V))
+    assert np.max(np.abs(ops.cos_scores(Qs, Ds).cpu().numpy() - z["cos_sim"])) <= COS_TOL
+    assert np.max(np.abs(ops.dot_scores(ops.pad_dim(Qs), ops.pad_dim(Ds)).cpu().numpy() - z["dot_score"])) <= COS_TOL * np.max(np.abs(z["dot_score"]))
+
+
+# ---- search: chunked mm -> topk -> heap -> sorted (splade/base.py:199-251 == util.semantic_search, hybrid.py:103) ----
+@pytest.mark.parametrize("sim", ["cos_sim", "dot_score"])
+def test_search_matches_reference(ops, sim):
+    from fusion_amd.distributed import ShardedDenseIndex
+    from fusion_amd.retrievers.hybrid import _rank_scores
+    z = np.load(os.path.join(GOLDEN, "search_Q6_N1000_d64.npz"))
+    Qe, De = dev(z["Qe"]), dev(z["De"])
+    Q, N = Qe.shape[0], De.shape[0]
+    if sim == "cos_sim":
+        Qn, Dn = ops.normalize_rows(Qe), ops.normalize_rows(De)
+        tol = COS_TOL
+    else:
+        Qn, Dn = Qe, De
+        tol = COS_TOL * float(np.max(np.abs(z[f"scores__{sim}__kN_qc100_dc500000"])))
+    S = ops.dot_scores(Qn, Dn)
+    # (a) the full ranking hybrid.py:103 asks for (top_k = N): Ranker's score -> rank path
+    rs = _rank_scores(S, np.arange(N), None)
+    order, sk = rs.order.cpu().numpy(), rs.sorted_scores.cpu().numpy()
+    e_ids, e_sc = z[f"ids__{sim}__kN_qc100_dc500000"], z[f"scores__{sim}__kN_qc100_dc500000"]
+    for q in range(Q):
+        assert_ranked_close(order[q], sk[q], e_ids[q], e_sc[q], tol)
+        assert sorted(order[q].tolist()) == list(range(N))
+    for a, b in [(20, 500), (21, 501), (22, 999), (3, 700)]:      # exact duplicates: ties -> ascending document index
+        for q in range(Q):
+            pa, pb = int(np.flatnonzero(order[q] == a)[0]), int(np.flatnonzero(order[q] == b)[0])
+            assert sk[q, pa] == sk[q, pb] and pb == pa + 1
+    # (b) top-k of the chunked search: one-shot top-k, and the sharded index's chunked GEMM -> streaming top-k
+    for cfg in z["configs"]:
+        name, k, _qc, dc = str(cfg).split(":")
+        k, dc = int(k), int(dc)
+        e_ids, e_sc = z[f"ids__{sim}__{name}"], z[f"scores__{sim}__{name}"]
+        g_sc, g_ids = ops.topk_rows(S, min(k, N))
+        idx = ShardedDenseIndex(Dn, id_base=0)
+        idx.CHUNK = min(dc, N)           # the reference's document chunking
+        c_sc, c_ids = idx.search(Qn, k=min(k, N))
+        for q in range(Q):
+            assert_ranked_close(g_ids[q].cpu().numpy(), g_sc[q].cpu().numpy(), e_ids[q], e_sc[q], tol, truncated=k < N)
+            assert_ranked_close(c_ids[q].cpu().numpy(), c_sc[q].cpu().numpy(), e_ids[q], e_sc[q], tol, truncated=k < N)
+    if sim == "cos_sim":   # F.normalize's eps clamp: the zero vector scores exactly 0
+        assert np.all(S[:, 123].cpu().numpy() == 0.0)
+
+
+# ---- SPLADE pooling: SPLADE.forward (splade/splade.py:88-99), 'max' (the hybrid path's pooling, hybrid.py:96) --------
+def test_splade_max_pool_matches_reference(ops):
+    z = np.load(os.path.join(GOLDEN, "splade_pool_B5_L24_V509.npz"))
+    logits, lens = z["logits"], z["lens"]
+    rows = np.concatenate([logits[b, : lens[b]] for b in range(len(lens))])          # packed: attended tokens only
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device="cuda")
+    for pad in (0, 3):                                                                 # vector path (V % 4 == 0) and scalar path
+        x = np.pad(rows, ((0, 0), (0, pad))) if pad else rows
+        got = ops.segment_splade_max(dev(x), cu).cpu().numpy()[:, : rows.shape[1]]
+        assert np.max(np.abs(got - z["max"])) <= 5e-7      # log1p: ocml vs torch's vectorised CPU implementation, 2 ulp of <= 2.2
+        assert got[1, 7] == 0.0 and np.all(got >= 0)
+
+
+# ---- N1: the weight-grid loop (hybrid.py:404-426) ---------------------------------------------------------------------
+TUNE_FILES = ["tune_seed20_S2_Q4_N257_ties.npz", "tune_seed21_S3_Q4_N257_colbert_first.npz"]
+TUNE_NORMS = ["min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent", "none"]
+
+
+def load_tune(fname):
+    z = np.load(os.path.join(GOLDEN, fname), allow_pickle=False)
+    systems, lists, Q = load_lists(z)
+    labels = [[int(x) for x in str(s).split(",")] for s in z["labels"]]
+    distr = {s: z[f"distr_{s}"] for s in systems}
+    return z, systems, lists, labels, distr
+
+
+@pytest.mark.parametrize("fname", TUNE_FILES)
+@pytest.mark.parametrize("norm", TUNE_NORMS)
+def test_tune_matches_reference_loop(fname, norm):
+    """Aggregator.tune == the reference's loop (deepcopy -> fuse -> run_evaluation per lattice vector), every metric of
+    every weight vector within 1e-12.  NCE rows with a zero weight are undefined in the reference (-inf * 0 = NaN keys
+    handed to sorted()) and excluded."""
+    from fusion_amd.retrievers.hybrid import Aggregator, weight_grid
+    z, systems, lists, labels, distr = load_tune(fname)
+    grid = weight_grid(systems)                                   # np.arange lattice, np.float64 scalars, as hybrid.py:405-409
+    assert np.array_equal(np.array([[w[s] for s in systems] for w in grid]), z["weights"])
+    names = [str(x) for x in z["metric_names"]]
+    got = Aggregator.tune(lists, norm, grid, labels, distr)
+    assert all(list(g) == names for g in got)
+    G = np.array([[float(g[k]) for k in names] for g in got])
+    rows = np.all(z["weights"] != 0.0, axis=1) if norm == "normal-curve-equivalent" else slice(None)
+    assert np.max(np.abs(G - z[f"metrics__{norm}"])[rows]) <= 1e-12
+
+
+def test_tune_with_python_float_weights_is_the_float32_sweep(oracle):
+    """A grid of Python floats fuses in float32 under NumPy 2 (weak scalars): tune() must follow -- checked against the
+    oracle, which is pinned on both promotions."""
+    from fusion_amd.retrievers.hybrid import Aggregator
+    z, systems, lists, labels, distr = load_tune(TUNE_FILES[1])
+    grid = [{s: float(w) for s, w in zip(systems, row)} for row in z["weights"][::7]]
+    for norm in ("min-max", "percentile-rank"):
+        got = Aggregator.tune(lists, norm, grid, labels, distr)
+        exp = oracle.tune_lists(lists, norm, grid, labels, distr)
+        for g, e in zip(got, exp):
+            assert list(g) == list(e)
+            assert all(abs(float(g[k]) - float(e[k])) <= 1e-12 for k in e)
+
+
+@pytest.mark.parametrize("norm", ["min-max", "percentile-rank", "z-score"])
+def test_fuse_with_float64_weights_matches_reference_order(oracle, norm):
+    """Aggregator.fuse with np.float64 weights (float64 products and sums) against the oracle's pinned promotion rules:
+    ids identical, scores bit for bit (min-max / percentile) or within the z-score tolerance."""
+    from fusion_amd.retrievers.hybrid import Aggregator
+    z, systems, lists, labels, distr = load_tune(TUNE_FILES[1])
+    for row in z["weights"][[3, 57, 120, 200]]:
+        for kinds in ("wide", "mixed"):
+            w = {s: (np.float64(x) if (kinds == "wide" or i % 2 == 0) else float(x)) for i, (s, x) in enumerate(zip(systems, row))}
+            got = Aggregator.fuse(lists, "nsf", norm, w, distr)
+            exp = oracle.fuse_lists(lists, "nsf", norm, w, distr)
+            for gq, eq in zip(got, exp):
+                g_ids, e_ids = [x["corpus_id"] for x in gq], [x["corpus_id"] for x in eq]
+                g_sc, e_sc = [float(x["score"]) for x in gq], [float(x["score"]) for x in eq]
+                if norm == "z-score":
+                    assert_ranked_close(g_ids, g_sc, e_ids, e_sc, 2e-6)
+                else:
+                    assert g_ids == e_ids and g_sc == e_sc
+
+
+# ---- N4: score-distribution analysis (hybrid.py:363-402) --------------------------------------------------------------
+@pytest.mark.parametrize("norm", ["none", "min-max", "z-score", "arctan", "percentile-rank"])
+def test_analysis_outputs_match_reference(tmp_path, norm):
+    import argparse
+    import pandas as pd
+    from fusion_amd.retrievers.hybrid import Aggregator, analyze_score_distributions
+    z = np.load(os.path.join(GOLDEN, "analysis_seed31_S3_Q3_N120.npz"))
+    systems, lists, Q = load_lists(z)
+    corpus = {int(i): "" for i in z["corpus_ids"]}
+    pos_pids = [[int(x) for x in str(s).split(",")] for s in z["pos_pids"]]
+    out = str(tmp_path)
+    if norm == "percentile-rank":     # the reference reads the 'raw' tables back from disk (hybrid.py:374)
+        pd.DataFrame({s: z[f"table__none__1000__{s}"] for s in systems}).to_csv(os.path.join(out, "score_distributions_raw_indomain_10k.csv"), index=False)
+    args = argparse.Namespace(normalization=norm, output_dir=out, eval_type="indomain", data_split="test")
+    analyze_score_distributions(args, Aggregator._to_device(lists), corpus, pos_pids, table_sizes=(10, 1000))
+    tol = {"none": 0.0, "min-max": 0.0, "percentile-rank": 0.0, "z-score": 2e-6, "arctan": 1e-6}[norm]
+    # scores_{norm}_{eval}_{split}.csv: per system, every listed (query, document) transformed score, in list order
+    df = pd.read_csv(os.path.join(out, f"scores_{norm}_indomain_test.csv"), float_precision="round_trip")
+    for s in systems:
+        got = df.loc[df["system"] == s, "score"].to_numpy(dtype=np.float64)
+        exp = z[f"scores__{norm}__{s}"]
+        assert got.shape == exp.shape
+        assert np.max(np.abs(np.sort(got) - np.sort(exp))) <= max(tol, 1e-15)      # CSV text round trip of float64 is exact
+        if tol == 0.0:
+            assert np.array_equal(got, exp)                                         # same order: (query, list position)
+    # the quantile tables
+    for n_pts, tag in ((10, "0k"), (1000, "1k")):
+        t = pd.read_csv(os.path.join(out, f"score_distributions_{norm}_indomain_{tag}.csv"), float_precision="round_trip")
+        assert list(t.columns) == systems and len(t) == n_pts + 1
+        for s in systems:
+            assert np.max(np.abs(t[s].to_numpy() - z[f"table__{norm}__{n_pts}__{s}"])) <= tol + 1e-9
+    # labelled scores of the positives and of the random.seed(42) negatives
+    ldf = pd.read_csv(os.path.join(out, f"labeled_scores_{norm}_indomain_test.csv"), float_precision="round_trip")
+    assert ldf["label"].tolist() == [str(x) for x in z[f"labeled_label__{norm}"]]
+    for s in systems:
+        assert np.max(np.abs(ldf[s].to_numpy(dtype=np.float64) - z[f"labeled__{norm}__{s}"])) <= tol
+
+
+# ---- unsorted / duplicate-id host lists (hybrid.py:255-262: statistics over the VALUES) -------------------------------
+def test_unsorted_and_duplicate_lists_match_reference():
+    from fusion_amd.retrievers.hybrid import Aggregator
+    g = json.load(open(os.path.join(GOLDEN, "unsorted_fuse.json")))
+    for cname, case in g.items():
+        for key, exp in case["out"].items():
+            if key in ("rrf", "bcf"):
+                got, tol = Aggregator.fuse(case["lists"], key), 0.0
+            else:
+                got = Aggregator.fuse(case["lists"], "nsf", key, case["weights"], {})
+                tol = {"min-max": 0.0, "none": 0.0, "z-score": 2e-6, "arctan": 1e-6}[key]
+            assert len(got) == len(exp)
+            for gq, eq in zip(got, exp):
+                g_ids, e_ids = [x["corpus_id"] for x in gq], [x["corpus_id"] for x in eq]
+                g_sc, e_sc = [float(x["score"]) for x in gq], [x["score"] for x in eq]
+                if tol == 0.0:
+                    assert g_ids == e_ids and g_sc == e_sc, (cname, key)
+                else:
+                    assert_ranked_close(g_ids, g_sc, e_ids, e_sc, tol)
+
+
+def test_none_passthrough_keeps_float64_scores(oracle):
+    """'none' keeps the systems' Python floats (hybrid.py:280): BM25's float64 scores and host lists whose scores are not
+    float32 values must not be rounded on the way."""
+    from fusion_amd.retrievers.hybrid import Aggregator
+    rng = np.random.default_rng(3)
+    n = 200
+    ids = rng.permutation(np.arange(1, n + 1))
+    mk = lambda v: [{"corpus_id": int(i), "score": float(s)} for i, s in zip(ids, np.sort(v)[::-1])]
+    lists = {"a": [mk(rng.gamma(2.0, 1.7, n)) for _ in range(3)], "b": [mk(rng.normal(0, 1, n)) for _ in range(3)]}
+    w = {"a": 0.35, "b": 0.65}
+    got = Aggregator.fuse(lists, "nsf", "none", w, {})
+    exp = oracle.fuse_lists(lists, "nsf", "none", w, {})
+    assert got == exp
+    got = Aggregator.fuse(lists, "unknown-method")     # raw scores summed (hybrid.py:203-218)
+    assert got == oracle.fuse_lists(lists, "unknown-method")
