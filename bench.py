@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec end-to-end (encode + score + fuse) on synthetic LLeQA-shaped batches.
 
-One "step" = one pass of the hot path over one batch of Q synthetic queries, inputs resident in HBM:
+N = 1 (the headline line; `--workload lleqa`).  One "step" = one pass of the hot path over one batch of Q synthetic
+queries, inputs resident in HBM:
     1. encode      query token ids -> CamemBERT-base-shaped encoder (random init, fp32; padding-free forward: PyTorch-ROCm
                    hipBLASLt Linears + this repo's HIP embedding / attention / GELU / LayerNorm / pooling kernels) -> mean pool
     2. dpr score   normalise + fp32-MFMA cos-sim GEMM against the resident corpus embeddings   [Q, N]
@@ -12,10 +13,16 @@ One "step" = one pass of the hot path over one batch of Q synthetic queries, inp
     7. order       stable sort of the fused scores in first-insertion order -> final ranked lists [Q, N]
 (the BM25+DPR RRF hybrid of BASELINE.json configs[0] run on the configs[1] scale: N = 27,942, d = 768, Q = 1024).
 The corpus side (document embeddings, BM25 index) is built once, untimed: the corpus is static.
+In the same run, after the timed region, the other BASELINE.json configs are timed live with HIP events and reported
+under "configs_measured" (DPR GEMM, SPLADE-shaped GEMM, ColBERT MaxSim, 4-system nsf fusion with a 40 %-invalid ColBERT
+plane, the 1771-vector weight sweep, one mMARCO 1/8 shard) with the same roofline arithmetic.
 
-Launch: `python bench.py --gpus 1 --steps K --warmup W`, or under torch.distributed.run for N > 1 (one rank per
-GPU; queries are sharded across ranks, each rank holds a corpus replica, no data-path collective: weak scaling).
-`--workload mmarco` runs the corpus-sharded config 5 instead (RCCL all-gather of per-shard top-k).
+N > 1 (under torch.distributed.run, one rank per GPU; `--workload mmarco`, the default when WORLD_SIZE > 1): the
+corpus-SHARDED config 5 that north_star names for 2/4/8 GPUs -- mMARCO-fr-shaped 8,841,823 x 768 fp32 corpus row-sharded
+over the ranks, queries encoded data-parallel (all-gather of the [Q, 768] embeddings), local chunked fp32-MFMA GEMM ->
+streaming top-1000, ONE RCCL all-gather of the per-shard [Q, k] lists + identical local merge.  Strong scaling (the
+corpus is fixed).  `--workload lleqa` at N > 1 gives query-sharded replicas with no data-path collective instead.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -32,6 +39,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32, dense
+MFMA_F16_PEAK_TF = 2500.0      # v_mfma_f32_32x32x16_f16, dense
+METRIC = "queries/sec end-to-end (encode+score+fuse), LLeQA test; recall@500 parity"
+TRAFFIC_PROFILES = ("r02_hbm_traffic.json", "r01_hbm_traffic.json")
 
 
 def parse():
@@ -39,7 +49,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="lleqa", choices=["lleqa", "mmarco"])
+    p.add_argument("--workload", default="auto", choices=["auto", "lleqa", "mmarco"],
+                   help="auto: lleqa on one GPU, the corpus-sharded mmarco config when WORLD_SIZE > 1")
     p.add_argument("--queries", type=int, default=1024)
     p.add_argument("--corpus", type=int, default=27942)
     p.add_argument("--dim", type=int, default=768)
@@ -53,13 +64,17 @@ def parse():
     p.add_argument("--no-gemm-tuning", action="store_true",
                    help="leave the encoder's fp32 Linears to the library heuristics instead of PyTorch TunableOp (fusion_amd/tuned/gemm_gfx950.csv)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-configs", action="store_true", help="skip the configs_measured block (configs 2-5 timed live after the headline region)")
     p.add_argument("--mmarco-docs", type=int, default=8841823)
     p.add_argument("--topk", type=int, default=1000)
+    p.add_argument("--rehearsal", action="store_true",
+                   help="allow several ranks on one device (gloo only): rehearses the N > 1 control flow on a smaller box; the numbers mean nothing")
     return p.parse_args()
 
 
 class Events:
-    """HIP events on torch's current stream (every kernel of the step is launched on it)."""
+    """HIP events on torch's current stream (every kernel of the step is launched on it: fusion_amd.ops passes
+    torch.cuda.current_stream() to the C ABI).  Each mark closes the interval since the previous one."""
 
     def __init__(self):
         self.marks = []
@@ -70,10 +85,35 @@ class Events:
         self.marks.append((name, e))
 
     def durations_ms(self):
-        out = {}
+        """-> ({name: total ms}, {name: number of intervals})"""
+        tot, cnt = {}, {}
         for (n0, e0), (n1, e1) in zip(self.marks[:-1], self.marks[1:]):
-            out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
-        return out
+            tot[n1] = tot.get(n1, 0.0) + e0.elapsed_time(e1)
+            cnt[n1] = cnt.get(n1, 0) + 1
+        return tot, cnt
+
+
+def timeit_ms(f, n=10, warm=2):
+    """Average duration of f() over n back-to-back calls, HIP events on the current stream."""
+    for _ in range(warm):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def roof(kernel, ms, work, bound, **extra):
+    """One roofline record: algorithmic work per launch / measured launch duration against the guide's peak."""
+    peak, unit, scale = {"hbm": (HBM_PEAK_GBS * 1e9, "GB/s", 1e9), "mfma_f32": (MFMA_F32_PEAK_TF * 1e12, "TFLOP/s", 1e12),
+                         "mfma_f16": (MFMA_F16_PEAK_TF * 1e12, "TFLOP/s", 1e12)}[bound]
+    ach = work / (ms * 1e-3) if ms > 0 else 0.0
+    return dict(kernel=kernel, bound="hbm" if bound == "hbm" else "mfma", ms=ms, achieved=ach / scale, peak=peak / scale, unit=unit,
+                frac=ach / peak, **extra)
 
 
 def synth_bm25_index(N, rng):
@@ -87,22 +127,25 @@ def synth_bm25_index(N, rng):
     return V, lens, tok, doc, p
 
 
+def synth_query_tokens(rng, Q, vocab_size, pad_id, L=64):
+    """LLeQA questions: 8-64 word pieces."""
+    qlen = rng.integers(8, L + 1, Q)
+    ids = rng.integers(7, vocab_size - 1, (Q, L))
+    mask = (np.arange(L)[None, :] < qlen[:, None]).astype(np.int64)
+    return np.where(mask == 1, ids, pad_id), mask, qlen
+
+
 def build_lleqa(args, dev, rank):
     from fusion_amd import encoders, ops
     rng = np.random.default_rng(1234 + rank)
     Q, N, d = args.queries, args.corpus, args.dim
     st = {}
-    # encoder + query tokens (LLeQA questions: ~15-40 word pieces, padded to the batch maximum <= 64)
     if not args.no_encode:
         enc = encoders.random_init("dpr", device=dev, size=args.encoder_size, seed=0)
         if not args.no_gemm_tuning and args.encode_mode == "packed":
             encoders.enable_gemm_tuning()      # TunableOp picks the hipBLASLt / rocBLAS solution per Linear shape (same fp32 arithmetic)
         d = enc.dim
-        L = 64
-        qlen = rng.integers(8, L + 1, Q)
-        ids = rng.integers(7, enc.backbone.config.vocab_size - 1, (Q, L))
-        mask = (np.arange(L)[None, :] < qlen[:, None]).astype(np.int64)
-        ids = np.where(mask == 1, ids, enc.backbone.config.pad_token_id)
+        ids, mask, qlen = synth_query_tokens(rng, Q, enc.backbone.config.vocab_size, enc.backbone.config.pad_token_id)
         st["enc"], st["ids"], st["mask"] = enc, torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
         st["qlen"] = qlen   # host token counts (a tokenizer returns them): drives length-bucketed batching
     else:
@@ -167,7 +210,7 @@ def step_lleqa(st, ev=None):
         q_emb = st["enc"].encode_ids_fused(st["ids"], st["qlen"], st["buckets"])
     else:
         q_emb = st["enc"].encode_ids_bucketed(st["ids"], st["mask"], st["qlen"], st["buckets"])
-    if ev: ev.mark("encode")
+    if ev: ev.mark("encode_pool")
     Qn = ops.normalize_rows(q_emb)
     S = ops.dot_scores(Qn, st["Dn"])
     if ev: ev.mark("dpr_score")
@@ -183,66 +226,74 @@ def step_lleqa(st, ev=None):
     if ev: ev.mark("fuse_rrf")
     order, scores, _ = ops.sort_rows_desc(fused, init_rank=r_b)   # ties keep BM25's (system 0) order
     if ev: ev.mark("final_order")
-    return order, scores, (S, B)
+    return order, scores, (S, B, q_emb)
 
 
 def algorithmic_work(st):
-    """Algorithmic bytes / flops per launch of each hand-written kernel (SURVEY.md 8d figures x units per launch)."""
+    """Algorithmic bytes / flops PER LAUNCH of every kernel of the step (SURVEY.md 8d figures x the units one launch
+    processes).  hand=False marks vendor kernels (hipBLASLt): reported, never the "dominant hand-written kernel"."""
     Q, N, d = st["Q"], st["N"], st["d"]
     e = Q * N
-    extra = {}
+    w = {}
     if "enc" in st and st.get("encode_mode") == "packed":
         cfg = st["enc"].backbone.config
-        T = int(np.minimum(np.asarray(st["qlen"]), st["ids"].shape[1]).sum())
-        # per launch: the fused-QKV rows read once + the context rows written once (fp32); one launch per layer
-        extra["encode_attn"] = dict(kernel="attn_varlen_kernel", bound="hbm", work=T * 4 * cfg.hidden_size * 4, peak=HBM_PEAK_GBS * 1e9, unit="GB/s",
-                                    launches=cfg.num_hidden_layers)
-    return {
-        **extra,
-        "dpr_score": dict(kernel="dot_scores_kernel", bound="mfma", work=2.0 * Q * N * d, peak=MFMA_F32_PEAK_TF * 1e12, unit="TFLOP/s"),
-        "dpr_rank": dict(kernel="sort_rows_kernel<1024,28,1>", bound="hbm", work=e * (4 + 4 + 4), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
-        "bm25_rank": dict(kernel="sort_rows_kernel<1024,28,2>", bound="hbm", work=e * (8 + 4 + 4), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
-        "fuse_rrf": dict(kernel="fuse_rank_kernel", bound="hbm", work=e * (2 * 4 + 8), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
-        "final_order": dict(kernel="sort_rows_kernel<1024,28,2> (placed)", bound="hbm", work=e * (8 + 4 + 4 + 8), peak=HBM_PEAK_GBS * 1e9, unit="GB/s"),
-    }
+        h, ff = cfg.hidden_size, cfg.intermediate_size
+        T = int(np.minimum(np.asarray(st["qlen"]), st["ids"].shape[1]).sum())          # real token rows
+        Tp = -(-T // 512) * 512 if torch.cuda.tunable.is_enabled() else T               # rows the row-wise kernels and GEMMs see
+        # per layer: QKV (3h), out (h), FFN1 (ff), FFN2 (ff) -> 4 GEMM launches averaging this many flops each
+        w["encode_gemm"] = dict(kernel="hipBLASLt Cijk_* (4 Linears / layer, vendor)", bound="mfma_f32", hand=False,
+                                work=2.0 * Tp * h * (3 * h + h + 2 * ff) / 4)
+        w["encode_attn"] = dict(kernel="attn_varlen_kernel", bound="hbm", work=T * 4 * h * 4)   # fused-QKV rows in + context rows out
+        w["encode_ln"] = dict(kernel="add_layernorm_kernel", bound="hbm", work=3 * Tp * h * 4)  # y + residual in, x out
+        w["encode_gelu"] = dict(kernel="gelu_kernel", bound="hbm", work=2 * Tp * ff * 4)        # in place: read + write
+    w.update({
+        "dpr_score": dict(kernel="dot_scores_kernel (+ normalize_rows)", bound="mfma_f32", work=2.0 * Q * N * d),
+        "dpr_rank": dict(kernel="sort_rows_kernel (f32 keys)", bound="hbm", work=e * (4 + 4 + 4)),
+        "bm25_rank": dict(kernel="sort_rows_kernel (f64 keys)", bound="hbm", work=e * (8 + 4 + 4)),
+        "fuse_rrf": dict(kernel="fuse_rank_kernel", bound="hbm", work=e * (2 * 4 + 8)),
+        "final_order": dict(kernel="sort_rows_kernel (f64 keys, placed)", bound="hbm", work=e * (8 + 4 + 4 + 8)),
+    })
+    return w
 
 
-def measured_traffic(stage, st):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_hbm_traffic.json; FETCH_SIZE doubled
-    per the gfx950 correction of MI355X_MICROARCH.md).  Only valid for the shape they were collected on."""
+def profiled_traffic(stage, st):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/r0X_hbm_traffic.json;
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  NOT measured in this run: valid only for the
+    shape it was collected on, otherwise None.  Returns (bytes, source file)."""
     if (st["Q"], st["N"], st["d"]) != (1024, 27942, 768):
-        return None
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-    except OSError:
-        return None
-    key = {"dpr_score": "fz::dot_scores_kernel<true>(fz::GemmArgs)", "dpr_rank": "fz::sort_rows_kernel<1024, 28, 1>(fz::SortArgs)",
-           "bm25_rank": "fz::sort_rows_kernel<1024, 28, 2>(fz::SortArgs)", "final_order": "fz::sort_rows_kernel<1024, 28, 2>(fz::SortArgs)",
-           "fuse_rrf": "fz::fuse_rank_kernel<true>(fz::ElemArgs, double*)", "encode_attn": "fz::attn_varlen_kernel<2>(fz::AttnArgs)"}.get(stage)
-    return t.get(key, {}).get("hbm_bytes_corrected")
+        return None, None
+    pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1>", "bm25_rank": "sort_rows_kernel<1024, 28, 2>",
+            "final_order": "sort_rows_kernel<1024, 28, 2>", "fuse_rrf": "fuse_rank_kernel", "encode_attn": "attn_varlen_kernel",
+            "encode_gelu": "gelu_kernel", "encode_ln": "add_layernorm_kernel"}
+    for name in TRAFFIC_PROFILES:
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except OSError:
+            continue
+        for k, v in t.items():
+            if k != "_note" and pats.get(stage, "\0") in k:
+                return v.get("hbm_bytes_corrected"), f"profiles/{name}"
+    return None, None
 
 
-def cpu_baseline_lleqa(st, S_dev, B_dev, budget_s=20.0):
-    """The CPU oracle ("port") on a bounded sample of the SAME batch: score + rank + fuse + order for the first
-    q queries (no transformer forward on the CPU side), all host cores via OpenMP."""
+def cpu_baseline_lleqa(st, q_emb_dev, budget_s=20.0):
+    """The CPU oracle ("port") on a bounded sample of the SAME batch: score + rank + fuse + order for the first q
+    queries, all host cores via OpenMP, fed with the embeddings the DEVICE scored (so the parity figures below compare
+    like with like); plus the encode leg on the host (the HF module on torch's CPU threads)."""
+    import ctypes as C
     from oracle import oracle
     oracle.build()
     N, d = st["N"], st["d"]
     h = st["host"]
     qs = 8
     Dn = st["Dn"].cpu().numpy()[:, :d]
-    if "enc" in st:
-        with torch.no_grad():
-            q_emb = st["enc"].encode_ids(st["ids"][:64], st["mask"][:64]).cpu().numpy()
-    else:
-        q_emb = st["q_emb"][:64].cpu().numpy()
+    q_emb = q_emb_dev[:64].cpu().numpy()
 
     def run(q):
         t0 = time.perf_counter()
         Qn = oracle.normalize_rows(q_emb[:q])
         S = oracle.dot_scores(Qn, Dn, fma_chain=True)
         _, _, r_d = oracle.sort_rows_desc(S, want_rank=True)
-        import ctypes as C
         B = np.empty((q, N), dtype=np.float64)
         lib = oracle.lib()
         qoff = np.ascontiguousarray(h["qoff"][: q + 1]); qterms = np.ascontiguousarray(h["qterms"][: int(qoff[-1]) + 1])
@@ -288,6 +339,266 @@ def cpu_baseline_lleqa(st, S_dev, B_dev, budget_s=20.0):
     return res, out, q
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# configs_measured: BASELINE.json configs 2-5 at their quoted sizes, timed live with HIP events, same roofline arithmetic
+# ---------------------------------------------------------------------------------------------------------------------
+def rand_plane(ops, Q, N, g, scale=1.0, shift=0.0):
+    p = ops.alloc_plane(Q, N, torch.float32, "cuda")
+    p.copy_(torch.randn((Q, N), generator=g, device="cuda") * scale + shift)
+    return p
+
+
+def measure_configs(dev, N=27942):
+    from fusion_amd import ops
+    from fusion_amd.planes import RankedSystem
+    from fusion_amd.retrievers.hybrid import Aggregator, weight_grid
+    out = []
+    g = torch.Generator(device=dev).manual_seed(11)
+
+    # -- config 2: DPR bi-encoder dot-product scoring, full LLeQA corpus, Q in {195, 1024} --------------------------
+    d = 768
+    Dn = ops.normalize_rows(torch.randn((N, d), generator=g, device=dev))
+    Qn = ops.normalize_rows(torch.randn((1024, d), generator=g, device=dev))
+    S = ops.alloc_plane(1024, N, torch.float32, dev)
+    for Q in (1024, 195):
+        Qs, So = Qn[:Q].contiguous(), S[:Q]
+        ms = timeit_ms(lambda: ops.dot_scores(Qs, Dn, out=So), n=20)
+        out.append(dict(config="2: DPR cos-sim scoring", shape=dict(Q=Q, N=N, d=d), **roof("dot_scores_kernel", ms, 2.0 * Q * N * d, "mfma_f32")))
+        ms = timeit_ms(lambda: ops.sort_rows_desc(So, want_keys=False, want_rank=True), n=10)
+        out.append(dict(config="2: DPR full ranking", shape=dict(Q=Q, N=N), **roof("sort_rows_kernel (f32 keys)", ms, Q * N * 12, "hbm")))
+    del Dn, Qn
+
+    # -- config 3: ColBERT MaxSim, Q = 195, L_q = 64, L_d ~ clip(N(300,120),16,512), dim 128, fp16 unit-norm tokens ---
+    rng = np.random.default_rng(0)
+    lens = np.clip(rng.normal(300, 120, N), 16, 512).astype(np.int64)
+    off = np.zeros(N + 1, dtype=np.int64); off[1:] = np.cumsum(lens)
+    sumL = int(off[-1])
+    Dtok = torch.nn.functional.normalize(torch.randn((sumL, 128), generator=g, device=dev), dim=-1).half()
+    Doff = torch.from_numpy(off).to(dev)
+    for Q, n in ((195, 5), (1024, 2)):
+        Qtok = torch.nn.functional.normalize(torch.randn((Q, 64, 128), generator=g, device=dev), dim=-1).half()
+        So = S[:Q]
+        ms = timeit_ms(lambda: ops.maxsim(Qtok, Dtok, Doff, out=So, max_doc_len=512), n=n, warm=1)
+        out.append(dict(config="3: ColBERT MaxSim", shape=dict(Q=Q, N=N, Lq=64, sumL=sumL, dim=128),
+                        **roof("maxsim_kernel", ms, 2.0 * Q * 64 * sumL * 128, "mfma_f16")))
+    del Dtok, Qtok
+
+    # -- config 3b: SPLADE-shaped dense scoring, V = 32,005 (the reference scores SPLADE vectors densely, hybrid.py:101-103)
+    V, Vp, Q = 32005, 32008, 1024
+    Ds = torch.zeros((N, Vp), device=dev)
+    for c0 in range(0, N, 4096):
+        c1 = min(N, c0 + 4096)
+        Ds[c0:c1, :V] = torch.log1p(torch.relu(torch.randn((c1 - c0, V), generator=g, device=dev) - 1.0))
+    Ds = ops.normalize_rows(Ds)
+    Qs = torch.zeros((Q, Vp), device=dev); Qs[:, :V] = torch.log1p(torch.relu(torch.randn((Q, V), generator=g, device=dev) - 1.5))
+    Qs = ops.normalize_rows(Qs)
+    ms = timeit_ms(lambda: ops.dot_scores(Qs, Ds, out=S), n=3, warm=1)
+    out.append(dict(config="3b: SPLADE dense cos-sim scoring", shape=dict(Q=Q, N=N, V=V), **roof("dot_scores_kernel", ms, 2.0 * Q * N * V, "mfma_f32")))
+    del Ds, Qs
+
+    # -- config 4: 4-way nsf fusion, colbert plane 40 % invalid; min-max / z-score / percentile-rank; Q in {1024, 195} --
+    names = ["bm25", "dpr", "splade", "colbert"]
+    for Q in (1024, 195):
+        planes = [rand_plane(ops, Q, N, g, s + 1.0, float(s)) for s in range(4)]
+        systems = {}
+        for i, (n, p) in enumerate(zip(names, planes)):
+            od, sk, rk = ops.sort_rows_desc(p, want_rank=True)
+            if n == "colbert":   # PLAID-style short lists: the last 40 % of every ranking is absent
+                k = int(0.6 * N)
+                rk = torch.where(rk < k, rk, torch.full_like(rk, -1)); od = od.clone(); od[:, k:] = -1
+                systems[n] = RankedSystem(scores=p, order=od, rank=rk, lens=torch.full((Q,), k, dtype=torch.int32, device=dev),
+                                          ids=np.arange(N), full=False, score_sorted=True)
+            else:
+                systems[n] = RankedSystem(scores=p, order=od, rank=rk, lens=torch.full((Q,), N, dtype=torch.int32, device=dev),
+                                          ids=np.arange(N), full=True, score_sorted=True)
+        ranks = [None if s.full else s.rank for s in systems.values()]   # what Aggregator.fuse_device passes: validity of the partial list only
+        w = [0.25] * 4
+        fused = ops.alloc_plane(Q, N, torch.float32, dev)
+        distr = [torch.quantile(p[:8].flatten()[:1000000].double(), torch.linspace(0, 1, 1001, device=dev, dtype=torch.float64)).float().contiguous()
+                 for p in planes]
+        # algorithmic bytes: S score planes + the ONE rank plane that carries validity in, fused plane out
+        work = (4 + 1 + 1) * Q * N * 4
+        for norm in ("min-max", "z-score", "percentile-rank"):
+            ms = timeit_ms(lambda: ops.fuse_nsf(planes, ranks, w, norm, distr if norm == "percentile-rank" else None, out=fused), n=10)
+            out.append(dict(config=f"4: nsf {norm} fusion, S=4, colbert 40% absent", shape=dict(Q=Q, N=N, S=4),
+                            **roof("fuse_nsf kernels", ms, work, "hbm")))
+        ms = timeit_ms(lambda: Aggregator.fuse_device(systems, "nsf", "min-max", dict(zip(names, w)), {}), n=5)
+        out.append(dict(config="4: Aggregator.fuse_device nsf min-max END TO END (stats + fuse + insertion order + final sort)", shape=dict(Q=Q, N=N, S=4),
+                        ms=ms, queries_per_s=Q / (ms * 1e-3)))
+        if Q == 195:   # the 1771-vector sweep of hybrid.py:404-426 on the LLeQA test split size
+            grid = weight_grid(names)
+            labels = [rng.choice(N, size=int(rng.integers(1, 6)), replace=False).tolist() for _ in range(Q)]
+            for norm in ("min-max", "z-score"):
+                Aggregator.tune(systems, norm, grid[:3], labels, {})
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                Aggregator.tune(systems, norm, grid, labels, {})
+                torch.cuda.synchronize(); dt = time.perf_counter() - t0
+                out.append(dict(config=f"4: weight sweep nsf {norm}, {len(grid)} vectors (np.float64 lattice, float64 sweep)", shape=dict(Q=Q, N=N, S=4, W=len(grid)),
+                                ms=dt * 1e3, ms_per_weight_vector=dt * 1e3 / len(grid), note="wall clock incl. host-side metrics"))
+        del planes, systems, ranks, fused
+
+    # -- config 5 at one GPU: one 1/8 shard of mMARCO (what each GPU does at G = 8), no collective ---------------------
+    from fusion_amd.distributed import ShardedDenseIndex
+    Nl, Q, k = 8841823 // 8, 1024, 1000
+    Dm = torch.empty((Nl, 768), dtype=torch.float32, device=dev)
+    for c0 in range(0, Nl, 1 << 19):
+        c1 = min(Nl, c0 + (1 << 19))
+        Dm[c0:c1] = ops.normalize_rows(torch.randn((c1 - c0, 768), generator=g, device=dev))
+    Qm = ops.normalize_rows(torch.randn((Q, 768), generator=g, device=dev))
+    idx = ShardedDenseIndex(Dm, 0)
+    ms = timeit_ms(lambda: idx.local_topk(Qm, k), n=3, warm=1)
+    out.append(dict(config="5: mMARCO 1/8 shard, chunked GEMM + streaming top-1000 (no collective)", shape=dict(Q=Q, N=Nl, d=768, k=k),
+                    **roof("dot_scores_kernel + topk kernels", ms, 2.0 * Q * Nl * 768, "mfma_f32")))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1: the corpus-sharded mMARCO config (north_star's multi-GPU configuration)
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_sharded(args, dev, rank, world, dist):
+    from fusion_amd import encoders, ops
+    from fusion_amd.distributed import ShardedDenseIndex, allgather_rows, allgather_topk, shard_bounds
+    N, d, Q, k = args.mmarco_docs, args.dim, args.queries, args.topk
+    lo, hi = shard_bounds(N, world, rank)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    Dn = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
+    for c0 in range(0, hi - lo, 1 << 20):   # generated on the device, shard by shard: 27 GB never cross PCIe
+        c1 = min(hi - lo, c0 + (1 << 20))
+        Dn[c0:c1] = ops.normalize_rows(torch.randn((c1 - c0, d), generator=g, device=dev))
+    index = ShardedDenseIndex(Dn, lo, None)
+    rng = np.random.default_rng(5)
+    enc = None
+    if not args.no_encode:
+        enc = encoders.random_init("dpr", device=dev, size=args.encoder_size, seed=0)
+        if not args.no_gemm_tuning:
+            encoders.enable_gemm_tuning()
+        ids, mask, qlen_all = synth_query_tokens(rng, Q, enc.backbone.config.vocab_size, 1)
+        qlo, qhi = shard_bounds(Q, world, rank)                         # this rank encodes its 1/world of the queries
+        ids_t = torch.from_numpy(ids[qlo:qhi]).to(dev)
+        qlen = qlen_all[qlo:qhi]
+    else:
+        q_emb = torch.from_numpy(rng.normal(0, 1, (Q, d)).astype(np.float32)).to(dev)
+
+    def step(mark=None):
+        if mark: mark("start")
+        if enc is not None:
+            e_loc = enc.encode_ids_packed(ids_t, qlen)
+            if mark: mark("encode_local")
+            e = allgather_rows(e_loc, Q)
+            if mark: mark("allgather_embeddings")
+        else:
+            e = q_emb
+        Qn = ops.normalize_rows(e)
+        s, i = index.local_topk(Qn, k, mark=mark)
+        gs, gi = allgather_topk(s, i, None)
+        if mark: mark("allgather_topk_merge")
+        return gs, gi
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist: dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    el = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # per-kernel durations of this rank, HIP events, second instrumented region
+    tot, cnt = {}, {}
+    for _ in range(args.steps):
+        ev = Events()
+        step(ev.mark)
+        torch.cuda.synchronize()
+        dt, dc = ev.durations_ms()
+        for kx, v in dt.items():
+            tot[kx] = tot.get(kx, 0.0) + v; cnt[kx] = cnt.get(kx, 0) + dc[kx]
+    stages = {kx: v / args.steps for kx, v in tot.items()}
+    per_launch = {kx: tot[kx] / cnt[kx] for kx in tot}
+    # the collective on its own (payload = the two [Q, k] lists this rank contributes)
+    s0 = torch.zeros((Q, k), dtype=torch.float32, device=dev); i0 = torch.zeros((Q, k), dtype=torch.int64, device=dev)
+    ag_ms = None
+    if dist:
+        gs_ = torch.empty((world * Q, k), dtype=torch.float32, device=dev); gi_ = torch.empty((world * Q, k), dtype=torch.int64, device=dev)
+        def ag():
+            dist.all_gather_into_tensor(gs_, s0); dist.all_gather_into_tensor(gi_, i0)
+        ag_ms = timeit_ms(ag, n=10)
+
+    # correctness of the collective path on a reduced corpus: sharded search == single-GPU search, bit for bit
+    Ns = 200_000
+    gsm = torch.Generator(device=dev).manual_seed(4242)                  # the same small corpus on every rank
+    Dsm = ops.normalize_rows(torch.randn((Ns, d), generator=gsm, device=dev))
+    Qsm = ops.normalize_rows(torch.randn((64, d), generator=gsm, device=dev))
+    slo, shi = shard_bounds(Ns, world, rank)
+    sh = ShardedDenseIndex(Dsm[slo:shi].contiguous(), slo, None); sh.CHUNK = 65536
+    ss, si = sh.search(Qsm, k)
+    whole = ShardedDenseIndex(Dsm, 0, None); whole.CHUNK = 65536
+    ws, wi = whole.local_topk(Qsm, k)
+    same = bool(torch.equal(ss, ws) and torch.equal(si, wi))
+    if dist:
+        flag = torch.tensor([int(same)], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        same = bool(flag.item())
+        devs = [None] * world
+        dist.all_gather_object(devs, f"rank {rank}: cuda:{dev.index} {torch.cuda.get_device_name(dev)}")
+    else:
+        devs = [f"rank 0: cuda:{dev.index} {torch.cuda.get_device_name(dev)}"]
+    del Dsm, sh, whole
+
+    chunk = min(ShardedDenseIndex.CHUNK, hi - lo)
+    rl_all = {}
+    if "shard_gemm" in per_launch:
+        rl_all["shard_gemm"] = roof("dot_scores_kernel", per_launch["shard_gemm"], 2.0 * Q * (hi - lo) * d / cnt["shard_gemm"] * args.steps, "mfma_f32",
+                                    launches_per_step=cnt["shard_gemm"] // args.steps)
+    if "shard_topk_update" in per_launch:   # one streaming pass over the chunk's scores
+        rl_all["shard_topk_update"] = roof("topk_filter + sort_rows (streaming update)", per_launch["shard_topk_update"], Q * chunk * 4, "hbm",
+                                           launches_per_step=cnt["shard_topk_update"] // args.steps)
+    if "shard_topk_first" in per_launch:
+        rl_all["shard_topk_first"] = roof("topk_rows (chunk-sort-truncate)", per_launch["shard_topk_first"], Q * chunk * 4, "hbm", launches_per_step=1)
+    dom = max((kx for kx in rl_all), key=lambda kx: stages.get(kx, 0.0))
+    rl = dict(rl_all[dom], stage=dom, traffic=None, traffic_source=None)
+    res = {"metric": METRIC, "value": Q * args.steps / el, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": f"mMARCO-fr-shaped sharded DPR encode+score (BASELINE.json configs[4]): N={N} passages x d={d} fp32 row-sharded x{world}, "
+                                  f"Q={Q} queries per step, top-{k}; data-parallel CamemBERT-base-shaped fp32 query encoder + all-gather of embeddings, "
+                                  "chunked fp32-MFMA cos-sim GEMM -> streaming top-k per shard, ONE RCCL all-gather of per-shard top-k + local merge",
+                      "corpus": N, "dim": d, "queries_per_step": Q, "topk": k, "encode_in_step": enc is not None,
+                      "parallelism": f"corpus row-sharded x{world} (RCCL all-gather of [Q,k] lists), encoder data-parallel x{world}"},
+           "stages_ms": stages, "roofline": rl, "roofline_all": rl_all,
+           "collective": {"op": "all_gather_into_tensor x2 (fp32 scores, int64 ids)", "payload_bytes_per_rank": Q * k * 12,
+                          "gathered_bytes_per_rank": world * Q * k * 12, "ms": ag_ms,
+                          "embeddings_allgather_bytes_per_rank": (-(-Q // world)) * d * 4 if enc is not None else 0},
+           "ranks": devs, "shard_rows": hi - lo,
+           "sharded_equals_single_gpu": {"equal": same, "corpus": Ns, "queries": 64, "k": k,
+                                         "what": "ShardedDenseIndex.search over this world's shards vs one-GPU local_topk of the whole corpus, scores and ids bit for bit"}}
+    if rank == 0 and not args.no_cpu_baseline:
+        # the oracle's search (cos -> top-k) on a bounded sample: 16 queries x 1/8 of this rank's shard, OpenMP
+        from oracle import oracle
+        oracle.build()
+        nq, nd = 16, min(hi - lo, 1 << 20) // 8
+        Qh, Dh = ops.normalize_rows(e_sample(dev, nq, d)).cpu().numpy(), Dn[:nd].cpu().numpy()
+        t0 = time.perf_counter()
+        oracle.topk_rows(oracle.dot_scores(Qh, Dh, fma_chain=True), k)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = dict(value=nq / (dt * ((hi - lo) * world / nd)), unit="queries/s", cores=oracle.num_threads(), kind="port",
+                                   sample=f"oracle cos-sim + top-{k} of {nq} queries x {nd} passages in {dt:.2f} s, scaled linearly to the {N}-passage corpus "
+                                          "(score + top-k only, no encoder)")
+    return res
+
+
+def e_sample(dev, n, d):
+    g = torch.Generator(device=dev).manual_seed(77)
+    return torch.randn((n, d), generator=g, device=dev)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -295,24 +606,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # one process per GPU; LOCAL_RANK beyond the visible devices only happens when the N > 1 flow is rehearsed on a
-    # smaller box (FUSION_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device)
-    local %= max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("FUSION_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if local >= max(ndev, 1):
+        # one process per GPU: RCCL hangs or fails with two ranks on one device, and a shared device is not an N-GPU measurement
+        if not (args.rehearsal and backend != "nccl"):
+            raise SystemExit(f"LOCAL_RANK {local} but only {ndev} visible GPU(s): one rank per GPU (pass --rehearsal with "
+                             "FUSION_BENCH_BACKEND=gloo to rehearse the control flow on a smaller box)")
+        local %= max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("FUSION_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    workload = args.workload if args.workload != "auto" else ("mmarco" if world > 1 else "lleqa")
 
-    if args.workload == "mmarco":
-        from fusion_amd import distributed as fd
-        res = fd.bench_sharded(args, dev, rank, world, dist)
+    if workload == "mmarco":
+        res = bench_sharded(args, dev, rank, world, dist)
+        if args.rehearsal:
+            res["rehearsal"] = "ranks share devices: control-flow rehearsal only, the numbers mean nothing"
         if rank == 0:
             print(json.dumps(res))
         if dist: dist.destroy_process_group()
@@ -338,36 +655,33 @@ def main():
         elapsed = float(t.item())
 
     # per-kernel durations, live, with HIP events over a second instrumented region of the same K steps
-    ev_tot = {}
+    tot, cnt = {}, {}
     for _ in range(args.steps):
         ev = Events()
         step_lleqa(st, ev)
         torch.cuda.synchronize()
-        for k, v in ev.durations_ms().items():
-            ev_tot[k] = ev_tot.get(k, 0.0) + v
-    stages = {k: v / args.steps for k, v in ev_tot.items()}
-    if "encode_attn" in stages:
-        stages["encode"] += stages["encode_attn"]   # "encode" = the whole forward; "encode_attn" = its attention launches, a subset
+        dt, dc = ev.durations_ms()
+        for k, v in dt.items():
+            tot[k] = tot.get(k, 0.0) + v; cnt[k] = cnt.get(k, 0) + dc[k]
+    stages = {k: v / args.steps for k, v in tot.items()}                               # ms per step
+    per_launch = {k: tot[k] / cnt[k] for k in tot}                                     # ms per launch
+    stages["encode"] = sum(v for k, v in stages.items() if k.startswith("encode_"))    # the whole forward
 
     if rank == 0:
         Q, N, d = st["Q"], st["N"], st["d"]
         work = algorithmic_work(st)
-        tot = {k: v for k, v in stages.items() if k in work}                        # ms per step spent in each hand-written kernel
-        kern = {k: v / work[k].get("launches", 1) for k, v in tot.items()}          # average duration of ONE launch
-        dom = max(tot, key=tot.get)                                                 # dominant = most time per step
-        w = work[dom]
-        achieved = w["work"] / (kern[dom] * 1e-3)
-        scale = 1e12 if w["unit"] == "TFLOP/s" else 1e9
-        roof = dict(kernel=w["kernel"], stage=dom, bound=w["bound"], achieved=achieved / scale, peak=w["peak"] / scale, unit=w["unit"],
-                    frac=achieved / w["peak"], traffic=measured_traffic(dom, st), ms=kern[dom], launches_per_step=w.get("launches", 1))
-        all_roof = {k: dict(kernel=work[k]["kernel"], ms=kern[k], launches_per_step=work[k].get("launches", 1),
-                            achieved=work[k]["work"] / (kern[k] * 1e-3) / (1e12 if work[k]["unit"] == "TFLOP/s" else 1e9),
-                            unit=work[k]["unit"], frac=work[k]["work"] / (kern[k] * 1e-3) / work[k]["peak"]) for k in kern}
+        all_roof = {k: roof(work[k]["kernel"], per_launch[k], work[k]["work"], work[k]["bound"], ms_per_step=stages[k],
+                            launches_per_step=cnt[k] // args.steps, hand_written=work[k].get("hand", True)) for k in work if k in per_launch}
+        hand = {k: v for k, v in all_roof.items() if v["hand_written"]}
+        dom = max(hand, key=lambda k: hand[k]["ms_per_step"])                          # dominant = most time per step among OUR kernels
+        traffic, src = profiled_traffic(dom, st)
+        rl = dict(hand[dom], stage=dom, traffic=traffic,
+                  traffic_source=(src + " (rocprofv3 PMC pass of this command at this shape; profile-derived, not measured in this run)") if src else None)
         res = {
-            "metric": "queries/sec end-to-end (encode+score+fuse), LLeQA test; recall@500 parity",
+            "metric": METRIC,
             "value": world * Q * args.steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not args.no_encode else "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"LLeQA-shaped BM25+DPR RRF hybrid: Q={Q} queries/GPU x N={N} articles, d={d}; "
                                    f"{'CamemBERT-base-shaped fp32 query encoder (random init; ' + st.get('encode_mode', '') + ' forward' + ('' if args.no_gemm_tuning or st.get('encode_mode') != 'packed' else ', hipBLASLt solutions recorded with TunableOp') + ') + ' if not args.no_encode else 'NO encoder + '}"
                                    "fp32-MFMA cos-sim + BM25(f64) + full stable ranking + RRF(f64) + final order",
@@ -375,19 +689,35 @@ def main():
                        "encode_in_step": not args.no_encode, "parallelism": f"query-sharded x{world}, corpus replicated"},
             "stages_ms": stages,
             "score_fuse_qps_per_gpu": Q / (sum(v for k, v in stages.items() if not k.startswith("encode")) * 1e-3),
-            "roofline": roof, "roofline_all": all_roof,
+            "roofline": rl, "roofline_all": all_roof,
         }
         if not args.no_cpu_baseline:
-            _, _, (S, B) = out
-            cb, (S_o, B_o, o_f, k_f), q = cpu_baseline_lleqa(st, S, B)
+            _, _, (S, B, q_emb) = out
+            cb, (S_o, B_o, o_f, k_f), q = cpu_baseline_lleqa(st, q_emb)
             res["cpu_baseline"] = cb
-            # parity on the sample while we are here: device scores vs oracle scores, device order vs oracle order
-            # (the order is compared on the oracle fed with the DEVICE's own scores: stage-wise parity)
-            res["parity_sample"] = {"cos_max_abs_err": float(np.max(np.abs(S[:q].cpu().numpy() - S_o))),
-                                    "bm25_bit_exact": bool(np.array_equal(B[:q].cpu().numpy(), B_o))}
+            # parity on the sample while we are here (same embeddings on both sides): device scores vs oracle scores,
+            # device BM25 vs oracle BM25, and the final ranked lists against the oracle fed with the DEVICE's own scores
+            order, scores, _ = out
+            _, _, r_d = oracle_sort(S[:q]); o_b, _, r_b = oracle_sort(B[:q])
+            from oracle import oracle
+            f = oracle.fuse_rank([r_b, r_d], np.full((2, q), N, dtype=np.int32), "rrf")
+            o_ref, k_ref = oracle.sort_rows_desc(f, init_order=o_b)
+            res["parity_sample"] = {"queries": q, "cos_max_abs_err": float(np.max(np.abs(S[:q].cpu().numpy() - S_o))),
+                                    "bm25_bit_exact": bool(np.array_equal(B[:q].cpu().numpy(), B_o)),
+                                    "ranked_lists_identical": bool(np.array_equal(order[:q].cpu().numpy(), o_ref)),
+                                    "fused_scores_bit_exact": bool(np.array_equal(scores[:q].cpu().numpy(), k_ref))}
+        if world == 1 and not args.no_configs and (Q, N) == (1024, 27942):
+            del st, out
+            torch.cuda.empty_cache()
+            res["configs_measured"] = measure_configs(dev, N)
         print(json.dumps(res))
     if dist:
         dist.destroy_process_group()
+
+
+def oracle_sort(plane):
+    from oracle import oracle
+    return oracle.sort_rows_desc(plane.cpu().numpy(), want_rank=True)
 
 
 if __name__ == "__main__":

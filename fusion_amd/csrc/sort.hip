@@ -6,8 +6,10 @@
 //
 // Design (MI355X-first): one workgroup owns one row.  A row (<= 35,840 keys) lives entirely in
 // the workgroup's registers (E keys per thread, "wave-striped": wave w, item i, lane l holds
-// sequence position w*E*64 + i*64 + l), so HBM sees each key once in and once out.  Each of
-// the 4 (fp32) / 8 (fp64) LSD passes over an 8-bit digit is
+// sequence position w*E*64 + i*64 + l), so HBM sees each key once in and once out.  fp32 keys
+// take 4 LSD passes; fp64 keys take 4 passes over their HIGH word plus an in-place repair of the
+// (short, adjacent) runs of equal high words -- the same permutation as 8 passes.  Each LSD pass
+// over an 8-bit digit is
 //   1. rank:     per item, the 64 lanes of a wave find their same-digit peers with 8 ballots
 //                (wave64 match-any), and bump a wave-private LDS counter (no atomics, stable);
 //   2. scan:     256 digits x NW waves counters -> exclusive prefix (digit-major);
@@ -42,6 +44,7 @@ struct SortArgs {
     const int64_t* idmap;        // nullable: out_ids = idmap[addr(col)] (same segment addressing as keys)
     int64_t id_base;             // else out_ids = id_base + col
     int64_t* out_ids;            // nullable, [rows][out_row_stride] like order
+    int32_t* row_flags;          // fp64 keys: [rows*chunks] 1 = the fast form left the row to the generic one
 };
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
@@ -53,10 +56,14 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
     return v;
 }
 
-template <int T, int E, int KW>
+// GEN (fp64 only): the generic eight-pass form, run as a second launch for the rows the fast form flags (see below).
+template <int T, int E, int KW, bool GEN>
 __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
+    static_assert(!GEN || KW == 2, "the generic form exists for fp64 keys only");
     constexpr int NW = T / 64;
     constexpr uint32_t SENT = 0xffffffffu;
+    constexpr int LG = (KW == 2) ? 7 : 14;         // global loads in flight per thread before the first use (one HBM latency per group)
+    constexpr int WALK = 16;                        // longest equal-high-word run the fp64 repair re-sorts in place
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* exch = smem;                         // [T*E]
     uint32_t* cnt = smem + T * E;                  // [NW*256] (plain LDS pointer: volatile would lower to flat sc0 sc1 accesses)
@@ -68,6 +75,12 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int c0 = chunk * a.chunk_len;
+    // this thread's first slot; SLOT_FRESH() makes it opaque again so that the 28 per-item slot numbers are re-derived (one add)
+    // in every phase instead of being kept live -- 28 registers -- from the first phase to the last
+    int slot0 = w * E * 64 + lane;
+#define SLOT_FRESH() asm volatile("" : "+v"(slot0))
+    if constexpr (GEN) { if (a.row_flags[prow] == 0) return; }                       // block-uniform: the fast form finished this row
+    else if constexpr (KW == 2) { if (threadIdx.x == 0) a.row_flags[prow] = 0; }
 
     int m_row = a.row_len ? a.row_len[row] : a.n_total;
     m_row = m_row < 0 ? 0 : (m_row > a.n_total ? a.n_total : m_row);
@@ -79,123 +92,160 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     const size_t krow = (size_t)row * a.key_row_stride;
     const bool seg = a.seg_len < a.n_total;  // block-uniform: segmented rows ([G][rows][k] top-k lists)
     const float* __restrict__ kf = reinterpret_cast<const float*>(a.keys) + krow;
-    const double* __restrict__ kd = reinterpret_cast<const double*>(a.keys) + krow;
+    const uint2* __restrict__ kd = reinterpret_cast<const uint2*>(a.keys) + krow;   // a double as its (low, high) words
     const int32_t* __restrict__ init_row = a.init_order ? a.init_order + krow : nullptr;
+    const int32_t* __restrict__ irow = a.init_rank ? a.init_rank + krow : nullptr;
     auto elem = [&](int col) -> long {  // element offset of column `col` relative to the row base
         return seg ? (long)(col / a.seg_len) * a.seg_stride + (col % a.seg_len) : (long)col;
     };
+    // outputs
+    const int lim = m < a.out_limit ? m : a.out_limit;
+    const size_t obase = (size_t)row * a.out_row_stride + (size_t)chunk * a.out_chunk_stride;
+    int32_t* __restrict__ o_order = a.order ? a.order + obase : nullptr;
+    int64_t* __restrict__ o_ids = a.out_ids ? a.out_ids + obase : nullptr;
+    float* __restrict__ o_kf = a.sorted_keys ? reinterpret_cast<float*>(a.sorted_keys) + obase : nullptr;
+    uint32_t* __restrict__ o_kw = a.sorted_keys ? reinterpret_cast<uint32_t*>(reinterpret_cast<double*>(a.sorted_keys) + obase) : nullptr;   // fp64 keys, word by word
+    int32_t* __restrict__ o_rank = a.rank ? a.rank + (size_t)row * a.out_row_stride : nullptr;
+    const int32_t* __restrict__ cmap = a.colmap ? a.colmap + (size_t)row * a.colmap_row_stride : nullptr;
+    const int64_t* __restrict__ imap = a.idmap ? a.idmap + krow : nullptr;
 
-    uint32_t k0[E];
-    uint32_t k1[KW == 2 ? E : 1];
+    // Register state, TWO words per key at any time (E = 28 keys x 3 words does not fit the 128 VGPRs of a 1024-thread
+    // workgroup): fp32 -> ks = the key; fp64 -> ks = the HIGH key word during the passes, the LOW key word afterwards
+    // (GEN: low word, four passes, high word, four passes, low word).
+    uint32_t ks[E];
     uint32_t meta[E];  // low 16: payload (column inside the chunk); high 16: scratch (offset / destination)
 
-    if (threadIdx.x < 4) misc[8 + threadIdx.x] = (threadIdx.x & 1) ? 0xffffffffu : 0u;  // [8]=or0 [9]=and0 [10]=or1 [11]=and1
-    __syncthreads();
-    uint32_t or0 = 0, and0 = 0xffffffffu, or1 = 0, and1 = 0xffffffffu;
-    if (a.init_rank) {
-        // placed sequence: column j sits at sequence position init_rank[j].  Keys and positions are read coalesced
-        // by column; each key word is scattered to exch[position] and read back in striped order (one LDS round
-        // per word) -- the random walk happens in LDS instead of as 27,942 uncoalesced 4/8-byte HBM reads per row.
-        const int32_t* __restrict__ irow = a.init_rank + krow;
-        uint32_t pos[E];
+    // fp64 key of the element at column `col` (re-derivable at any time from global memory: L2 / Infinity-Cache hits)
+    auto key64 = [&](uint2 v) -> uint64_t { return desc_key_f64(__hiloint2double((int)v.y, (int)v.x)); };
+
+    if (threadIdx.x < 4) misc[8 + threadIdx.x] = (threadIdx.x & 1) ? 0xffffffffu : 0u;  // [8] = or, [9] = and of the sort words
+    uint32_t orw = 0, andw = 0xffffffffu;
+    if (irow) {
+        // placed sequence: column j sits at sequence position init_rank[j].  Keys and positions are read coalesced by
+        // column; the sort word, then the payload, are scattered to exch[position] and read back in striped order -- the
+        // random walk happens in LDS instead of as 27,942 uncoalesced HBM reads per row.  The positions are read twice
+        // (second time from L2) rather than held in 28 registers.
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = SENT;
+        __syncthreads();
+SLOT_FRESH();
+#pragma unroll
+        for (int i0 = 0; i0 < E; i0 += LG) {
+            uint32_t pos_t[LG], lo_t[LG], hi_t[LG];
+#pragma unroll
+            for (int i = i0; i < (i0 + LG < E ? i0 + LG : E); ++i) {
+                const int j = (slot0 + i * 64);
+                const bool in = j < a.n_total;
+                pos_t[i - i0] = (uint32_t)(in ? irow[j] : -1);
+                if (KW == 1) lo_t[i - i0] = __float_as_uint(kf[in ? j : 0]);
+                else { const uint2 v = kd[in ? j : 0]; lo_t[i - i0] = v.x; hi_t[i - i0] = v.y; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = i0; i < (i0 + LG < E ? i0 + LG : E); ++i) {
+                const int j = (slot0 + i * 64);
+                const uint32_t kw = KW == 1 ? desc_key_f32(__uint_as_float(lo_t[i - i0]))
+                                            : (uint32_t)(key64(make_uint2(lo_t[i - i0], hi_t[i - i0])) >> (GEN ? 0 : 32));
+                if (j < a.n_total && pos_t[i - i0] < (uint32_t)m) exch[pos_t[i - i0]] = kw;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) ks[i] = exch[(slot0 + i * 64)];
+        __syncthreads();
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = 0xffffu;
+        __syncthreads();
+SLOT_FRESH();
+#pragma unroll
+        for (int i0 = 0; i0 < E; i0 += 2 * LG) {
+            uint32_t pos_t[2 * LG];
+#pragma unroll
+            for (int i = i0; i < (i0 + 2 * LG < E ? i0 + 2 * LG : E); ++i) {
+                const int j = (slot0 + i * 64);
+                pos_t[i - i0] = (uint32_t)(j < a.n_total ? irow[j] : -1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = i0; i < (i0 + 2 * LG < E ? i0 + 2 * LG : E); ++i) {
+                const int j = (slot0 + i * 64);
+                if (j < a.n_total && pos_t[i - i0] < (uint32_t)m) exch[pos_t[i - i0]] = (uint32_t)j;   // payload = own column (< 65535)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const int j = w * E * 64 + i * 64 + lane;
-            const bool in = j < a.n_total;
-            const int r = in ? irow[j] : -1;
-            const bool ok = in && (unsigned)r < (unsigned)m;
-            pos[i] = ok ? (uint32_t)r : 0xffffffffu;
-            if (KW == 1) {
-                k0[i] = desc_key_f32(kf[in ? j : 0]);
-            } else {
-                const uint64_t kk = desc_key_f64(kd[in ? j : 0]);
-                k0[i] = (uint32_t)kk;
-                k1[KW == 2 ? i : 0] = (uint32_t)(kk >> 32);
-            }
-            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            meta[i] = exch[(slot0 + i * 64)];
+            if (meta[i] != 0xffffu) { orw |= ks[i]; andw &= ks[i]; }   // a real element landed in this slot
         }
-        auto place = [&](uint32_t (&reg)[E], uint32_t fill) {
-#pragma unroll
-            for (int i = 0; i < E; ++i) exch[w * E * 64 + i * 64 + lane] = fill;
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < E; ++i)
-                if (pos[i] != 0xffffffffu) exch[pos[i]] = reg[i];
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < E; ++i) reg[i] = exch[w * E * 64 + i * 64 + lane];
-            __syncthreads();
-        };
-        place(k0, SENT);
-        if constexpr (KW == 2) place(k1, SENT);
-#pragma unroll
-        for (int i = 0; i < E; ++i) meta[i] = (uint32_t)(w * E * 64 + i * 64 + lane);   // payload = own column (< 65535)
-        place(meta, 0xffffu);
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            if (meta[i] != 0xffffu) {   // a real element landed in this slot
-                or0 |= k0[i]; and0 &= k0[i];
-                if (KW == 2) { or1 |= k1[KW == 2 ? i : 0]; and1 &= k1[KW == 2 ? i : 0]; }
-            }
-        }
+        __syncthreads();
     } else {
+SLOT_FRESH();
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
-        // branch-free: out-of-range lanes load a safe element (column c0 exists because m > 0) and discard it
-        const int p = w * E * 64 + i * 64 + lane;
-        const bool valid = p < m;
-        int col = valid ? c0 + p : c0;
-        if (init_row) col = init_row[col];
-        const bool ok = valid && (unsigned)col < (unsigned)a.n_total;
-        col = ok ? col : c0;
-        if (KW == 1) {
-            const uint32_t kk = desc_key_f32(kf[elem(col)]);
-            k0[i] = ok ? kk : SENT;
-        } else {
-            const uint64_t kk = desc_key_f64(kd[elem(col)]);
-            k0[i] = ok ? (uint32_t)kk : SENT;
-            k1[KW == 2 ? i : 0] = ok ? (uint32_t)(kk >> 32) : SENT;
-            or1 |= ok ? k1[KW == 2 ? i : 0] : 0u; and1 &= ok ? k1[KW == 2 ? i : 0] : 0xffffffffu;
+        for (int i0 = 0; i0 < E; i0 += LG) {
+            uint32_t lo_t[LG], hi_t[KW == 2 ? LG : 1];
+#pragma unroll
+            for (int i = i0; i < (i0 + LG < E ? i0 + LG : E); ++i) {
+                // branch-free: out-of-range lanes load a safe element (column c0 exists because m > 0) and discard it
+                const int p = (slot0 + i * 64);
+                const bool valid = p < m;
+                int col = valid ? c0 + p : c0;
+                if (init_row) col = init_row[col];
+                const bool ok = valid && (unsigned)col < (unsigned)a.n_total;
+                // payload: the source column (gathered sequence) or the column inside the chunk
+                meta[i] = ok ? (uint32_t)(init_row ? col : col - c0) : 0xffffu;
+                col = ok ? col : c0;
+                if (KW == 1) lo_t[i - i0] = __float_as_uint(kf[elem(col)]);
+                else { const uint2 v = kd[elem(col)]; lo_t[i - i0] = v.x; hi_t[KW == 2 ? i - i0 : 0] = v.y; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = i0; i < (i0 + LG < E ? i0 + LG : E); ++i) {
+                const bool ok = meta[i] != 0xffffu;
+                const uint32_t kw = KW == 1 ? desc_key_f32(__uint_as_float(lo_t[i - i0]))
+                                            : (uint32_t)(key64(make_uint2(lo_t[i - i0], hi_t[KW == 2 ? i - i0 : 0])) >> (GEN ? 0 : 32));
+                ks[i] = ok ? kw : SENT;
+                orw |= ok ? kw : 0u; andw &= ok ? kw : 0xffffffffu;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        or0 |= ok ? k0[i] : 0u; and0 &= ok ? k0[i] : 0xffffffffu;
-        // payload: the source column (gathered sequence) or the column inside the chunk
-        meta[i] = ok ? (uint32_t)(init_row ? col : col - c0) & 0xffffu : 0xffffu;
-        if ((i & (KW == 2 ? 1 : 3)) == (KW == 2 ? 1 : 3)) __builtin_amdgcn_sched_barrier(0);  // few items in flight
+        __syncthreads();   // misc[8..9] initialised
     }
-    }
-    // which digits vary over the row?
+    // which bits of the sort word vary over the row?
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        or0 |= __shfl_xor(or0, o, 64); and0 &= __shfl_xor(and0, o, 64);
-        if (KW == 2) { or1 |= __shfl_xor(or1, o, 64); and1 &= __shfl_xor(and1, o, 64); }
-    }
-    if (lane == 0) {
-        atomicOr(&misc[8], or0); atomicAnd(&misc[9], and0);
-        if (KW == 2) { atomicOr(&misc[10], or1); atomicAnd(&misc[11], and1); }
-    }
+    for (int o = 32; o > 0; o >>= 1) { orw |= __shfl_xor(orw, o, 64); andw &= __shfl_xor(andw, o, 64); }
+    if (lane == 0) { atomicOr(&misc[8], orw); atomicAnd(&misc[9], andw); }
     __syncthreads();
-    const uint32_t diff0 = misc[8] ^ misc[9];
-    const uint32_t diff1 = (KW == 2) ? (misc[10] ^ misc[11]) : 0u;
+    const uint32_t diff = misc[8] ^ misc[9];          // bits that vary among the REAL keys: a digit without any is skipped
+    // Slots beyond the sequence hold the all-ones sentinel and take part in the wave ballots: a bit may only be left out
+    // of the match when it is constant over the sentinels too, i.e. constant ONE.
+    const bool has_sent = irow || init_row || m < T * E;
+    const uint32_t diff_match = has_sent ? ~misc[9] : diff;
 
-#ifndef FZ_ABL_NOPASS  // FZ_ABL_*: diagnostic ablation builds (tools/ablate); never defined in the product build
-    for (int pass = 0; pass < 4 * KW; ++pass) {
-        const int shift = (pass & 3) * 8;
-        const bool hi = (KW == 2) && pass >= 4;
-        const uint32_t diff = hi ? diff1 : diff0;
-        if (((diff >> shift) & 0xffu) == 0u) continue;  // constant digit among real keys: order unchanged
-
+    // One stable LSD pass over the 8-bit digit at `shift` of ks (which travels with the payload).
+    // dmask: the digit's bits that vary over the row.
+    auto radix_pass = [&](const int shift, const uint32_t dmask) {
         // ---- 1. rank inside the wave ------------------------------------------------
         uint32_t* my = cnt + w * 256;
         my[lane] = 0; my[lane + 64] = 0; my[lane + 128] = 0; my[lane + 192] = 0;
+SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const uint32_t kw = hi ? k1[KW == 2 ? i : 0] : k0[i];
+            const uint32_t kw = ks[i];
             const uint32_t d = (kw >> shift) & 0xffu;
-            // wave64 match-any on the 8 digit bits, 4 VALU per bit: sign-extended bit (0 / -1), ballot, and
-            // mask &= ~(ballot ^ sext) as one v_bitop3 per 32-lane half
+            // wave64 match-any on the digit's VARYING bits (a bit that is constant over the row cannot separate peers;
+            // dmask is wave-uniform, the skip is a scalar branch), 4 VALU per bit: sign-extended bit (0 / -1), ballot,
+            // and mask &= ~(ballot ^ sext) as one v_bitop3 per 32-lane half
             uint32_t mlo = 0xffffffffu, mhi = 0xffffffffu;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
+                if (!((dmask >> b) & 1u)) continue;
                 const uint32_t sx = (uint32_t)__builtin_amdgcn_sbfe((int)kw, (unsigned)(shift + b), 1u);
                 const unsigned long long bal = __ballot(sx != 0u);
                 mlo &= ~(((uint32_t)bal) ^ sx);
@@ -234,102 +284,283 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             for (int ww = 0; ww < NW; ++ww) cnt[ww * 256 + threadIdx.x] += base;
         }
         __syncthreads();
-#ifdef FZ_ABL_RANKONLY
-        continue;
-#endif
         // ---- 3. destination, exchange --------------------------------------------------
         // (sched_barrier every 4 items: without it hipcc hoists all E LDS addresses/values and spills)
+SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            uint32_t kw = hi ? k1[KW == 2 ? i : 0] : k0[i];
+            uint32_t kw = ks[i];
             asm volatile("" : "+v"(kw));  // recompute the digit here instead of keeping &my[d] alive per item
             const uint32_t d = (kw >> shift) & 0xffu;
             const uint32_t dst = my[d] + (meta[i] >> 16);
             meta[i] = __builtin_amdgcn_perm(dst, meta[i], 0x05040100u);
             asm volatile("" : "+v"(meta[i]));
-            exch[dst] = k0[i];
+            exch[dst] = kw;
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            k0[i] = exch[w * E * 64 + i * 64 + lane];
+            ks[i] = exch[(slot0 + i * 64)];
             if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        if (KW == 2) {
-#pragma unroll
-            for (int i = 0; i < E; ++i) {
-                exch[meta[i] >> 16] = k1[KW == 2 ? i : 0];
-                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < E; ++i) {
-                k1[KW == 2 ? i : 0] = exch[w * E * 64 + i * 64 + lane];
-                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
-        }
+SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             exch[meta[i] >> 16] = meta[i] & 0xffffu;
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            meta[i] = exch[w * E * 64 + i * 64 + lane];
+            meta[i] = exch[(slot0 + i * 64)];
             if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+    };
+    // move (ks, payload) to the slots in meta's high halves (a permutation of [0, m)); slots >= m keep theirs
+    auto permute_to_meta_hi = [&]() {
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) exch[meta[i] >> 16] = ks[i];
+        __syncthreads();
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) ks[i] = exch[(slot0 + i * 64)];
+        __syncthreads();
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) exch[meta[i] >> 16] = meta[i] & 0xffffu;
+        __syncthreads();
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) meta[i] = exch[(slot0 + i * 64)];
+        __syncthreads();
+    };
+    // fp64: (re)load one key word of every slot's element from global memory, by payload (a gather; rare paths only)
+    auto reload_word = [&](bool high) {
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint32_t py = meta[i] & 0xffffu;
+            const int col = py == 0xffffu ? c0 : (int)py + ((init_row || irow) ? 0 : c0);
+            const uint64_t kk = key64(kd[elem(col)]);
+            ks[i] = py == 0xffffu ? SENT : (high ? (uint32_t)(kk >> 32) : (uint32_t)kk);
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    static_assert(KW == 1 || E <= 32, "fp64: per-thread slot masks are 32 bits");
+    uint32_t signm = 0u, nanm = 0u;   // fp64: bit i = slot i's key has its (ascending-key) sign bit set / is the NaN key
+    for (int pass = 0; pass < 4; ++pass) {
+        if (((diff >> (pass * 8)) & 0xffu) == 0u) continue;  // constant digit among real keys: order unchanged
+        radix_pass(pass * 8, (diff_match >> (pass * 8)) & 0xffu);
     }
-#endif  // FZ_ABL_NOPASS
+    if constexpr (GEN) {
+        // generic form: the four passes above ran over the LOW key words; now the high words (re-derived from global
+        // memory by payload), four more passes, the high halves of the sorted keys, and the low words again for the output
+        reload_word(true);
+        uint32_t o1 = 0u, a1 = 0xffffffffu;
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) if ((meta[i] & 0xffffu) != 0xffffu) { o1 |= ks[i]; a1 &= ks[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0) { misc[8] = 0u; misc[9] = 0xffffffffu; }
+        __syncthreads();
+        atomicOr(&misc[8], o1); atomicAnd(&misc[9], a1);
+        __syncthreads();
+        const uint32_t dh = misc[8] ^ misc[9], dh_match = has_sent ? ~misc[9] : dh;
+        for (int pass = 0; pass < 4; ++pass)
+            if (((dh >> (pass * 8)) & 0xffu) != 0u) radix_pass(pass * 8, (dh_match >> (pass * 8)) & 0xffu);
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int p = (slot0 + i * 64);
+            const uint32_t asc = ~ks[i];
+            const bool nan = ks[i] == 0u, sgn = (asc >> 31) & 1u;
+            signm |= (uint32_t)sgn << i; nanm |= (uint32_t)nan << i;
+            if (o_kw && p < lim) o_kw[2 * p + 1] = nan ? 0x7ff80000u : (sgn ? (asc & 0x7fffffffu) : ~asc);
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        reload_word(false);
+    } else if constexpr (KW == 2) {
+        // fp64 keys: the FOUR passes above ordered the rows by the HIGH key word only (sign, exponent, 20 mantissa bits).
+        // Two keys that share a high word but differ in the low word may now be out of order -- but they are ADJACENT
+        // (a stable sort by the high word leaves each equal-high-word run contiguous and in sequence order), and such
+        // a run is almost always 2-3 keys long, except runs of EQUAL keys (BM25's zeros), which need nothing.  So:
+        // note which slots continue their left neighbour's run, write the high halves of the sorted keys, swap the
+        // high words for the low words (re-derived from global memory by the thread that loaded them, handed over
+        // through LDS by payload), and repair the dirty short runs in place.  Same permutation as eight LSD passes
+        // over the 64-bit key at half the ranking work and a third of the exchanges.  A row with a dirty run longer
+        // than WALK + 1 is flagged instead (row_flags) and redone by the generic eight-pass form of this kernel (GEN), a
+        // second launch in which every other row's workgroup exits at once.
+        uint32_t* runbits = cnt;   // [T*E/32]: bit (p & 31) of word p >> 5 = "slot p has the same high word as slot p-1"
+        auto bit_of = [&](int p) -> bool { return (runbits[p >> 5] >> (p & 31)) & 1u; };
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = ks[i];
+        __syncthreads();
+        uint32_t nextsame = 0u;   // bit i: slot i of this thread has the same high word as the slot after it
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int p = (slot0 + i * 64);
+            const bool ps = p > 0 && p < m && exch[p - 1] == ks[i];
+            const bool ns = p + 1 < m && exch[p + 1] == ks[i];
+            nextsame |= (uint32_t)ns << i;
+            const unsigned long long bal = __ballot(ps);
+            if (lane == 0) { runbits[(w * E + i) * 2] = (uint32_t)bal; runbits[(w * E + i) * 2 + 1] = (uint32_t)(bal >> 32); }
+            // the sorted key's high half is final now (the repair only moves keys inside runs of EQUAL high words)
+            const uint32_t asc = ~ks[i];
+            const bool nan = ks[i] == 0u;           // every NaN maps to the all-zero key; no other key has a zero high word
+            const bool sgn = (asc >> 31) & 1u;
+            signm |= (uint32_t)sgn << i; nanm |= (uint32_t)nan << i;
+            if (o_kw && p < lim) o_kw[2 * p + 1] = nan ? 0x7ff80000u : (sgn ? (asc & 0x7fffffffu) : ~asc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // ---- low words: re-derived by the thread that loaded the element, published under its payload ----
+        constexpr int LGG = 4;
+SLOT_FRESH();
+#pragma unroll
+        for (int i0 = 0; i0 < E; i0 += LGG) {
+            uint32_t lo_t[LGG], hi_t[LGG];
+            int pay_t[LGG];
+#pragma unroll
+            for (int i = i0; i < (i0 + LGG < E ? i0 + LGG : E); ++i) {
+                const int p = (slot0 + i * 64);
+                int pay, col;   // payload this slot was loaded with, and its column in the row
+                if (irow) { pay = p < a.n_total ? p : -1; col = pay; }
+                else if (init_row) { col = p < m ? init_row[c0 + p] : -1; col = (unsigned)col < (unsigned)a.n_total ? col : -1; pay = col; }
+                else { pay = p < m ? p : -1; col = pay < 0 ? -1 : c0 + pay; }
+                pay_t[i - i0] = pay;
+                const uint2 v = kd[elem(col < 0 ? c0 : col)];
+                lo_t[i - i0] = v.x; hi_t[i - i0] = v.y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = i0; i < (i0 + LGG < E ? i0 + LGG : E); ++i)
+                if (pay_t[i - i0] >= 0) exch[pay_t[i - i0]] = (uint32_t)key64(make_uint2(lo_t[i - i0], hi_t[i - i0]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint32_t py = meta[i] & 0xffffu;
+            ks[i] = py != 0xffffu ? exch[py] : SENT;     // from here on ks = the LOW key word
+            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // ---- repair: every SHORT run (<= WALK + 1 slots) is re-sorted by its first slot's thread, which leaves the move of
+        // every member (new slot - old slot, one signed byte) in delta[]; 0x7f = "not in a short run".  A misordered pair
+        // whose slots stay 0x7f sits in a long run: that row takes the generic path.
+        int8_t* delta = reinterpret_cast<int8_t*>(smem + T * E + NW * 256 + 32);   // [T*E] bytes
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = ks[i];
+        {
+            uint32_t* d32 = reinterpret_cast<uint32_t*>(delta);
+#pragma unroll
+            for (int i = 0; i < (E + 3) / 4; ++i) { const int x = i * T + threadIdx.x; if (x < T * E / 4) d32[x] = 0x7f7f7f7fu; }
+        }
+        __syncthreads();
+        uint32_t badm = 0u;
+SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int p = (slot0 + i * 64);
+            if ((nextsame >> i) & 1u) badm |= (uint32_t)(ks[i] > exch[p + 1]) << i;
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (__syncthreads_or(badm != 0u ? 1 : 0)) {
+            // The runs are described completely by LDS state (runbits = "same high word as the slot before", exch = low
+            // words), so ANY thread can repair a run: thread t takes the 32 slots of runbits word t and handles the run
+            // heads among them (~bit(p) & bit(p+1)) -- a sparse loop, no per-item unrolled code.
+            static_assert(E <= 32, "one runbits word per thread");
+            if (threadIdx.x < T * E / 32) {
+                const int t = threadIdx.x;
+                const uint32_t b = runbits[t], bn = (t + 1 < T * E / 32) ? runbits[t + 1] : 0u;
+                uint32_t heads = ~b & ((b >> 1) | (bn << 31));      // bits of slots >= m are clear: no run crosses m
+                while (heads) {
+                    const int p = 32 * t + __builtin_ctz(heads);
+                    heads &= heads - 1;
+                    const uint32_t lo0 = exch[p], lo1 = exch[p + 1];
+                    const bool more = (p + 2 < m) && bit_of(p + 2);
+                    if (!more) {                               // the usual case: a run of two
+                        const bool sw = lo0 > lo1;
+                        delta[p] = sw ? 1 : 0; delta[p + 1] = sw ? -1 : 0;
+                    } else {
+                        int re = p + 2;                        // last slot known to belong to the run
+                        while (re - p < WALK && (re + 1 < m) && bit_of(re + 1)) ++re;
+                        if (!((re + 1 < m) && bit_of(re + 1))) {   // closed within WALK + 1 slots: stable counting sort of the run
+                            for (int x = p; x <= re; ++x) {
+                                const uint32_t vx = exch[x];
+                                int before = 0;
+                                for (int y = p; y <= re; ++y) { const uint32_t vy = exch[y]; before += (vy < vx || (vy == vx && y < x)) ? 1 : 0; }
+                                delta[x] = (int8_t)(p + before - x);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            bool fallback = false;
+SLOT_FRESH();
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int p = (slot0 + i * 64);
+                const int d = p < m ? (int)delta[p] : 0;
+                fallback |= ((badm >> i) & 1u) && d == 0x7f;
+                const uint32_t np = (uint32_t)(p + (d == 0x7f ? 0 : d));
+                meta[i] = __builtin_amdgcn_perm(np, meta[i], 0x05040100u);
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (__syncthreads_or(fallback ? 1 : 0)) {      // block-uniform: leave the row to the generic form
+                if (threadIdx.x == 0) a.row_flags[prow] = 1;
+                return;
+            }
+            permute_to_meta_hi();
+        }
+    }
 
     // ---- output (coalesced: consecutive lanes = consecutive ranks) -------------------------
-    const int lim = m < a.out_limit ? m : a.out_limit;
-    const size_t obase = (size_t)row * a.out_row_stride + (size_t)chunk * a.out_chunk_stride;
-    int32_t* __restrict__ o_order = a.order ? a.order + obase : nullptr;
-    int64_t* __restrict__ o_ids = a.out_ids ? a.out_ids + obase : nullptr;
-    float* __restrict__ o_kf = a.sorted_keys ? reinterpret_cast<float*>(a.sorted_keys) + obase : nullptr;
-    double* __restrict__ o_kd = a.sorted_keys ? reinterpret_cast<double*>(a.sorted_keys) + obase : nullptr;
-    int32_t* __restrict__ o_rank = a.rank ? a.rank + (size_t)row * a.out_row_stride : nullptr;
-    const int32_t* __restrict__ cmap = a.colmap ? a.colmap + (size_t)row * a.colmap_row_stride : nullptr;
-    const int64_t* __restrict__ imap = a.idmap ? a.idmap + krow : nullptr;
     // rank = inverse permutation.  Scattering it straight to HBM costs as much as the four radix passes
     // (27,942 random 4-byte writes per row); it is inverted in LDS instead and stored coalesced.
     const bool rank_via_lds = o_rank && !cmap && a.chunks == 1;   // block-uniform
-    const bool full_row = (m == a.n_total) && !init_row && !a.init_rank;   // a gathered/placed sequence may skip columns
+    const bool full_row = (m == a.n_total) && !init_row && !irow;   // a gathered/placed sequence may skip columns
     if (rank_via_lds && !full_row) {
+SLOT_FRESH();
 #pragma unroll
-        for (int i = 0; i < E; ++i) exch[w * E * 64 + i * 64 + lane] = 0xffffffffu;   // columns outside the sequence
+        for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = 0xffffffffu;   // columns outside the sequence
         __syncthreads();
     }
+SLOT_FRESH();
 #pragma unroll
     for (int i = 0; i < E; ++i) {
-        const int p = w * E * 64 + i * 64 + lane;
+        const int p = (slot0 + i * 64);
         if (p < lim) {
             int col = (int)(meta[i] & 0xffffu);
-            if (!init_row && !a.init_rank) col += c0;
+            if (!init_row && !irow) col += c0;
             const int oc = cmap ? cmap[col] : col;  // -1 = padding candidate of a short top-k chunk
             if (o_order) o_order[p] = oc;
             if (o_ids) o_ids[p] = imap ? imap[elem(col)] : (oc < 0 ? (int64_t)-1 : a.id_base + (int64_t)oc);
-            if (o_kf) {
-                if (KW == 1) o_kf[p] = desc_key_f32_inv(k0[i]);
-                else o_kd[p] = desc_key_f64_inv(((uint64_t)k1[KW == 2 ? i : 0] << 32) | (uint64_t)k0[i]);
-            }
-#ifndef FZ_ABL_NORANKSCATTER
+            if (KW == 1) { if (o_kf) o_kf[p] = desc_key_f32_inv(ks[i]); }
+            else if (o_kw) o_kw[2 * p] = ((nanm >> i) & 1u) ? 0u : (((signm >> i) & 1u) ? ~ks[i] : ks[i]);   // low half of desc_key_f64_inv
             if (rank_via_lds) exch[col] = (uint32_t)p;          // col < n_total <= T*E
             else if (o_rank && oc >= 0) o_rank[oc] = p;
-#endif
         }
         if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     if (rank_via_lds) {
         __syncthreads();
+SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const int j = w * E * 64 + i * 64 + lane;
+            const int j = (slot0 + i * 64);
             if (j < a.n_total) {
                 const uint32_t r = exch[j];
                 if (full_row || r != 0xffffffffu) o_rank[j] = (int32_t)r;
@@ -337,6 +568,8 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         }
     }
 }
+
+#undef SLOT_FRESH
 
 // pad the tail of top-k outputs with (-inf, -1)
 __global__ void topk_pad_kernel(float* out_scores, int64_t* out_ids, int rows, int k, int have) {
@@ -429,14 +662,24 @@ static inline bool pick_cfg(int n, int kw, SortCfg& c) {
 
 template <int T, int E, int KW>
 static int launch_cfg(const SortArgs& a, int prows, hipStream_t st) {
-    constexpr size_t lds = ((size_t)T * E + (T / 64) * 256 + 32) * 4;
-    static bool attr_set = false;  // per (T,E,KW) instantiation
-    if (!attr_set) {
-        FZ_HIP_TRY(hipFuncSetAttribute((const void*)sort_rows_kernel<T, E, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    constexpr size_t lds = ((size_t)T * E + (T / 64) * 256 + 32) * 4 + (KW == 2 ? (size_t)T * E : 0);   // fp64: + one move byte per slot
+    static_assert(lds <= 160 * 1024, "LDS budget of one CU");
+    int dev = 0;
+    FZ_HIP_TRY(hipGetDevice(&dev));
+    static unsigned long long attr_set = 0ull;   // per (T,E,KW) instantiation, one bit per device (the attribute is per device)
+    if (dev >= 64 || !((attr_set >> dev) & 1ull)) {
+        FZ_HIP_TRY(hipFuncSetAttribute((const void*)sort_rows_kernel<T, E, KW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if constexpr (KW == 2)
+            FZ_HIP_TRY(hipFuncSetAttribute((const void*)sort_rows_kernel<T, E, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev < 64) attr_set |= 1ull << dev;
     }
-    sort_rows_kernel<T, E, KW><<<prows, T, lds, st>>>(a);
+    if (KW == 2 && !a.row_flags) return FZ_ERR_WORKSPACE;
+    sort_rows_kernel<T, E, KW, false><<<prows, T, lds, st>>>(a);
     FZ_LAUNCH_CHECK();
+    if constexpr (KW == 2) {   // rows the fast form flagged (a dirty run of > 17 equal high words): generic eight passes; all others exit at once
+        sort_rows_kernel<T, E, 2, true><<<prows, T, lds, st>>>(a);
+        FZ_LAUNCH_CHECK();
+    }
     return FZ_OK;
 }
 
@@ -458,8 +701,11 @@ using namespace fz;
 extern "C" int fz_sort_max_n(void) { return 35840; }   // fp32 keys; fp64 keys: 28672
 extern "C" int fz_sort_max_n_f64(void) { return 28672; }
 
+extern "C" size_t fz_sort_workspace_bytes(int key_bits, int rows, int n) { (void)n; return key_bits == 64 && rows > 0 ? (size_t)rows * 4 : 0; }
+
 extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows,
-                                 int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream) {
+                                 int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
     if ((key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
     if (rows == 0 || n == 0) return FZ_OK;      // nothing to do (empty tensors carry null pointers)
     if (!keys) return FZ_ERR_ARG;
@@ -470,11 +716,13 @@ extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* 
     a.chunks = 1; a.chunk_len = n;
     a.order = order; a.sorted_keys = sorted_keys; a.rank = rank;
     a.out_row_stride = ld; a.out_chunk_stride = 0; a.out_limit = n;
+    if (key_bits == 64) { if (!workspace || workspace_bytes < fz_sort_workspace_bytes(64, rows, n)) return FZ_ERR_WORKSPACE; a.row_flags = (int32_t*)workspace; }
     return launch_sort(a, key_bits / 32, rows, n, as_stream(stream));
 }
 
 extern "C" int fz_sort_rows_desc_placed(const void* keys, int key_bits, const int32_t* init_rank, const int32_t* row_len, int rows,
-                                        int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream) {
+                                        int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
     if ((key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
     if (rows == 0 || n == 0) return FZ_OK;
     if (!keys || !init_rank) return FZ_ERR_ARG;
@@ -485,6 +733,7 @@ extern "C" int fz_sort_rows_desc_placed(const void* keys, int key_bits, const in
     a.chunks = 1; a.chunk_len = n;
     a.order = order; a.sorted_keys = sorted_keys; a.rank = rank;
     a.out_row_stride = ld; a.out_chunk_stride = 0; a.out_limit = n;
+    if (key_bits == 64) { if (!workspace || workspace_bytes < fz_sort_workspace_bytes(64, rows, n)) return FZ_ERR_WORKSPACE; a.row_flags = (int32_t*)workspace; }
     return launch_sort(a, key_bits / 32, rows, n, as_stream(stream));
 }
 

@@ -15,8 +15,6 @@ Ties are broken by ascending global document id everywhere, so the result does n
 """
 from __future__ import annotations
 
-import time
-
 import numpy as np
 import torch
 
@@ -73,83 +71,32 @@ class ShardedDenseIndex:
     def __init__(self, Dn_local: torch.Tensor, id_base: int, group=None):
         self.Dn, self.id_base, self.group = Dn_local, int(id_base), group
 
-    def local_topk(self, Qn: torch.Tensor, k: int, streaming: bool = True):
+    def local_topk(self, Qn: torch.Tensor, k: int, streaming: bool = True, mark=None):
         """Chunked score -> top-k over this shard.  First chunk: exact chunk-sort-truncate.  Later chunks: only scores
         above the running k-th best can enter, so they go through the streaming threshold filter (ops.topk_update);
-        if any row overflowed its candidate buffer the search is redone on the exact path (flag read once, at the end)."""
+        if any row overflowed its candidate buffer the search is redone on the exact path (flag read once, at the end).
+        `mark(name)`: optional instrumentation hook (bench.py records a HIP event per call)."""
         from . import ops
+        mark = mark or (lambda name: None)
         n = self.Dn.shape[0]
         best_s = best_i = None
         overflow = None
         for c0 in range(0, max(n, 1), self.CHUNK):
             c1 = min(n, c0 + self.CHUNK)
-            S = ops.dot_scores(Qn, self.Dn[c0:c1])
+            S = ops.dot_scores(Qn, self.Dn[c0:c1]); mark("shard_gemm")
             if best_s is None:
-                best_s, best_i = ops.topk_rows(S, k, id_base=self.id_base + c0)
+                best_s, best_i = ops.topk_rows(S, k, id_base=self.id_base + c0); mark("shard_topk_first")
             elif streaming and k + self.CAP <= 35840:
-                best_s, best_i, overflow = ops.topk_update(S, self.id_base + c0, best_s, best_i, self.CAP, overflow)
+                best_s, best_i, overflow = ops.topk_update(S, self.id_base + c0, best_s, best_i, self.CAP, overflow); mark("shard_topk_update")
             else:   # exact path: per-chunk top-k, then merge two id-ascending lists (chunks arrive in id order)
                 s, i = ops.topk_rows(S, k, id_base=self.id_base + c0)
-                best_s, best_i = ops.topk_merge(torch.stack([best_s, s]), torch.stack([best_i, i]))
+                best_s, best_i = ops.topk_merge(torch.stack([best_s, s]), torch.stack([best_i, i])); mark("shard_topk_exact")
         if overflow is not None and int(overflow.item()) != 0:
-            return self.local_topk(Qn, k, streaming=False)
+            return self.local_topk(Qn, k, streaming=False, mark=mark)
         return best_s, best_i
 
-    def search(self, Qn: torch.Tensor, k: int = 1000):
-        s, i = self.local_topk(Qn, k)
-        return allgather_topk(s, i, self.group)
-
-
-def bench_sharded(args, dev, rank, world, dist):
-    """bench.py --workload mmarco: encode + sharded score + top-k + all-gather, queries/s (strong scaling: the corpus is fixed)."""
-    from . import encoders, ops
-    N, d, Q, k = args.mmarco_docs, args.dim, args.queries, args.topk
-    lo, hi = shard_bounds(N, world, rank)
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    Dn = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
-    for c0 in range(0, hi - lo, 1 << 20):   # generated on the device, shard by shard: 27 GB never cross PCIe
-        c1 = min(hi - lo, c0 + (1 << 20))
-        Dn[c0:c1] = ops.normalize_rows(torch.randn((c1 - c0, d), generator=g, device=dev))
-    index = ShardedDenseIndex(Dn, lo, None)
-    rng = np.random.default_rng(5)
-    if not args.no_encode:
-        enc = encoders.random_init("dpr", device=dev, size=args.encoder_size, seed=0)
-        if not getattr(args, "no_gemm_tuning", False):
-            encoders.enable_gemm_tuning()
-        L = 64
-        qlen = rng.integers(8, L + 1, Q)
-        ids = rng.integers(7, enc.backbone.config.vocab_size - 1, (Q, L))
-        mask = (np.arange(L)[None, :] < qlen[:, None]).astype(np.int64)
-        qlo, qhi = shard_bounds(Q, world, rank)                         # this rank encodes its 1/world of the queries
-        ids_t = torch.from_numpy(np.where(mask == 1, ids, 1)[qlo:qhi]).to(dev)
-        qlen = qlen[qlo:qhi]
-    else:
-        q_emb = torch.from_numpy(rng.normal(0, 1, (Q, d)).astype(np.float32)).to(dev)
-
-    def step():
-        e = allgather_rows(enc.encode_ids_packed(ids_t, qlen), Q) if not args.no_encode else q_emb
-        return index.search(ops.normalize_rows(e), k)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist: dist.barrier()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    el = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    flops = 2.0 * Q * (hi - lo) * d
-    return {"metric": "queries/sec end-to-end (encode+score+fuse), mMARCO-fr-shaped sharded DPR", "value": Q * args.steps / el,
-            "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"mMARCO-fr-shaped DPR: N={N} passages sharded x{world}, d={d}, Q={Q}, top-{k}, RCCL all-gather of per-shard top-k",
-                       "encode_in_step": not args.no_encode},
-            "shard_gemm_tflop": flops / 1e12}
+    def search(self, Qn: torch.Tensor, k: int = 1000, mark=None):
+        s, i = self.local_topk(Qn, k, mark=mark)
+        out = allgather_topk(s, i, self.group)
+        if mark: mark("allgather_merge")
+        return out

@@ -221,8 +221,9 @@ class PackedBertForward(FusedBertForward):
     def hidden(self, input_ids: torch.Tensor, lengths, mark=None):
         """input_ids [n, Lmax] (anything beyond a row's length is ignored), lengths: HOST token counts ->
         (last hidden states of the real tokens, packed [T, hidden] fp32 in row order; cu_rows [n+1] int32 on the device).
-        `mark(name)`: optional instrumentation hook (bench.py records a HIP event per call): "encode" closes an interval
-        of everything but attention, "encode_attn" closes one fz_attn_varlen_f32 launch."""
+        `mark(name)`: optional instrumentation hook (bench.py records a HIP event per call); every call closes the interval
+        since the previous one: "encode_embed" the embedding kernel (+ index uploads), "encode_gemm" one hipBLASLt Linear,
+        "encode_attn" / "encode_ln" / "encode_gelu" one launch of fz_attn_varlen_f32 / fz_add_layernorm_f32 / fz_gelu_f32."""
         import numpy as np
         from . import ops
         F = torch.nn.functional
@@ -249,14 +250,17 @@ class PackedBertForward(FusedBertForward):
         # embedding gather + position + type + LayerNorm in one pass over the packed rows
         x = ops.embed_layernorm(self.word, self.pos, self.type0, ids, meta[T:], *self.emb_ln, out=x)
         ctx = torch.zeros_like(x)                 # attention writes the real rows of this buffer in every layer
+        mark = mark or (lambda name: None)
+        mark("encode_embed")
         for ly in self.layers:
-            qkv = F.linear(x, ly["wqkv"], ly["bqkv"])
-            if mark: mark("encode")
-            ops.attn_varlen(qkv, strips_d, H, out=ctx)
-            if mark: mark("encode_attn")
-            x = ops.add_layernorm(F.linear(ctx, ly["wo"], ly["bo"]), x, *ly["ln1"])
-            h = ops.gelu_(F.linear(x, ly["w1"], ly["b1"]))          # in place, non-temporal loads
-            x = ops.add_layernorm(F.linear(h, ly["w2"], ly["b2"]), x, *ly["ln2"])
+            qkv = F.linear(x, ly["wqkv"], ly["bqkv"]); mark("encode_gemm")
+            ops.attn_varlen(qkv, strips_d, H, out=ctx); mark("encode_attn")
+            y = F.linear(ctx, ly["wo"], ly["bo"]); mark("encode_gemm")
+            x = ops.add_layernorm(y, x, *ly["ln1"]); mark("encode_ln")
+            h = F.linear(x, ly["w1"], ly["b1"]); mark("encode_gemm")
+            h = ops.gelu_(h); mark("encode_gelu")                   # in place, non-temporal loads
+            y = F.linear(h, ly["w2"], ly["b2"]); mark("encode_gemm")
+            x = ops.add_layernorm(y, x, *ly["ln2"]); mark("encode_ln")
         return x[:T], cu_d
 
     @torch.no_grad()

@@ -234,6 +234,9 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
         row_len = row_len.contiguous()
         _need(row_len.numel() == rows, f"row_len: expected {rows} entries, got {row_len.numel()}")
     bits = 32 if keys.dtype == torch.float32 else 64
+    lib = _lib.lib()
+    wsb = int(lib.fz_sort_workspace_bytes(bits, rows, n))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
     if init_rank is not None:
         _dev(init_rank, torch.int32, "init_rank")
         _need(tuple(init_rank.shape) == (rows, n), f"init_rank: expected shape {(rows, n)}, got {tuple(init_rank.shape)}")
@@ -241,11 +244,11 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
             t = mk(torch.int32, -1)
             t.copy_(init_rank)
             init_rank = t
-        check(_lib.lib().fz_sort_rows_desc_placed(_ptr(keys), bits, _ptr(init_rank), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk),
-                                                  _ptr(rank), _stream(keys)), "fz_sort_rows_desc_placed")
+        check(lib.fz_sort_rows_desc_placed(_ptr(keys), bits, _ptr(init_rank), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk),
+                                           _ptr(rank), _ptr(ws), wsb, _stream(keys)), "fz_sort_rows_desc_placed")
     else:
-        check(_lib.lib().fz_sort_rows_desc(_ptr(keys), bits, _ptr(init_order), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk),
-                                           _ptr(rank), _stream(keys)), "fz_sort_rows_desc")
+        check(lib.fz_sort_rows_desc(_ptr(keys), bits, _ptr(init_order), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk),
+                                    _ptr(rank), _ptr(ws), wsb, _stream(keys)), "fz_sort_rows_desc")
     return order, sk, rank
 
 

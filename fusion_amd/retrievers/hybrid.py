@@ -184,7 +184,7 @@ class Aggregator:
             raise ValueError("device systems must be planes over the same corpus")
         dev = S[0].scores.device
         all_full = all(s.full for s in S)
-        ranks = None if all_full else [s.rank for s in S]
+        ranks = None if all_full else [None if s.full else s.rank for s in S]   # validity: only the partial lists need their rank plane read
 
         if method in ("bcf", "rrf"):
             lens = torch.stack([s.lens for s in S]).contiguous()
@@ -199,8 +199,8 @@ class Aggregator:
                 if normalization in ("percentile-rank", "normal-curve-equivalent"):
                     distr = [cls._table(percentile_distributions.get(n), dev) for n in names]
                 if any(wide):   # transform every system in float32 (weight 1: fl32(t * 1) == t), then weight + sum as NumPy does
-                    T = [ops.fuse_nsf([s.scores], [s.rank], [1.0], normalization, None if distr is None else [distr[i]]) for i, s in enumerate(S)]
-                    fused = ops.fuse_wsum(T, [s.rank for s in S], w, narrow=[not x for x in wide])
+                    T = [ops.fuse_nsf([s.scores], None if s.full else [s.rank], [1.0], normalization, None if distr is None else [distr[i]]) for i, s in enumerate(S)]
+                    fused = ops.fuse_wsum(T, ranks, w, narrow=[not x for x in wide])
                 elif normalization == "min-max" and all(s.score_sorted for s in S):
                     # score-sorted lists: min / max are the two ends of every list, no row reduction
                     fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, orders=[s.order for s in S],

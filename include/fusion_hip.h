@@ -89,15 +89,21 @@ int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* Doff, int64
  * one workgroup). */
 int fz_sort_max_n(void);
 int fz_sort_max_n_f64(void);
+/* workspace: fz_sort_workspace_bytes(key_bits, rows, n) bytes of device memory (0 for fp32 rows that fit one workgroup).
+ * fp64 keys are sorted by their high word (4 radix passes) and repaired in place where equal high words hide a low-word
+ * inversion; a row with such a run longer than 17 keys is flagged in the workspace and redone by a generic 8-pass launch. */
+size_t fz_sort_workspace_bytes(int key_bits, int rows, int n);
 int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows, int n,
-                      int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream);
+                      int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* Same sort, incoming sequence given the other way round: init_rank[row][j] = position of column j in the incoming
  * sequence (-1 = not in it); restricted to the columns in the sequence it is a bijection onto [0, row_len[row]).
  * This is what a rank plane IS, so the fused-list ordering (ties keep system 0's order) needs no gather:
  * keys and positions are read coalesced and placed through LDS. */
 int fz_sort_rows_desc_placed(const void* keys, int key_bits, const int32_t* init_rank, const int32_t* row_len, int rows, int n,
-                             int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* stream);
+                             int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /* ---- K5b: rank-based fusion, hybrid.py:206-211,248-252,301-304 ------------------------- */
 /* fused[q][j] = sum over systems s (in the given order, fp64, starting from 0.0) of
