@@ -125,11 +125,11 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         // column; the sort word, then the payload, are scattered to exch[position] and read back in striped order -- the
         // random walk happens in LDS instead of as 27,942 uncoalesced HBM reads per row.  The positions are read twice
         // (second time from L2) rather than held in 28 registers.
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = SENT;
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i0 = 0; i0 < E; i0 += LG) {
             uint32_t pos_t[LG], lo_t[LG], hi_t[LG];
@@ -152,15 +152,15 @@ SLOT_FRESH();
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) ks[i] = exch[(slot0 + i * 64)];
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = 0xffffu;
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i0 = 0; i0 < E; i0 += 2 * LG) {
             uint32_t pos_t[2 * LG];
@@ -178,7 +178,7 @@ SLOT_FRESH();
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             meta[i] = exch[(slot0 + i * 64)];
@@ -186,7 +186,7 @@ SLOT_FRESH();
         }
         __syncthreads();
     } else {
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i0 = 0; i0 < E; i0 += LG) {
             uint32_t lo_t[LG], hi_t[KW == 2 ? LG : 1];
@@ -234,7 +234,7 @@ SLOT_FRESH();
         // ---- 1. rank inside the wave ------------------------------------------------
         uint32_t* my = cnt + w * 256;
         my[lane] = 0; my[lane + 64] = 0; my[lane + 128] = 0; my[lane + 192] = 0;
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const uint32_t kw = ks[i];
@@ -286,7 +286,7 @@ SLOT_FRESH();
         __syncthreads();
         // ---- 3. destination, exchange --------------------------------------------------
         // (sched_barrier every 4 items: without it hipcc hoists all E LDS addresses/values and spills)
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             uint32_t kw = ks[i];
@@ -299,21 +299,21 @@ SLOT_FRESH();
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             ks[i] = exch[(slot0 + i * 64)];
             if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             exch[meta[i] >> 16] = meta[i] & 0xffffu;
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             meta[i] = exch[(slot0 + i * 64)];
@@ -323,26 +323,26 @@ SLOT_FRESH();
     };
     // move (ks, payload) to the slots in meta's high halves (a permutation of [0, m)); slots >= m keep theirs
     auto permute_to_meta_hi = [&]() {
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) exch[meta[i] >> 16] = ks[i];
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) ks[i] = exch[(slot0 + i * 64)];
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) exch[meta[i] >> 16] = meta[i] & 0xffffu;
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) meta[i] = exch[(slot0 + i * 64)];
         __syncthreads();
     };
     // fp64: (re)load one key word of every slot's element from global memory, by payload (a gather; rare paths only)
     auto reload_word = [&](bool high) {
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const uint32_t py = meta[i] & 0xffffu;
@@ -364,7 +364,7 @@ SLOT_FRESH();
         // memory by payload), four more passes, the high halves of the sorted keys, and the low words again for the output
         reload_word(true);
         uint32_t o1 = 0u, a1 = 0xffffffffu;
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) if ((meta[i] & 0xffffu) != 0xffffu) { o1 |= ks[i]; a1 &= ks[i]; }
         __syncthreads();
@@ -375,7 +375,7 @@ SLOT_FRESH();
         const uint32_t dh = misc[8] ^ misc[9], dh_match = has_sent ? ~misc[9] : dh;
         for (int pass = 0; pass < 4; ++pass)
             if (((dh >> (pass * 8)) & 0xffu) != 0u) radix_pass(pass * 8, (dh_match >> (pass * 8)) & 0xffu);
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const int p = (slot0 + i * 64);
@@ -393,24 +393,20 @@ SLOT_FRESH();
         // a run is almost always 2-3 keys long, except runs of EQUAL keys (BM25's zeros), which need nothing.  So:
         // note which slots continue their left neighbour's run, write the high halves of the sorted keys, swap the
         // high words for the low words (re-derived from global memory by the thread that loaded them, handed over
-        // through LDS by payload), and repair the dirty short runs in place.  Same permutation as eight LSD passes
-        // over the 64-bit key at half the ranking work and a third of the exchanges.  A row with a dirty run longer
-        // than WALK + 1 is flagged instead (row_flags) and redone by the generic eight-pass form of this kernel (GEN), a
-        // second launch in which every other row's workgroup exits at once.
+        // through LDS by payload), and repair the dirty runs in place.  Same permutation as eight LSD passes over the
+        // 64-bit key at half the ranking work and a third of the exchanges.  A row the repair cannot take (see below) is
+        // flagged instead (row_flags) and redone by the generic eight-pass form of this kernel (GEN), a second launch in
+        // which every other row's workgroup exits at once.
         uint32_t* runbits = cnt;   // [T*E/32]: bit (p & 31) of word p >> 5 = "slot p has the same high word as slot p-1"
-        auto bit_of = [&](int p) -> bool { return (runbits[p >> 5] >> (p & 31)) & 1u; };
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = ks[i];
         __syncthreads();
-        uint32_t nextsame = 0u;   // bit i: slot i of this thread has the same high word as the slot after it
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const int p = (slot0 + i * 64);
             const bool ps = p > 0 && p < m && exch[p - 1] == ks[i];
-            const bool ns = p + 1 < m && exch[p + 1] == ks[i];
-            nextsame |= (uint32_t)ns << i;
             const unsigned long long bal = __ballot(ps);
             if (lane == 0) { runbits[(w * E + i) * 2] = (uint32_t)bal; runbits[(w * E + i) * 2 + 1] = (uint32_t)(bal >> 32); }
             // the sorted key's high half is final now (the repair only moves keys inside runs of EQUAL high words)
@@ -424,7 +420,7 @@ SLOT_FRESH();
         __syncthreads();
         // ---- low words: re-derived by the thread that loaded the element, published under its payload ----
         constexpr int LGG = 4;
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i0 = 0; i0 < E; i0 += LGG) {
             uint32_t lo_t[LGG], hi_t[LGG];
@@ -447,7 +443,7 @@ SLOT_FRESH();
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const uint32_t py = meta[i] & 0xffffu;
@@ -455,74 +451,118 @@ SLOT_FRESH();
             if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        // ---- repair: every SHORT run (<= WALK + 1 slots) is re-sorted by its first slot's thread, which leaves the move of
-        // every member (new slot - old slot, one signed byte) in delta[]; 0x7f = "not in a short run".  A misordered pair
-        // whose slots stay 0x7f sits in a long run: that row takes the generic path.
+        // ---- repair.  The runs are described completely by LDS state -- runbits ("same high word as the slot before")
+        // and the low words by slot in exch[] -- so the work is done by whichever thread is convenient, not by the slots'
+        // owners:
+        //   1. thread t inspects the 32 slots of runbits word t: a misordered neighbour pair inside a run marks the
+        //      run's head (nearest clear bit to the left) in dirtybits;
+        //   2. the thread whose word holds a DIRTY head re-sorts the run: up to WALK + 1 slots by itself (stable counting
+        //      sort; the usual case is a pair), leaving every member's move as a signed byte in delta[]; a longer run
+        //      (up to 2 T slots) goes on a short list;
+        //   3. listed runs are counted by the whole workgroup (slot x of the run: how many members precede it), the new
+        //      slot numbers replace the low words in exch[] and delta[] says 0x7e = "look there";
+        //   4. every owner moves (low word, payload) to slot p + delta[p] (0x7f: stays).
+        // Runs of EQUAL keys (BM25's zeros, ties) are never dirty and cost nothing.  A dirty run longer than 2 T slots,
+        // or more than BIGCAP listed runs, flags the row for the generic launch.
+        constexpr int NWORDS = T * E / 32, BIGCAP = 64, BIGMAX = 2 * T;
+        static_assert(2 * NWORDS + BIGCAP <= NW * 256 && BIGMAX < 4096, "repair state lives in the counter area");
+        uint32_t* dirtybits = cnt + NWORDS;
+        uint32_t* biglist = cnt + 2 * NWORDS;
         int8_t* delta = reinterpret_cast<int8_t*>(smem + T * E + NW * 256 + 32);   // [T*E] bytes
-SLOT_FRESH();
+        const int t = threadIdx.x;
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = ks[i];
         {
             uint32_t* d32 = reinterpret_cast<uint32_t*>(delta);
 #pragma unroll
-            for (int i = 0; i < (E + 3) / 4; ++i) { const int x = i * T + threadIdx.x; if (x < T * E / 4) d32[x] = 0x7f7f7f7fu; }
+            for (int i = 0; i < (E + 3) / 4; ++i) { const int x = i * T + t; if (x < T * E / 4) d32[x] = 0x7f7f7f7fu; }
+            if (t < NWORDS) dirtybits[t] = 0u;
+            if (t == 0) { misc[12] = 0u; misc[13] = 0u; }
         }
         __syncthreads();
-        uint32_t badm = 0u;
-SLOT_FRESH();
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const int p = (slot0 + i * 64);
-            if ((nextsame >> i) & 1u) badm |= (uint32_t)(ks[i] > exch[p + 1]) << i;
-            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        bool anybad = false;
+        if (t < NWORDS) {
+            const uint32_t b = runbits[t], bn = (t + 1 < NWORDS) ? runbits[t + 1] : 0u;
+            uint32_t cont = (b >> 1) | (bn << 31);             // bit k: slot 32 t + k + 1 continues the run of slot 32 t + k
+            while (cont) {
+                const int k = __builtin_ctz(cont);
+                cont &= cont - 1;
+                const int p = 32 * t + k;
+                if (exch[p] > exch[p + 1]) {                   // out of order in the low word
+                    anybad = true;
+                    int wd = t;
+                    uint32_t z = ~b & ((2u << k) - 1u);        // clear bits at or below slot p in this word (k = 31: all of it)
+                    while (z == 0u) { --wd; z = ~runbits[wd]; }   // terminates: slot 0 never continues a run
+                    const int h = wd * 32 + 31 - __builtin_clz(z);
+                    atomicOr(&dirtybits[h >> 5], 1u << (h & 31));
+                }
+            }
         }
-        if (__syncthreads_or(badm != 0u ? 1 : 0)) {
-            // The runs are described completely by LDS state (runbits = "same high word as the slot before", exch = low
-            // words), so ANY thread can repair a run: thread t takes the 32 slots of runbits word t and handles the run
-            // heads among them (~bit(p) & bit(p+1)) -- a sparse loop, no per-item unrolled code.
-            static_assert(E <= 32, "one runbits word per thread");
-            if (threadIdx.x < T * E / 32) {
-                const int t = threadIdx.x;
-                const uint32_t b = runbits[t], bn = (t + 1 < T * E / 32) ? runbits[t + 1] : 0u;
-                uint32_t heads = ~b & ((b >> 1) | (bn << 31));      // bits of slots >= m are clear: no run crosses m
+        if (__syncthreads_or(anybad ? 1 : 0)) {
+            if (t < NWORDS) {
+                uint32_t heads = dirtybits[t];
                 while (heads) {
-                    const int p = 32 * t + __builtin_ctz(heads);
+                    const int h = 32 * t + __builtin_ctz(heads);
                     heads &= heads - 1;
-                    const uint32_t lo0 = exch[p], lo1 = exch[p + 1];
-                    const bool more = (p + 2 < m) && bit_of(p + 2);
-                    if (!more) {                               // the usual case: a run of two
-                        const bool sw = lo0 > lo1;
-                        delta[p] = sw ? 1 : 0; delta[p + 1] = sw ? -1 : 0;
-                    } else {
-                        int re = p + 2;                        // last slot known to belong to the run
-                        while (re - p < WALK && (re + 1 < m) && bit_of(re + 1)) ++re;
-                        if (!((re + 1 < m) && bit_of(re + 1))) {   // closed within WALK + 1 slots: stable counting sort of the run
-                            for (int x = p; x <= re; ++x) {
-                                const uint32_t vx = exch[x];
-                                int before = 0;
-                                for (int y = p; y <= re; ++y) { const uint32_t vy = exch[y]; before += (vy < vx || (vy == vx && y < x)) ? 1 : 0; }
-                                delta[x] = (int8_t)(p + before - x);
-                            }
+                    // end of the run: first slot after h whose bit is clear (slots >= m never continue a run)
+                    const int e0 = h + 1;
+                    int wd = e0 >> 5;
+                    uint32_t z = ~runbits[wd] & ~((1u << (e0 & 31)) - 1u);
+                    while (z == 0u && wd + 1 < NWORDS) { ++wd; z = ~runbits[wd]; }
+                    const int L = (z ? wd * 32 + __builtin_ctz(z) : NWORDS * 32) - h;
+                    if (L == 2) { delta[h] = 1; delta[h + 1] = -1; }             // a dirty pair: swap
+                    else if (L <= WALK + 1) {                                     // stable counting sort by one thread
+                        for (int x = 0; x < L; ++x) {
+                            const uint32_t vx = exch[h + x];
+                            int before = 0;
+                            for (int y = 0; y < L; ++y) { const uint32_t vy = exch[h + y]; before += (vy < vx || (vy == vx && y < x)) ? 1 : 0; }
+                            delta[h + x] = (int8_t)(before - x);
                         }
-                    }
+                    } else if (L <= BIGMAX) {
+                        const uint32_t idx = atomicAdd(&misc[12], 1u);
+                        if (idx < (uint32_t)BIGCAP) biglist[idx] = ((uint32_t)h << 12) | (uint32_t)L;
+                        else misc[13] = 1u;
+                    } else misc[13] = 1u;
                 }
             }
             __syncthreads();
-            bool fallback = false;
-SLOT_FRESH();
+            if (misc[13] != 0u) {                              // block-uniform: leave the row to the generic form
+                if (t == 0) a.row_flags[prow] = 1;
+                return;
+            }
+            const int nbig = (int)misc[12];
+            for (int bi = 0; bi < nbig; ++bi) {
+                const uint32_t ent = biglist[bi];
+                const int h = (int)(ent >> 12), L = (int)(ent & 0xfffu);
+                int npos[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int x = t + r * T;
+                    npos[r] = -1;
+                    if (x < L) {
+                        const uint32_t vx = exch[h + x];
+                        int before = 0;
+                        for (int y = 0; y < L; ++y) { const uint32_t vy = exch[h + y]; before += (vy < vx || (vy == vx && y < x)) ? 1 : 0; }
+                        npos[r] = h + before;
+                    }
+                }
+                __syncthreads();                               // every low word of the run has been read
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if (npos[r] >= 0) { exch[h + t + r * T] = (uint32_t)npos[r]; delta[h + t + r * T] = 0x7e; }
+            }
+            __syncthreads();
+            SLOT_FRESH();
 #pragma unroll
             for (int i = 0; i < E; ++i) {
                 const int p = (slot0 + i * 64);
-                const int d = p < m ? (int)delta[p] : 0;
-                fallback |= ((badm >> i) & 1u) && d == 0x7f;
-                const uint32_t np = (uint32_t)(p + (d == 0x7f ? 0 : d));
+                const int d = p < m ? (int)delta[p] : 0x7f;
+                const uint32_t np = d == 0x7f ? (uint32_t)p : (d == 0x7e ? exch[p] : (uint32_t)(p + d));
                 meta[i] = __builtin_amdgcn_perm(np, meta[i], 0x05040100u);
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            if (__syncthreads_or(fallback ? 1 : 0)) {      // block-uniform: leave the row to the generic form
-                if (threadIdx.x == 0) a.row_flags[prow] = 1;
-                return;
-            }
+            __syncthreads();                                   // the slot numbers in exch[] have been read
             permute_to_meta_hi();
         }
     }
@@ -533,12 +573,12 @@ SLOT_FRESH();
     const bool rank_via_lds = o_rank && !cmap && a.chunks == 1;   // block-uniform
     const bool full_row = (m == a.n_total) && !init_row && !irow;   // a gathered/placed sequence may skip columns
     if (rank_via_lds && !full_row) {
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = 0xffffffffu;   // columns outside the sequence
         __syncthreads();
     }
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         const int p = (slot0 + i * 64);
@@ -557,7 +597,7 @@ SLOT_FRESH();
     }
     if (rank_via_lds) {
         __syncthreads();
-SLOT_FRESH();
+        SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const int j = (slot0 + i * 64);

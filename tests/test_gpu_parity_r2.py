@@ -242,3 +242,55 @@ def test_none_passthrough_keeps_float64_scores(oracle):
     assert got == exp
     got = Aggregator.fuse(lists, "unknown-method")     # raw scores summed (hybrid.py:203-218)
     assert got == oracle.fuse_lists(lists, "unknown-method")
+
+
+# ---- fp64 row sort: high-word passes + run repair + generic second launch (csrc/sort.hip) -----------------------------
+@pytest.mark.parametrize("n", [300, 5000, 27942])
+@pytest.mark.parametrize("mode", ["plain", "placed", "gathered"])
+def test_sort_f64_equal_high_word_runs(ops, oracle, n, mode):
+    """Keys that share their high 32 bits (sign, exponent, 20 mantissa bits) and differ only below: runs of 2..17 go
+    through the in-place repair, longer dirty runs through the generic eight-pass launch, runs of EQUAL keys need nothing.
+    All must give the oracle's stable order."""
+    rng = np.random.default_rng(n)
+    rows = 6
+    k = rng.gamma(2.0, 3.0, (rows, n))
+    ulp20 = 2.0 ** -20
+    # row 0: pairs / triples; row 1: runs up to 17; row 2: runs of 18..40 (long, dirty); row 3: ONE run over the whole row;
+    # row 4: a long run of equal keys (clean) next to short dirty runs; row 5: negative values, zeros of both signs, inf, nan
+    def plant(r, lengths):
+        pos = 0
+        for L in lengths:
+            if pos + L > n:
+                break
+            base = 1.0 + float(rng.integers(0, 1 << 19)) * ulp20 * 2        # exactly representable, low word zero
+            k[r, pos: pos + L] = base + rng.permutation(L) * 2.0 ** -40       # same high word, distinct low words, shuffled
+            pos += L + int(rng.integers(0, 3))
+    plant(0, rng.integers(2, 4, n // 4))
+    plant(1, rng.integers(2, 18, n // 12))
+    plant(2, rng.integers(18, 41, n // 40))
+    k[3] = 3.0 + rng.permutation(n) * 2.0 ** -45
+    k[4, : n // 2] = 0.0
+    plant(4, [2] * 10)
+    k[4] = np.roll(k[4], n // 3)
+    k[5] = -k[5]
+    k[5, ::7] = 0.0; k[5, 3::11] = -0.0
+    if n > 20:
+        k[5, 5] = np.inf; k[5, 6] = -np.inf; k[5, 9] = np.nan; k[5, 10: 14] = k[5, 10] + np.arange(4) * 2.0 ** -50
+    kp = ops.alloc_plane(rows, n, torch.float64, "cuda"); kp.copy_(torch.from_numpy(k))
+    if mode == "plain":
+        order, sk, rank = ops.sort_rows_desc(kp, want_rank=True)
+        e_order, e_sk, e_rank = oracle.sort_rows_desc(k, want_rank=True)
+    else:
+        init = np.stack([rng.permutation(n) for _ in range(rows)]).astype(np.int32)       # incoming sequence = a permutation
+        lens = np.array([n, n - 1, max(1, n // 2), n, n, max(1, n - 7)], dtype=np.int32)
+        e_order, e_sk, e_rank = oracle.sort_rows_desc(k, init_order=init, row_len=lens, want_rank=True)
+        if mode == "gathered":
+            order, sk, rank = ops.sort_rows_desc(kp, init_order=dev(init), row_len=dev(lens), want_rank=True)
+        else:
+            inv = np.full((rows, n), -1, dtype=np.int32)
+            for r in range(rows):
+                inv[r, init[r, : lens[r]]] = np.arange(lens[r], dtype=np.int32)
+            order, sk, rank = ops.sort_rows_desc(kp, init_rank=dev(inv), row_len=dev(lens), want_rank=True)
+    np.testing.assert_array_equal(order.cpu().numpy(), e_order)
+    np.testing.assert_array_equal(rank.cpu().numpy(), e_rank)
+    np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)
