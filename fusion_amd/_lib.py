@@ -46,7 +46,7 @@ _PROTOS = {
     "fz_sort_max_n": (_i, []),
     "fz_sort_max_n_f64": (_i, []),
     "fz_sort_workspace_bytes": (_sz, [_i, _i, _i]),
-    "fz_sort_rows_desc": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fz_sort_rows_desc": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_sort_rows_desc_placed": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_fuse_rank_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fz_row_stats_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

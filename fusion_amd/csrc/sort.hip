@@ -45,6 +45,8 @@ struct SortArgs {
     int64_t id_base;             // else out_ids = id_base + col
     int64_t* out_ids;            // nullable, [rows][out_row_stride] like order
     int32_t* row_flags;          // fp64 keys: [rows*chunks] 1 = the fast form left the row to the generic one
+    float* row_mean;             // nullable [rows]: mean and unbiased standard deviation of the row's float32 values, a by-product
+    float* row_std;              //   of having the row in registers (the z-score statistics of hybrid.py:261-262); plain rows only
 };
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
@@ -186,6 +188,13 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         }
         __syncthreads();
     } else {
+        double s1 = 0.0, s2 = 0.0, sn = 0.0, x0 = 0.0;   // row statistics (only when a.row_mean)
+        if (!GEN && a.row_mean) {
+            float f0;
+            if (KW == 1) f0 = kf[elem(init_row ? 0 : c0)];
+            else { const uint2 v0 = kd[elem(init_row ? 0 : c0)]; f0 = (float)__hiloint2double((int)v0.y, (int)v0.x); }
+            x0 = (f0 == f0 && fabsf(f0) != INFINITY) ? (double)f0 : 0.0;   // any finite sample of the row keeps the one-pass sums stable
+        }
         SLOT_FRESH();
 #pragma unroll
         for (int i0 = 0; i0 < E; i0 += LG) {
@@ -212,10 +221,33 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
                                             : (uint32_t)(key64(make_uint2(lo_t[i - i0], hi_t[KW == 2 ? i - i0 : 0])) >> (GEN ? 0 : 32));
                 ks[i] = ok ? kw : SENT;
                 orw |= ok ? kw : 0u; andw &= ok ? kw : 0xffffffffu;
+                if (!GEN && a.row_mean) {   // the value as the normalisations see it: float32 (BM25's float64 scores rounded, hybrid.py:261)
+                    const float xf = KW == 1 ? __uint_as_float(lo_t[i - i0]) : (float)__hiloint2double((int)hi_t[KW == 2 ? i - i0 : 0], (int)lo_t[i - i0]);
+                    const double dd = ok ? (double)xf - x0 : 0.0;
+                    s1 += dd; s2 = fma(dd, dd, s2); sn += ok ? 1.0 : 0.0;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();   // misc[8..9] initialised
+        if (!GEN && a.row_mean && a.chunks == 1) {   // block-uniform
+            // z-score statistics of the row (torch.mean / torch.std of the float32 scores, hybrid.py:261-262): one pass, shifted by
+            // the row's first value, fp64 throughout; wave sums by shuffles, the NW partial triples through the (still unused)
+            // counter area, folded in wave order by every thread identically
+            s1 = wave_reduce_sum(s1); s2 = wave_reduce_sum(s2); sn = wave_reduce_sum(sn);
+            double* red = reinterpret_cast<double*>(cnt);
+            if (lane == 0) { red[w] = s1; red[NW + w] = s2; red[2 * NW + w] = sn; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double S1 = 0.0, S2 = 0.0, n = 0.0;
+                for (int i = 0; i < NW; ++i) { S1 += red[i]; S2 += red[NW + i]; n += red[2 * NW + i]; }
+                const double mean = n > 0.0 ? x0 + S1 / n : (double)NAN;
+                const double var = n > 1.0 ? (S2 - S1 * S1 / n) / (n - 1.0) : (double)NAN;
+                a.row_mean[row] = (float)mean;
+                a.row_std[row] = (float)sqrt(var < 0.0 ? 0.0 : var);
+            }
+            __syncthreads();
+        }
     }
     // which bits of the sort word vary over the row?
 #pragma unroll
@@ -744,17 +776,18 @@ extern "C" int fz_sort_max_n_f64(void) { return 28672; }
 extern "C" size_t fz_sort_workspace_bytes(int key_bits, int rows, int n) { (void)n; return key_bits == 64 && rows > 0 ? (size_t)rows * 4 : 0; }
 
 extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows,
-                                 int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, float* row_mean, float* row_std,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
     if ((key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
     if (rows == 0 || n == 0) return FZ_OK;      // nothing to do (empty tensors carry null pointers)
     if (!keys) return FZ_ERR_ARG;
     if (n > (key_bits == 32 ? 35840 : 28672)) return FZ_ERR_UNSUPPORTED;
     SortArgs a{};
+    if ((row_mean != nullptr) != (row_std != nullptr)) return FZ_ERR_ARG;
     a.keys = keys; a.init_order = init_order; a.row_len = row_len;
     a.n_total = n; a.key_row_stride = ld; a.seg_len = n; a.seg_stride = 0;
     a.chunks = 1; a.chunk_len = n;
-    a.order = order; a.sorted_keys = sorted_keys; a.rank = rank;
+    a.order = order; a.sorted_keys = sorted_keys; a.rank = rank; a.row_mean = row_mean; a.row_std = row_std;
     a.out_row_stride = ld; a.out_chunk_stride = 0; a.out_limit = n;
     if (key_bits == 64) { if (!workspace || workspace_bytes < fz_sort_workspace_bytes(64, rows, n)) return FZ_ERR_WORKSPACE; a.row_flags = (int32_t*)workspace; }
     return launch_sort(a, key_bits / 32, rows, n, as_stream(stream));

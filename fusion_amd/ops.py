@@ -197,12 +197,15 @@ def sort_max_n(dtype=torch.float32) -> int:
 
 
 def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, row_len: torch.Tensor | None = None,
-                   want_order=True, want_keys=True, want_rank=False, init_rank: torch.Tensor | None = None):
+                   want_order=True, want_keys=True, want_rank=False, init_rank: torch.Tensor | None = None,
+                   stats_out: tuple[torch.Tensor, torch.Tensor] | None = None):
     """Stable descending row sort (Python sorted(reverse=True): bm25.py:104, hybrid.py:306).
     Incoming sequence: identity (default), `init_order` (column at each sequence position) or `init_rank`
     (sequence position of each column: a rank plane; read coalesced, the fast form).
     Returns (order|None, sorted_keys|None, rank|None); order/sorted_keys entries beyond row_len are -1 / -inf,
-    rank entries of elements outside the sequence are -1."""
+    rank entries of elements outside the sequence are -1.
+    stats_out = (mean, std): two fp32 tensors of `rows` entries that receive each row's mean and unbiased standard deviation
+    (of the float32 values) as a by-product of the sort -- identity sequence only."""
     _dev(keys, None, "sort_rows_desc(keys)")
     if keys.dtype not in (torch.float32, torch.float64):
         raise TypeError("keys must be float32 or float64")
@@ -247,8 +250,15 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
         check(lib.fz_sort_rows_desc_placed(_ptr(keys), bits, _ptr(init_rank), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk),
                                            _ptr(rank), _ptr(ws), wsb, _stream(keys)), "fz_sort_rows_desc_placed")
     else:
+        mean = std = None
+        if stats_out is not None:
+            mean, std = stats_out
+            _need(init_order is None, "sort_rows_desc(stats_out): identity sequence only")
+            for x in (mean, std):
+                _dev(x, torch.float32, "sort_rows_desc(stats_out)")
+                _need(x.numel() == rows and x.is_contiguous(), f"sort_rows_desc(stats_out): need contiguous tensors of {rows} entries")
         check(lib.fz_sort_rows_desc(_ptr(keys), bits, _ptr(init_order), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk),
-                                    _ptr(rank), _ptr(ws), wsb, _stream(keys)), "fz_sort_rows_desc")
+                                    _ptr(rank), _ptr(mean), _ptr(std), _ptr(ws), wsb, _stream(keys)), "fz_sort_rows_desc")
     return order, sk, rank
 
 
@@ -310,10 +320,13 @@ def minmax_from_order(scores: torch.Tensor, order: torch.Tensor, lens: torch.Ten
 
 def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None, weights, norm: str,
              distr: list[torch.Tensor] | None = None, out: torch.Tensor | None = None,
-             orders: list[torch.Tensor] | None = None, lens: torch.Tensor | None = None) -> torch.Tensor:
+             orders: list[torch.Tensor] | None = None, lens: torch.Tensor | None = None,
+             stats: tuple[torch.Tensor, torch.Tensor] | None = None) -> torch.Tensor:
     """normalise -> weight -> sum in one HBM pass (hybrid.py:212-214,254-280,291,301-304).
     orders (+ lens [S, Q]): the systems' order planes, when they are ranked -- min-max then takes every list's minimum and
-    maximum from its two ends and the fusion is one flat streaming pass (same bits as the reducing kernel)."""
+    maximum from its two ends and the fusion is one flat streaming pass (same bits as the reducing kernel).
+    stats = (a, b): the row statistics [S*Q] fp32 each (min / max, or mean / unbiased std), when the caller has them -- e.g. from
+    the sort that ranked the systems (sort_rows_desc(stats_out=...)): the fusion is then one flat streaming pass."""
     for p in planes:
         _dev(p, torch.float32, "fuse_nsf(planes)")
     S = len(planes)
@@ -343,6 +356,14 @@ def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None
         dptr = _ptr_array(distr)
         P = (C.c_int32 * S)(*[int(d.numel()) for d in distr])
     lib = _lib.lib()
+    if stats is not None and norm in ("min-max", "z-score") and Q > 0 and N > 0:
+        sa, sb = stats
+        for x in (sa, sb):
+            _dev(x, torch.float32, "fuse_nsf(stats)")
+            _need(x.numel() == S * Q and x.is_contiguous(), f"fuse_nsf(stats): need contiguous tensors of {S * Q} entries")
+        check(lib.fz_fuse_nsf_stats_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm],
+                                        dptr, P, _ptr(sa), _ptr(sb), _ptr(fused), _stream(planes[0])), "fz_fuse_nsf_stats_f32")
+        return fused
     if norm == "min-max" and orders is not None and Q > 0 and N > 0:
         _need(len(orders) == S, f"fuse_nsf: {S} planes but {len(orders)} order planes")
         if lens is not None:

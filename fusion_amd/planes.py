@@ -27,6 +27,7 @@ class RankedSystem:
     scores64: torch.Tensor | None = None   # [Q, N] float64 plane when the raw scores are not float32 values (BM25's Python
                                            # floats, host lists): the 'none' passthrough keeps them unrounded (hybrid.py:280)
     score_sorted: bool = False    # every list is in descending order of its float32 scores (rankers: yes; host lists: checked)
+    zstats: tuple | None = None   # (mean [Q], unbiased std [Q]) fp32 of the FULL rows, a by-product of the ranking sort (z-score)
 
     @property
     def Q(self) -> int:

@@ -54,8 +54,9 @@ def _device():
 
 def _rank_scores(scores: torch.Tensor, ids: np.ndarray, return_topk: int | None) -> RankedSystem:
     """Full ranking of a [Q, N] score plane: what util.semantic_search(top_k=N) + sorted() produce (hybrid.py:103)."""
-    order, sk, rank = ops.sort_rows_desc(scores, want_rank=True)
     Q, N = scores.shape
+    zstats = (torch.empty(Q, dtype=torch.float32, device=scores.device), torch.empty(Q, dtype=torch.float32, device=scores.device))
+    order, sk, rank = ops.sort_rows_desc(scores, want_rank=True, stats_out=zstats)   # the sort has the row in registers: mean / std for free
     k = N if return_topk is None else min(return_topk, N)
     lens = torch.full((Q,), k, dtype=torch.int32, device=scores.device)
     full = k == N
@@ -63,7 +64,8 @@ def _rank_scores(scores: torch.Tensor, ids: np.ndarray, return_topk: int | None)
         rank = torch.where(rank < k, rank, torch.full_like(rank, -1))
         order = order.clone()
         order[:, k:] = -1
-    return RankedSystem(scores=scores, order=order, rank=rank, lens=lens, ids=ids, sorted_scores=sk, full=full, score_sorted=True)
+    return RankedSystem(scores=scores, order=order, rank=rank, lens=lens, ids=ids, sorted_scores=sk, full=full, score_sorted=True,
+                        zstats=zstats if full else None)   # a truncated list's statistics are over its k entries only
 
 
 class Ranker:
@@ -201,6 +203,10 @@ class Aggregator:
                 if any(wide):   # transform every system in float32 (weight 1: fl32(t * 1) == t), then weight + sum as NumPy does
                     T = [ops.fuse_nsf([s.scores], None if s.full else [s.rank], [1.0], normalization, None if distr is None else [distr[i]]) for i, s in enumerate(S)]
                     fused = ops.fuse_wsum(T, ranks, w, narrow=[not x for x in wide])
+                elif normalization == "z-score" and all_full and all(s.zstats is not None for s in S):
+                    # ranked systems bring their row statistics along (by-product of the ranking sort): one flat pass
+                    fused = ops.fuse_nsf([s.scores for s in S], None, w, normalization,
+                                         stats=(torch.cat([s.zstats[0] for s in S]), torch.cat([s.zstats[1] for s in S])))
                 elif normalization == "min-max" and all(s.score_sorted for s in S):
                     # score-sorted lists: min / max are the two ends of every list, no row reduction
                     fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, orders=[s.order for s in S],

@@ -93,9 +93,12 @@ int fz_sort_max_n_f64(void);
  * fp64 keys are sorted by their high word (4 radix passes) and repaired in place where equal high words hide a low-word
  * inversion; a row with such a run longer than 17 keys is flagged in the workspace and redone by a generic 8-pass launch. */
 size_t fz_sort_workspace_bytes(int key_bits, int rows, int n);
+/* row_mean / row_std (both or neither, [rows] fp32, nullable): the mean and the UNBIASED standard deviation of each row's
+ * values as float32 (fp64 keys rounded first) -- torch.mean / torch.std of hybrid.py:261-262, a by-product of having the
+ * row in registers: with them z-score fusion of ranked systems is one flat pass (fz_fuse_nsf_stats_f32). */
 int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows, int n,
-                      int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* workspace, size_t workspace_bytes,
-                      void* stream);
+                      int ld, int32_t* order, void* sorted_keys, int32_t* rank, float* row_mean, float* row_std,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same sort, incoming sequence given the other way round: init_rank[row][j] = position of column j in the incoming
  * sequence (-1 = not in it); restricted to the columns in the sequence it is a bijection onto [0, row_len[row]).

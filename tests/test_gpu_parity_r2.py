@@ -294,3 +294,46 @@ def test_sort_f64_equal_high_word_runs(ops, oracle, n, mode):
     np.testing.assert_array_equal(order.cpu().numpy(), e_order)
     np.testing.assert_array_equal(rank.cpu().numpy(), e_rank)
     np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)
+
+
+# ---- z-score statistics as a by-product of the ranking sort -----------------------------------------------------------
+@pytest.mark.parametrize("Q,N", [(3, 1), (4, 2), (5, 300), (3, 27942)])
+def test_sort_row_stats_feed_zscore_fusion(ops, oracle, Q, N):
+    """sort_rows_desc(stats_out=...) == torch.mean / torch.std of the float32 rows (hybrid.py:261-262), and the z-score fusion
+    that uses them (ranked systems: one flat pass) == the oracle's fusion within the z-score tolerance (2e-6)."""
+    from fusion_amd.retrievers.hybrid import Aggregator, _rank_scores
+    rng = np.random.default_rng(Q * 1000 + N)
+    p32 = rng.normal(2.0, 3.0, (Q, N)).astype(np.float32)
+    p64 = np.maximum(0.0, rng.gamma(0.5, 4.0, (Q, N)) - 2.0)                      # BM25-like float64 scores, many exact zeros
+    if N >= 300:
+        p32[1, :] = 0.125                                                           # a constant row: std == 0 -> zeros (hybrid.py:263)
+    ids = np.arange(10, 10 + N)
+    a = _rank_scores(dev(p32), ids, None)
+    from fusion_amd.planes import RankedSystem
+    sc64 = ops.alloc_plane(Q, N, torch.float64, "cuda"); sc64.copy_(torch.from_numpy(p64))
+    zs = (torch.empty(Q, device="cuda"), torch.empty(Q, device="cuda"))
+    od, sk, rk = ops.sort_rows_desc(sc64, want_rank=True, stats_out=zs)
+    b = RankedSystem(scores=ops.f64_to_f32(sc64), order=od, rank=rk, lens=torch.full((Q,), N, dtype=torch.int32, device="cuda"), ids=ids,
+                     sorted_scores=sk, full=True, scores64=sc64, score_sorted=True, zstats=zs)
+    for rs, plane_np in ((a, p32), (b, p64.astype(np.float32))):
+        e_mean, e_std = oracle.row_stats(plane_np, None, "z-score")
+        g_mean, g_std = rs.zstats[0].cpu().numpy(), rs.zstats[1].cpu().numpy()
+        if N > 1:
+            assert np.max(np.abs(g_mean - e_mean) / np.maximum(1.0, np.abs(e_mean))) <= 2e-7
+            assert np.max(np.abs(g_std - e_std) / np.maximum(1e-30, np.abs(e_std)), initial=0.0, where=e_std > 0) <= 2e-7
+            assert np.array_equal(g_std == 0, e_std == 0)
+        else:
+            assert np.all(np.isnan(g_std)) and np.all(np.isnan(e_std))             # torch.std of one element
+    w = {"x": 0.4, "y": 0.6}
+    fused = Aggregator.fuse_device({"x": a, "y": b}, "nsf", "z-score", w, {})
+    exp = oracle.fuse_nsf([p32, p64.astype(np.float32)], None, [0.4, 0.6], "z-score")
+    got = np.empty((Q, N), dtype=np.float32)
+    o, s_ = fused.order.cpu().numpy(), fused.scores.cpu().numpy()
+    for q in range(Q):
+        got[q, o[q]] = s_[q]
+    if N > 1:
+        assert np.max(np.abs(got - exp)) <= 2e-6
+        slow = ops.fuse_nsf([a.scores, b.scores], None, [0.4, 0.6], "z-score").cpu().numpy()   # the reducing row kernel
+        assert np.max(np.abs(got - slow)) <= 1e-6
+    else:
+        assert np.all(np.isnan(got)) and np.all(np.isnan(exp))

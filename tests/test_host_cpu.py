@@ -31,9 +31,9 @@ def test_abi_argument_validation_without_gpu():
     """Argument errors are reported before any HIP call, so they are checkable on a CPU-only box."""
     from fusion_amd import _lib
     L = _lib.lib()
-    assert L.fz_sort_rows_desc(None, 32, None, None, 1, 1, 1, None, None, None, None, 0, None) == _lib.FZ_ERR_ARG
-    assert L.fz_sort_rows_desc(None, 32, None, None, 0, 5, 8, None, None, None, None, 0, None) == _lib.FZ_OK      # empty batch: nothing to do
-    assert L.fz_sort_rows_desc(None, 16, None, None, 1, 1, 1, None, None, None, None, 0, None) == _lib.FZ_ERR_ARG
+    assert L.fz_sort_rows_desc(None, 32, None, None, 1, 1, 1, None, None, None, None, None, None, 0, None) == _lib.FZ_ERR_ARG
+    assert L.fz_sort_rows_desc(None, 32, None, None, 0, 5, 8, None, None, None, None, None, None, 0, None) == _lib.FZ_OK      # empty batch: nothing to do
+    assert L.fz_sort_rows_desc(None, 16, None, None, 1, 1, 1, None, None, None, None, None, None, 0, None) == _lib.FZ_ERR_ARG
     assert L.fz_fuse_rank_f64(None, None, 2, 1, 1, 1, 0, None, None) == _lib.FZ_ERR_ARG
     assert L.fz_dot_scores_f32(None, 4, None, 4, 1, 1, 4, None, 1, None) == _lib.FZ_ERR_ARG
     assert L.fz_topk_workspace_bytes(4, 100000, 1000) > 0 and L.fz_topk_workspace_bytes(4, 1000, 10) <= 256

@@ -15,7 +15,7 @@ print("bm25 sort ms", round(ms, 4))
 lib = _lib.lib()
 order = torch.empty((Q, B.stride(0)), dtype=torch.int32, device="cuda"); rank = torch.empty_like(order)
 ws = torch.full((Q,), -7, dtype=torch.int32, device="cuda")
-rc = lib.fz_sort_rows_desc(ops._ptr(B), 64, None, None, Q, N, B.stride(0), ops._ptr(order), None, ops._ptr(rank), ops._ptr(ws), Q * 4, ops._stream(B))
+rc = lib.fz_sort_rows_desc(ops._ptr(B), 64, None, None, Q, N, B.stride(0), ops._ptr(order), None, ops._ptr(rank), None, None, ops._ptr(ws), Q * 4, ops._stream(B))
 torch.cuda.synchronize()
 f = ws.cpu().numpy(); print("rc", rc, "flag values", np.unique(f, return_counts=True))
 h = B.cpu().numpy()
