@@ -418,8 +418,12 @@ def measure_configs(dev, N=27942):
                  for p in planes]
         # algorithmic bytes: S score planes + the ONE rank plane that carries validity in, fused plane out
         work = (4 + 1 + 1) * Q * N * 4
+        orders = [s.order for s in systems.values()]
+        lens4 = torch.stack([s.lens for s in systems.values()]).contiguous()
         for norm in ("min-max", "z-score", "percentile-rank"):
-            ms = timeit_ms(lambda: ops.fuse_nsf(planes, ranks, w, norm, distr if norm == "percentile-rank" else None, out=fused), n=10)
+            # called the way Aggregator.fuse_device calls it: min-max of score-sorted lists takes the statistics from the list ends
+            kw = dict(orders=orders, lens=lens4) if norm == "min-max" else {}
+            ms = timeit_ms(lambda: ops.fuse_nsf(planes, ranks, w, norm, distr if norm == "percentile-rank" else None, out=fused, **kw), n=10)
             out.append(dict(config=f"4: nsf {norm} fusion, S=4, colbert 40% absent", shape=dict(Q=Q, N=N, S=4),
                             **roof("fuse_nsf kernels", ms, work, "hbm")))
         ms = timeit_ms(lambda: Aggregator.fuse_device(systems, "nsf", "min-max", dict(zip(names, w)), {}), n=5)
