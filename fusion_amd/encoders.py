@@ -87,7 +87,7 @@ class _Base(nn.Module):
             yield idx, ids.to(self._device, non_blocking=True), mask.to(self._device, non_blocking=True)
 
 
-def _token_batches(base, sentences, max_len, batch_size):
+def _token_batches(base, sentences, max_len, batch_size, tokenize=None):
     """Sub-batches for the padding-free forward, longest sentences first (as SentenceTransformer.encode sorts), cut by an
     estimate of the TOKEN count (activations stay under ~1 GB) rather than by sentence count.
     Yields (indices into `sentences`, ids [b, L] on the HOST, lengths [b] numpy)."""
@@ -96,7 +96,7 @@ def _token_batches(base, sentences, max_len, batch_size):
     while s < len(order):
         step = max(batch_size, base.packed_tokens // min(max_len, 8 + 2 * len(sentences[order[s]].split())))
         idx = order[s: s + step]
-        ids, mask = base.tokenizer([sentences[i] for i in idx], max_len)
+        ids, mask = (tokenize or base.tokenizer)([sentences[i] for i in idx], max_len)
         yield idx, ids, mask.sum(1).numpy()
         s += step
 
@@ -365,15 +365,39 @@ class SpladeEncoder(_Base):
 
 
 class ColbertEncoder(_Base):
-    """ColBERT: CamemBERT -> Linear(768,128, bias=False) -> L2-normalised token vectors (fp16)."""
+    """ColBERT: CamemBERT -> Linear(768,128, bias=False) -> L2-normalised token vectors (fp16).
+
+    Tokenisation follows colbert-ai (requirements.txt:15, absent from the tree; its published QueryTokenizer / DocTokenizer):
+    the text is prefixed with ". " and the token after <s> is then overwritten with the [Q] / [D] marker id
+    (`tokenizer.convert_tokens_to_ids("[unused0]" / "[unused1]")`: the unknown-token id in a CamemBERT vocabulary); queries are
+    padded to query_maxlen with the mask token and -- `--attend_to_mask_tokens`, run_colbert.sh:29 -- attended; document tokens
+    whose id is in the punctuation skiplist are dropped (`--mask_punctuation`, run_colbert.sh:28).  `q_marker_id` /
+    `d_marker_id` None (synthetic HashTokenizer runs): no marker, no prefix."""
     dim = 128
 
-    def __init__(self, backbone, tokenizer, device, punct_ids: tuple[int, ...] = ()):
+    def __init__(self, backbone, tokenizer, device, punct_ids: tuple[int, ...] = (), linear_weight: torch.Tensor | None = None,
+                 q_marker_id: int | None = None, d_marker_id: int | None = None, attend_to_mask_tokens: bool = True):
         super().__init__(tokenizer, device)
         self.backbone = backbone.to(self._device).eval()
+        if linear_weight is not None:
+            self.dim = int(linear_weight.shape[0])
         self.linear = nn.Linear(backbone.config.hidden_size, self.dim, bias=False).to(self._device)
+        if linear_weight is not None:     # the checkpoint's projection (colbert-ai saves it as `linear.weight`)
+            if tuple(linear_weight.shape) != (self.dim, backbone.config.hidden_size):
+                raise ValueError(f"ColBERT projection {tuple(linear_weight.shape)} does not fit hidden size {backbone.config.hidden_size}")
+            with torch.no_grad():
+                self.linear.weight.copy_(linear_weight.to(self._device, torch.float32))
         self._clamp_lengths(backbone.config)
         self.punct_ids = torch.tensor(list(punct_ids), dtype=torch.long, device=self._device)
+        self.q_marker_id, self.d_marker_id, self.attend_to_mask_tokens = q_marker_id, d_marker_id, attend_to_mask_tokens
+
+    def _marked(self, texts: list[str], max_len: int, marker_id: int | None, pad_to_max: bool):
+        """colbert-ai tensorize(): '. ' + text, tokenise, ids[:, 1] = marker."""
+        if marker_id is None:
+            return self.tokenizer(texts, max_len, pad_to_max)
+        ids, mask = self.tokenizer([". " + t for t in texts], max_len, pad_to_max)
+        ids[:, 1] = marker_id
+        return ids, mask
 
     @torch.no_grad()
     def _tokens(self, ids, mask):
@@ -383,24 +407,24 @@ class ColbertEncoder(_Base):
 
     @torch.no_grad()
     def encode_queries(self, queries: list[str], batch_size: int = 64) -> torch.Tensor:
-        """-> [Q, 64, 128] fp16; pads with the mask token and attends to it (run_colbert.sh:29)."""
-        out = torch.empty((len(queries), self.max_query_length, self.dim), dtype=torch.float16, device=self._device)
-        fwd = self._packed_forward(self.backbone)
-        if fwd is not None:
-            import numpy as np
-            from . import ops
-            Lq = self.max_query_length
-            for s in range(0, len(queries), max(batch_size, self.packed_tokens // Lq)):
-                part = queries[s: s + max(batch_size, self.packed_tokens // Lq)]
-                ids, mask = self.tokenizer(part, Lq, True)
-                ids = torch.where(mask.bool(), ids, torch.full_like(ids, self.tokenizer.mask_token_id)).to(self._device, non_blocking=True)
-                x, _ = fwd.hidden(ids, np.full(len(part), Lq))       # every query is Lq tokens long: [MASK] padding is attended
-                out[s: s + len(part)] = ops.normalize_rows(self.linear(x)).view(len(part), Lq, self.dim).half()
-            return out
-        for idx, ids, mask in self._batches(queries, batch_size, self.max_query_length, pad_to_max=True):
-            ids = torch.where(mask.bool(), ids, torch.full_like(ids, self.tokenizer.mask_token_id))
-            v = self._tokens(ids, torch.ones_like(mask))
-            out[torch.tensor(idx, device=self._device)] = v.half()
+        """-> [Q, query_maxlen, dim] fp16; pads with the mask token and attends to it (run_colbert.sh:29)."""
+        import numpy as np
+        from . import ops
+        Lq = self.max_query_length
+        out = torch.empty((len(queries), Lq, self.dim), dtype=torch.float16, device=self._device)
+        fwd = self._packed_forward(self.backbone) if self.attend_to_mask_tokens else None   # every query is Lq attended tokens: already "packed"
+        step = batch_size if fwd is None else max(batch_size, self.packed_tokens // Lq)
+        for s0 in range(0, len(queries), step):
+            part = queries[s0: s0 + step]
+            ids, mask = self._marked(part, Lq, self.q_marker_id, True)
+            ids = torch.where(mask.bool(), ids, torch.full_like(ids, self.tokenizer.mask_token_id)).to(self._device, non_blocking=True)
+            if fwd is not None:
+                x, _ = fwd.hidden(ids, np.full(len(part), Lq))
+                out[s0: s0 + len(part)] = ops.normalize_rows(self.linear(x)).view(len(part), Lq, self.dim).half()
+            else:
+                # colbert-ai multiplies Q by (ids != pad), all ones once the padding is the mask token: every row is kept
+                att = torch.ones_like(ids) if self.attend_to_mask_tokens else mask.to(self._device)
+                out[s0: s0 + len(part)] = self._tokens(ids, att).half()
         return out
 
     @torch.no_grad()
@@ -410,7 +434,11 @@ class ColbertEncoder(_Base):
         if fwd is not None:
             return self._encode_docs_packed(fwd, docs, batch_size)
         per_doc: list[torch.Tensor | None] = [None] * len(docs)
-        for idx, ids, mask in self._batches(docs, batch_size, self.max_doc_length):
+        order = sorted(range(len(docs)), key=lambda i: -len(docs[i]))
+        for s0 in range(0, len(order), batch_size):
+            idx = order[s0: s0 + batch_size]
+            ids, mask = self._marked([docs[i] for i in idx], self.max_doc_length, self.d_marker_id, False)
+            ids, mask = ids.to(self._device), mask.to(self._device)
             v = self._tokens(ids, mask).half()
             keep = mask.bool()
             if self.punct_ids.numel():
@@ -433,7 +461,8 @@ class ColbertEncoder(_Base):
         punct = self.punct_ids.cpu().numpy()
         chunks, counts, place = [], np.zeros(len(docs), dtype=np.int64), []
         base = 0
-        for idx, ids, lens in _token_batches(self, docs, self.max_doc_length, batch_size):
+        for idx, ids, lens in _token_batches(self, docs, self.max_doc_length, batch_size,
+                                             tokenize=lambda texts, L: self._marked(texts, L, self.d_marker_id, False)):
             x, _ = fwd.hidden(ids.to(self._device, non_blocking=True), lens)
             v = ops.normalize_rows(self.linear(x)).half()                               # [T, 128], rows in sub-batch order
             ids_np = ids.numpy()
@@ -475,9 +504,26 @@ def random_init(kind: str, device="cuda", size: str = "base", seed: int = 0):
         torch.random.set_rng_state(g)
 
 
+def _checkpoint_tensor(model_name_or_path: str, name: str) -> torch.Tensor | None:
+    """One tensor of a local checkpoint directory (model.safetensors or pytorch_model.bin), None when it is not there."""
+    st = os.path.join(model_name_or_path, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors import safe_open
+        with safe_open(st, framework="pt", device="cpu") as f:
+            return f.get_tensor(name) if name in f.keys() else None
+    pt = os.path.join(model_name_or_path, "pytorch_model.bin")
+    if os.path.exists(pt):
+        return torch.load(pt, map_location="cpu", weights_only=True).get(name)
+    return None
+
+
 def from_pretrained(model_name_or_path: str, kind: str, device="cuda"):
-    """Load a real checkpoint from a local directory / HF cache (no network on the build boxes)."""
-    from transformers import AutoModel, AutoModelForMaskedLM, AutoTokenizer
+    """Load a real checkpoint from a local directory / HF cache (no network on the build boxes).
+    kind: 'dpr' (AutoModel + mean pooling), 'splade' (AutoModelForMaskedLM), 'colbert' (colbert-ai layout: base model +
+    `linear.weight` + artifact.metadata), 'monobert' (AutoModelForSequenceClassification, hybrid.py:139-163)."""
+    import json
+    import string
+    from transformers import AutoModel, AutoModelForMaskedLM, AutoModelForSequenceClassification, AutoTokenizer
     hf_tok = AutoTokenizer.from_pretrained(model_name_or_path, local_files_only=True)
 
     class _Tok:
@@ -486,13 +532,48 @@ def from_pretrained(model_name_or_path: str, kind: str, device="cuda"):
         def __call__(self, texts, max_length, pad_to_max=False):
             e = hf_tok(texts, padding="max_length" if pad_to_max else True, truncation=True, max_length=max_length, return_tensors="pt")
             return e["input_ids"], e["attention_mask"]
+
+        def encode_pairs(self, first, second, max_length):   # "<s> query </s></s> document </s>", truncation as CrossEncoder.smart_batching_collate
+            e = hf_tok(first, second, padding=True, truncation="longest_first", max_length=max_length, return_tensors="pt")
+            return e["input_ids"], e["attention_mask"]
     if kind == "dpr":
         return DenseEncoder(AutoModel.from_pretrained(model_name_or_path, local_files_only=True), _Tok(), device)
     if kind == "splade":
         return SpladeEncoder(AutoModelForMaskedLM.from_pretrained(model_name_or_path, local_files_only=True), _Tok(), device)
     if kind == "colbert":
-        enc = ColbertEncoder(AutoModel.from_pretrained(model_name_or_path, local_files_only=True), _Tok(), device)
+        meta = {}
+        mp = os.path.join(model_name_or_path, "artifact.metadata")       # colbert-ai's ColBERTConfig dump
+        if os.path.exists(mp):
+            with open(mp) as f:
+                meta = json.load(f)
+        lin = _checkpoint_tensor(model_name_or_path, "linear.weight")
+        if lin is None:
+            raise FileNotFoundError(f"{model_name_or_path}: no `linear.weight` -- not a ColBERT checkpoint (colbert-ai saves the 768 -> dim "
+                                    "projection under that name next to the base model)")
+        punct = ()
+        if meta.get("mask_punctuation", True):                            # run_colbert.sh:28; colbert-ai's skiplist: first sub-token of each symbol
+            punct = tuple(sorted({hf_tok.encode(sym, add_special_tokens=False)[0] for sym in string.punctuation
+                                  if hf_tok.encode(sym, add_special_tokens=False)}))
+        enc = ColbertEncoder(AutoModel.from_pretrained(model_name_or_path, local_files_only=True), _Tok(), device, punct_ids=punct,
+                             linear_weight=lin,
+                             q_marker_id=hf_tok.convert_tokens_to_ids(meta.get("query_token_id", "[unused0]")),
+                             d_marker_id=hf_tok.convert_tokens_to_ids(meta.get("doc_token_id", "[unused1]")),
+                             attend_to_mask_tokens=bool(meta.get("attend_to_mask_tokens", True)))
+        enc.max_query_length = min(enc.max_query_length, int(meta.get("query_maxlen", enc.max_query_length)))   # hybrid.py:129 passes 64 / 512
+        enc.max_doc_length = min(enc.max_doc_length, int(meta.get("doc_maxlen", enc.max_doc_length)))
         return enc
+    if kind == "monobert":
+        model = AutoModelForSequenceClassification.from_pretrained(model_name_or_path, local_files_only=True)
+        act = getattr(model.config, "sbert_ce_default_activation_function", None)   # CrossEncoderCustom.__init__ (sentence_transformers.py:546-551)
+        if act is None:
+            act = "sigmoid" if model.config.num_labels == 1 else "identity"
+        elif "Sigmoid" in act:
+            act = "sigmoid"
+        elif "Identity" in act:
+            act = "identity"
+        else:
+            raise ValueError(f"cross-encoder activation {act!r} is not supported")
+        return CrossEncoder(model, _Tok(), device, activation=act)
     raise ValueError(kind)
 
 
@@ -500,28 +581,44 @@ class CrossEncoder(_Base):
     """monoBERT reranker (hybrid.py:139-163, CrossEncoderCustom): CamemBERT sequence classifier over "<s> query </s></s> doc </s>",
     one logit per pair, fp32.  `predict(pairs)` is what Ranker.cross_encoder_search calls."""
 
-    def __init__(self, classifier, tokenizer, device, max_length: int = 512):
+    def __init__(self, classifier, tokenizer, device, max_length: int = 512, activation: str = "identity"):
         super().__init__(tokenizer, device)
         self.model = classifier.to(self._device).eval()
         self._clamp_lengths(classifier.config)
         self.max_length = min(max_length, self.max_doc_length)
+        self.activation = activation     # CrossEncoder.predict applies the default activation: Sigmoid for one label (ST 2.2.2)
+
+    def _pair_ids(self, pairs, max_len):
+        """(query, document) pairs -> ids, mask.  A real tokenizer encodes the PAIR ("<s> q </s></s> d </s>", longest-first
+        truncation); the synthetic HashTokenizer has no pair API: the separator is an ordinary token there."""
+        if hasattr(self.tokenizer, "encode_pairs"):
+            return self.tokenizer.encode_pairs([q for q, _ in pairs], [d for _, d in pairs], max_len)
+        return self.tokenizer([q + " </s> " + d for q, d in pairs], max_len)
 
     @torch.no_grad()
     def predict(self, pairs: list[tuple[str, str]], batch_size: int = 64) -> torch.Tensor:
         out = torch.empty(len(pairs), dtype=torch.float32, device=self._device)
-        texts = [q + " </s> " + d for q, d in pairs]    # HashTokenizer has no pair API: the separator is an ordinary token
+        texts = [q + " " + d for q, d in pairs]          # only for the length-sorted batching
         base = getattr(self.model, self.model.base_model_prefix)
         fwd = self._packed_forward(base) if hasattr(self.model, "classifier") else None
-        if fwd is not None:
-            # padding-free forward; the classification head reads the first token (<s>) of every pair: features[:, 0, :]
-            for idx, ids, lens in _token_batches(self, texts, self.max_length, batch_size):
-                x, cu_d = fwd.hidden(ids.to(self._device, non_blocking=True), lens)
+        order = sorted(range(len(pairs)), key=lambda i: -len(texts[i]))
+        s0 = 0
+        while s0 < len(order):
+            step = batch_size if fwd is None else max(batch_size, self.packed_tokens // min(self.max_length, 8 + 2 * len(texts[order[s0]].split())))
+            idx = order[s0: s0 + step]
+            s0 += step
+            ids, mask = self._pair_ids([pairs[i] for i in idx], self.max_length)
+            if fwd is not None:
+                # padding-free forward; the classification head reads the first token (<s>) of every pair: features[:, 0, :]
+                x, cu_d = fwd.hidden(ids.to(self._device, non_blocking=True), mask.sum(1).numpy())
                 first = x.index_select(0, cu_d[:-1].long())
-                out[torch.tensor(idx, device=self._device)] = self.model.classifier(first.unsqueeze(1)).reshape(-1).float()
-            return out
-        for idx, ids, mask in self._batches(texts, batch_size, self.max_length):
-            logits = self.model(input_ids=ids, attention_mask=mask).logits
-            out[torch.tensor(idx, device=self._device)] = logits[:, 0].float()
+                logits = self.model.classifier(first.unsqueeze(1)).reshape(len(idx), -1)
+            else:
+                logits = self.model(input_ids=ids.to(self._device), attention_mask=mask.to(self._device)).logits
+            if logits.shape[1] != 1:
+                raise ValueError(f"cross-encoder with {logits.shape[1]} labels: the rerank stage expects one relevance logit (hybrid.py:159)")
+            score = logits[:, 0].float()                     # one label: score[0] (CrossEncoder.predict)
+            out[torch.tensor(idx, device=self._device)] = torch.sigmoid(score) if self.activation == "sigmoid" else score
         return out
 
 

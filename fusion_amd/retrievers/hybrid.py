@@ -143,10 +143,12 @@ class Ranker:
         """monoBERT rerank (hybrid.py:139-163).  The reference's version is dead code (`docs` undefined at :159, and main passes
         fused lists where it expects dicts, :462).  Working form: `candidates[i]` is a dict id->text, or -- as main
         passes it -- a fused ranked list of {'corpus_id', 'score'} together with `corpus` to look the texts up.
-        `model` = fusion_amd.encoders.CrossEncoder (PyTorch-ROCm forward); ties keep the candidate order (stable sort)."""
+        `model` (optional) = an already-built fusion_amd.encoders.CrossEncoder (PyTorch-ROCm forward), else the checkpoint at
+        `model_name_or_path` is loaded; ties keep the candidate order (stable sort)."""
         from .. import encoders
-        if model is None:
-            raise NotImplementedError(f"no cross-encoder checkpoint for {model_name_or_path!r} offline: pass model=encoders.CrossEncoder(...)")
+        own = model is None
+        if own:   # CrossEncoderCustom(model_name_or_path), hybrid.py:151: a local checkpoint directory / HF cache entry (no network here)
+            model = encoders.from_pretrained(model_name_or_path, "monobert", device=_device())
         ranked_lists = []
         for query, cands in zip(queries, candidates):
             if isinstance(cands, dict):
@@ -157,6 +159,9 @@ class Ranker:
             scores = model.predict([(query, d) for d in docs]).cpu().tolist() if docs else []
             order = sorted(range(len(docs)), key=lambda i: scores[i], reverse=True)[: return_topk or len(docs)]
             ranked_lists.append([{"corpus_id": cids[i], "score": scores[i]} for i in order])
+        if own:
+            del model
+            torch.cuda.empty_cache()
         return ranked_lists
 
 

@@ -337,3 +337,34 @@ def test_sort_row_stats_feed_zscore_fusion(ops, oracle, Q, N):
         assert np.max(np.abs(got - slow)) <= 1e-6
     else:
         assert np.all(np.isnan(got)) and np.all(np.isnan(exp))
+
+
+# ---- real-checkpoint loaders on the device: the padding-free HIP forward against the plain HF path -----------------------
+def test_checkpoint_loaders_packed_path_matches_plain_path(tmp_path):
+    """from_pretrained('colbert' / 'monobert') with 64-wide heads takes the padding-free forward (HIP attention / LayerNorm /
+    GELU kernels) on the GPU: same token vectors / relevance scores as the plain HF path on the CPU (test_checkpoints_cpu.py
+    pins that one on the colbert-ai / CrossEncoder formulas)."""
+    from checkpoint_utils import write_colbert_checkpoint, write_monobert_checkpoint
+    from fusion_amd import encoders
+    from fusion_amd.retrievers.hybrid import Ranker
+    queries = ["le juge peut , un bail ?", "la loi", "article de le code civil ( droit ) chat chien"]
+    docs = ["le chat est un chien .", "article : le bail , la loi ; le code civil !", "droit"]
+    write_colbert_checkpoint(str(tmp_path / "colbert"), heads=2, hidden=128)        # head_dim 64: PackedBertForward applies
+    cpu = encoders.from_pretrained(str(tmp_path / "colbert"), "colbert", device="cpu")
+    gpu = encoders.from_pretrained(str(tmp_path / "colbert"), "colbert", device="cuda")
+    assert gpu._packed_forward(gpu.backbone) is not None
+    assert torch.max(torch.abs(gpu.encode_queries(queries).float().cpu() - cpu.encode_queries(queries).float())).item() <= 2e-3
+    (tg, og), (tc, oc) = gpu.encode_docs(docs), cpu.encode_docs(docs)
+    assert og.cpu().tolist() == oc.tolist()
+    assert torch.max(torch.abs(tg.float().cpu() - tc.float())).item() <= 2e-3
+    write_monobert_checkpoint(str(tmp_path / "mono"), heads=2, hidden=128)
+    pairs = [(q, d) for q in queries for d in docs]
+    ce_cpu = encoders.from_pretrained(str(tmp_path / "mono"), "monobert", device="cpu")
+    ce_gpu = encoders.from_pretrained(str(tmp_path / "mono"), "monobert", device="cuda")
+    assert torch.max(torch.abs(ce_gpu.predict(pairs).cpu() - ce_cpu.predict(pairs))).item() <= 1e-5
+    # Ranker.cross_encoder_search builds the loader itself when no model is injected (hybrid.py:151)
+    cands = [{10: docs[0], 11: docs[1], 12: docs[2]}] * len(queries)
+    got = Ranker.cross_encoder_search(queries, cands, str(tmp_path / "mono"))
+    exp = ce_cpu.predict(pairs).view(len(queries), len(docs))
+    for q, lst in enumerate(got):
+        assert [x["corpus_id"] for x in lst] == [10 + int(i) for i in torch.argsort(exp[q], descending=True, stable=True)]
