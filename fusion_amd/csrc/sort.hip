@@ -719,6 +719,94 @@ __global__ __launch_bounds__(1024) void topk_filter_kernel(FilterArgs a) {
     if (over) atomicExch(a.overflow, 1);
 }
 
+
+// ---- rows longer than one workgroup holds (the drop-in path must not stop at 28,672 documents) -------------
+// chunk-sort (the kernel above, one workgroup per chunk of the SEQUENCE) + cross-chunk ranking: an element's final
+// position = its position in its own sorted chunk + for every other chunk the number of elements that precede it there
+// (binary search; ties go to the earlier chunk, i.e. to the earlier sequence position: the stable order).  Exact, any n;
+// O(n * chunks * log) work, meant for corpora of 10^5..10^6 documents, not for the LLeQA hot path.
+struct LongArgs {
+    const void* keys; int key_bits; const int32_t* init_order; const int32_t* init_rank; const int32_t* row_len;
+    int rows, n; long ld;
+    void* seq_keys; int32_t* seq_cols;            // [rows][n] the incoming sequence, materialised (gathered / placed input only)
+    const void* ck; const int32_t* cc;            // [rows][n] chunk-sorted keys / columns
+    int chunk_len;
+    int32_t* order; void* sorted_keys; int32_t* rank; long out_ld;
+};
+
+template <typename K>
+__global__ void long_seq_kernel(LongArgs a) {
+    const int row = blockIdx.y;
+    const K* keys = reinterpret_cast<const K*>(a.keys) + (size_t)row * a.ld;
+    K* sk = reinterpret_cast<K*>(a.seq_keys) + (size_t)row * a.n;
+    int32_t* sc = a.seq_cols + (size_t)row * a.n;
+    int m = a.row_len ? a.row_len[row] : a.n;
+    m = m < 0 ? 0 : (m > a.n ? a.n : m);
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < a.n; x += gridDim.x * blockDim.x) {
+        if (a.init_order) {                                   // slot x <- column init_order[x]
+            const int col = x < m ? a.init_order[(size_t)row * a.ld + x] : -1;
+            const bool ok = (unsigned)col < (unsigned)a.n;
+            sk[x] = ok ? keys[col] : (K)(-INFINITY);
+            sc[x] = ok ? col : -1;
+        } else {                                              // column x -> slot init_rank[x]
+            const int r = a.init_rank[(size_t)row * a.ld + x];
+            if ((unsigned)r < (unsigned)m) { sk[r] = keys[x]; sc[r] = x; }
+        }
+    }
+}
+
+template <typename K> struct DescKey;
+template <> struct DescKey<float> { typedef uint32_t T; static __device__ __forceinline__ T of(float v) { return desc_key_f32(v); } };
+template <> struct DescKey<double> { typedef uint64_t T; static __device__ __forceinline__ T of(double v) { return desc_key_f64(v); } };
+
+template <typename K>
+__global__ void long_merge_kernel(LongArgs a) {
+    typedef typename DescKey<K>::T U;
+    const int row = blockIdx.y;
+    int m = a.row_len ? a.row_len[row] : a.n;
+    m = m < 0 ? 0 : (m > a.n ? a.n : m);
+    const K* ck = reinterpret_cast<const K*>(a.ck) + (size_t)row * a.n;
+    const int32_t* cc = a.cc + (size_t)row * a.n;
+    const int CH = a.chunk_len, C = (m + CH - 1) / CH;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < m; x += gridDim.x * blockDim.x) {
+        const int c = x / CH, i = x - c * CH;
+        const K v = ck[x];
+        const U key = DescKey<K>::of(v);
+        int pos = i;
+        for (int c2 = 0; c2 < C; ++c2) {
+            if (c2 == c) continue;
+            const K* base = ck + (size_t)c2 * CH;
+            const int len = (m - c2 * CH) < CH ? (m - c2 * CH) : CH;
+            int lo = 0, hi = len;                              // first index whose key is > key (c2 < c: ties precede) or >= key (c2 > c)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const U k2 = DescKey<K>::of(base[mid]);
+                const bool before = c2 < c ? (k2 <= key) : (k2 < key);
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            pos += lo;
+        }
+        const int col = cc[x];
+        if (a.order) a.order[(size_t)row * a.out_ld + pos] = col;
+        if (a.sorted_keys) {
+            // the key as the short-row kernel writes it back: -0.0 -> +0.0, every NaN -> the canonical quiet NaN
+            K o = v;
+            if (v != v) o = sizeof(K) == 4 ? (K)__uint_as_float(0x7fc00000u) : (K)__longlong_as_double(0x7ff8000000000000ll);
+            else if (v == (K)0) o = (K)0;
+            reinterpret_cast<K*>(a.sorted_keys)[(size_t)row * a.out_ld + pos] = o;
+        }
+        if (a.rank && col >= 0) a.rank[(size_t)row * a.out_ld + col] = pos;
+    }
+}
+
+template <typename K>
+__global__ void long_fill_kernel(K* keys, int32_t* cols, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        keys[i] = (K)(-INFINITY);
+        cols[i] = -1;
+    }
+}
+
 struct SortCfg { int T, E; };
 
 static inline bool pick_cfg(int n, int kw, SortCfg& c) {
@@ -770,10 +858,64 @@ static int launch_sort(const SortArgs& a, int kw, int prows, int n_chunk, hipStr
 
 using namespace fz;
 
-extern "C" int fz_sort_max_n(void) { return 35840; }   // fp32 keys; fp64 keys: 28672
+extern "C" int fz_sort_max_n(void) { return 35840; }   // single-workgroup rows (the fast path), fp32 keys; fp64 keys: 28672.  Longer rows: chunk-sort + merge
 extern "C" int fz_sort_max_n_f64(void) { return 28672; }
 
-extern "C" size_t fz_sort_workspace_bytes(int key_bits, int rows, int n) { (void)n; return key_bits == 64 && rows > 0 ? (size_t)rows * 4 : 0; }
+
+static size_t long_ws_bytes(int key_bits, int rows, int n) {
+    const size_t ksz = key_bits / 8;
+    const int CH = key_bits == 32 ? 35840 : 28672;
+    const size_t C = ((size_t)n + CH - 1) / CH;
+    return (size_t)rows * n * (ksz + 4) * 2 + (size_t)rows * C * 4 + 512;
+}
+
+static int sort_long_rows(const void* keys, int key_bits, const int32_t* init_order, const int32_t* init_rank, const int32_t* row_len,
+                          int rows, int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* workspace,
+                          size_t workspace_bytes, hipStream_t st) {
+    if (!workspace || workspace_bytes < long_ws_bytes(key_bits, rows, n)) return FZ_ERR_WORKSPACE;
+    const size_t ksz = key_bits / 8;
+    const int CH = key_bits == 32 ? 35840 : 28672;
+    const int C = (n + CH - 1) / CH;
+    char* ws = reinterpret_cast<char*>(workspace);
+    void* seq_keys = ws; ws += (size_t)rows * n * ksz;
+    void* ck = ws; ws += (size_t)rows * n * ksz;
+    int32_t* seq_cols = reinterpret_cast<int32_t*>(ws); ws += (size_t)rows * n * 4;
+    int32_t* cc = reinterpret_cast<int32_t*>(ws); ws += (size_t)rows * n * 4;
+    int32_t* flags = reinterpret_cast<int32_t*>(ws);
+    LongArgs L{};
+    L.keys = keys; L.key_bits = key_bits; L.init_order = init_order; L.init_rank = init_rank; L.row_len = row_len;
+    L.rows = rows; L.n = n; L.ld = ld; L.seq_keys = seq_keys; L.seq_cols = seq_cols; L.ck = ck; L.cc = cc; L.chunk_len = CH;
+    L.order = order; L.sorted_keys = sorted_keys; L.rank = rank; L.out_ld = ld;
+    const bool seq = init_order || init_rank;
+    dim3 grid((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), (unsigned)rows);
+    if (seq) {
+        if (init_rank) {   // slots no column claims: (-inf, -1)
+            if (key_bits == 32) long_fill_kernel<float><<<1024, 256, 0, st>>>((float*)seq_keys, seq_cols, (size_t)rows * n);
+            else long_fill_kernel<double><<<1024, 256, 0, st>>>((double*)seq_keys, seq_cols, (size_t)rows * n);
+            FZ_LAUNCH_CHECK();
+        }
+        if (key_bits == 32) long_seq_kernel<float><<<grid, 256, 0, st>>>(L); else long_seq_kernel<double><<<grid, 256, 0, st>>>(L);
+        FZ_LAUNCH_CHECK();
+    }
+    SortArgs a{};
+    a.keys = seq ? seq_keys : keys; a.row_len = row_len;
+    a.n_total = n; a.key_row_stride = seq ? n : ld; a.seg_len = n; a.seg_stride = 0;
+    a.chunks = C; a.chunk_len = CH;
+    a.order = cc; a.sorted_keys = ck; a.out_row_stride = n; a.out_chunk_stride = CH; a.out_limit = CH;
+    a.colmap = seq ? seq_cols : nullptr; a.colmap_row_stride = n;
+    a.row_flags = flags;
+    int rc = launch_sort(a, key_bits / 32, rows * C, CH, st);
+    if (rc != FZ_OK) return rc;
+    if (key_bits == 32) long_merge_kernel<float><<<grid, 256, 0, st>>>(L); else long_merge_kernel<double><<<grid, 256, 0, st>>>(L);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+extern "C" size_t fz_sort_workspace_bytes(int key_bits, int rows, int n) {
+    if (rows <= 0 || n <= 0) return 0;
+    if (n > (key_bits == 32 ? 35840 : 28672)) return long_ws_bytes(key_bits, rows, n);
+    return key_bits == 64 ? (size_t)rows * 4 : 0;
+}
 
 extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows,
                                  int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, float* row_mean, float* row_std,
@@ -781,9 +923,13 @@ extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* 
     if ((key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
     if (rows == 0 || n == 0) return FZ_OK;      // nothing to do (empty tensors carry null pointers)
     if (!keys) return FZ_ERR_ARG;
-    if (n > (key_bits == 32 ? 35840 : 28672)) return FZ_ERR_UNSUPPORTED;
-    SortArgs a{};
     if ((row_mean != nullptr) != (row_std != nullptr)) return FZ_ERR_ARG;
+    if (n > (key_bits == 32 ? 35840 : 28672)) {   // longer than one workgroup's registers: chunk-sort + cross-chunk ranking
+        if (row_mean) return FZ_ERR_UNSUPPORTED;  // the statistics by-product exists for single-workgroup rows only (fz_row_stats_f32 otherwise)
+        return sort_long_rows(keys, key_bits, init_order, nullptr, row_len, rows, n, ld, order, sorted_keys, rank, workspace, workspace_bytes,
+                              as_stream(stream));
+    }
+    SortArgs a{};
     a.keys = keys; a.init_order = init_order; a.row_len = row_len;
     a.n_total = n; a.key_row_stride = ld; a.seg_len = n; a.seg_stride = 0;
     a.chunks = 1; a.chunk_len = n;
@@ -799,7 +945,9 @@ extern "C" int fz_sort_rows_desc_placed(const void* keys, int key_bits, const in
     if ((key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
     if (rows == 0 || n == 0) return FZ_OK;
     if (!keys || !init_rank) return FZ_ERR_ARG;
-    if (n > (key_bits == 32 ? 35840 : 28672)) return FZ_ERR_UNSUPPORTED;
+    if (n > (key_bits == 32 ? 35840 : 28672))
+        return sort_long_rows(keys, key_bits, nullptr, init_rank, row_len, rows, n, ld, order, sorted_keys, rank, workspace, workspace_bytes,
+                              as_stream(stream));
     SortArgs a{};
     a.keys = keys; a.init_rank = init_rank; a.row_len = row_len;
     a.n_total = n; a.key_row_stride = ld; a.seg_len = n; a.seg_stride = 0;

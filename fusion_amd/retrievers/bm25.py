@@ -72,7 +72,9 @@ class BM25:
     def search_device(self, queries: list[str], ids: np.ndarray | None = None) -> RankedSystem:
         sc64 = self.scores(queries)
         Q, N = sc64.shape
-        zstats = (torch.empty(Q, dtype=torch.float32, device=self.device), torch.empty(Q, dtype=torch.float32, device=self.device))
+        zstats = None
+        if N <= ops.sort_max_n(torch.float64):
+            zstats = (torch.empty(Q, dtype=torch.float32, device=self.device), torch.empty(Q, dtype=torch.float32, device=self.device))
         order, sk, rank = ops.sort_rows_desc(sc64, want_rank=True, stats_out=zstats)   # ranks from the float64 scores, ties -> ascending index
         lens = torch.full((Q,), N, dtype=torch.int32, device=self.device)
         # float32 plane for the normalisations (torch.tensor(scores, dtype=float32), hybrid.py:255); the float64 scores stay

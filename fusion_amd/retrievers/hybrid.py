@@ -55,8 +55,10 @@ def _device():
 def _rank_scores(scores: torch.Tensor, ids: np.ndarray, return_topk: int | None) -> RankedSystem:
     """Full ranking of a [Q, N] score plane: what util.semantic_search(top_k=N) + sorted() produce (hybrid.py:103)."""
     Q, N = scores.shape
-    zstats = (torch.empty(Q, dtype=torch.float32, device=scores.device), torch.empty(Q, dtype=torch.float32, device=scores.device))
-    order, sk, rank = ops.sort_rows_desc(scores, want_rank=True, stats_out=zstats)   # the sort has the row in registers: mean / std for free
+    zstats = None
+    if N <= ops.sort_max_n(scores.dtype):   # single-workgroup rows: the sort has the row in registers, mean / std come for free
+        zstats = (torch.empty(Q, dtype=torch.float32, device=scores.device), torch.empty(Q, dtype=torch.float32, device=scores.device))
+    order, sk, rank = ops.sort_rows_desc(scores, want_rank=True, stats_out=zstats)
     k = N if return_topk is None else min(return_topk, N)
     lens = torch.full((Q,), k, dtype=torch.int32, device=scores.device)
     full = k == N

@@ -85,8 +85,9 @@ int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* Doff, int64
  *   order[row][r]       payload (corpus position) at output rank r, r < row_len[row]
  *   sorted_keys[row][r] its key (same type as keys)
  *   rank[row][payload]  = r  (inverse permutation; other entries untouched: pre-fill with -1)
- * Supported n: 1 .. fz_sort_max_n() for fp32 keys, 1 .. fz_sort_max_n_f64() for fp64 keys (a row lives in the registers of
- * one workgroup). */
+ * Any n.  Rows of up to fz_sort_max_n() (fp32 keys) / fz_sort_max_n_f64() (fp64 keys) elements live in the registers of one
+ * workgroup (the fast path: LLeQA's 27,942 articles fit both); longer rows are chunk-sorted and ranked across chunks
+ * (exact and stable as well, O(n * chunks * log n); row_mean / row_std are not produced there). */
 int fz_sort_max_n(void);
 int fz_sort_max_n_f64(void);
 /* workspace: fz_sort_workspace_bytes(key_bits, rows, n) bytes of device memory (0 for fp32 rows that fit one workgroup).

@@ -72,12 +72,38 @@ def test_sort_rows_f64(ops, oracle, n):
     np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)
 
 
-def test_sort_unsupported_n_fails_loudly(ops):
-    from fusion_amd._lib import FusionHipError
-    with pytest.raises(FusionHipError):
-        ops.sort_rows_desc(torch.zeros((2, 40000), device="cuda"))
+def test_sort_has_no_cpu_path(ops):
     with pytest.raises(TypeError):
         ops.sort_rows_desc(torch.zeros((2, 10)))   # CPU tensor: no CPU path
+
+
+@pytest.mark.parametrize("n,dtype", [(35841, np.float32), (28673, np.float64), (60000, np.float64), (100003, np.float32)])
+@pytest.mark.parametrize("mode", ["plain", "gathered", "placed"])
+def test_sort_rows_longer_than_one_workgroup(ops, oracle, n, dtype, mode):
+    """Rows beyond the single-workgroup capacity (35,840 fp32 / 28,672 fp64 keys): chunk-sort + cross-chunk ranking, same
+    stable order, ties / NaN / signed zeros / infinities included."""
+    rng = np.random.default_rng(n)
+    rows = 3
+    k = keys_with_ties(rng, rows, n, dtype)
+    k[2, :] = np.round(k[2, :], 1)                        # heavy ties across chunk boundaries
+    kp = plane(ops, k)
+    if mode == "plain":
+        order, sk, rank = ops.sort_rows_desc(kp, want_rank=True)
+        e_order, e_sk, e_rank = oracle.sort_rows_desc(k, want_rank=True)
+    else:
+        init = np.stack([rng.permutation(n) for _ in range(rows)]).astype(np.int32)
+        lens = np.array([n, n - 5, n // 2 + 7], dtype=np.int32)
+        e_order, e_sk, e_rank = oracle.sort_rows_desc(k, init_order=init, row_len=lens, want_rank=True)
+        if mode == "gathered":
+            order, sk, rank = ops.sort_rows_desc(kp, init_order=dev(init), row_len=dev(lens), want_rank=True)
+        else:
+            inv = np.full((rows, n), -1, dtype=np.int32)
+            for r in range(rows):
+                inv[r, init[r, : lens[r]]] = np.arange(lens[r], dtype=np.int32)
+            order, sk, rank = ops.sort_rows_desc(kp, init_rank=dev(inv), row_len=dev(lens), want_rank=True)
+    np.testing.assert_array_equal(order.cpu().numpy(), e_order)
+    np.testing.assert_array_equal(rank.cpu().numpy(), e_rank)
+    np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)
 
 
 @pytest.mark.parametrize("n,dtype", [(5, np.float32), (300, np.float32), (5000, np.float64), (27942, np.float32)])

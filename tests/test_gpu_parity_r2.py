@@ -368,3 +368,23 @@ def test_checkpoint_loaders_packed_path_matches_plain_path(tmp_path):
     exp = ce_cpu.predict(pairs).view(len(queries), len(docs))
     for q, lst in enumerate(got):
         assert [x["corpus_id"] for x in lst] == [10 + int(i) for i in torch.argsort(exp[q], descending=True, stable=True)]
+
+
+def test_pipeline_beyond_the_single_workgroup_row_limit(ops, oracle):
+    """A 40,000-document corpus (rows longer than the fast sort path and than the register-resident fusion kernel): rank ->
+    fuse -> order through the drop-in classes equals the oracle, ranked-list identity for rrf, bit-exact min-max."""
+    from fusion_amd.retrievers.hybrid import Aggregator, _rank_scores
+    rng = np.random.default_rng(4)
+    Q, N = 3, 40000
+    a = rng.normal(0, 1, (Q, N)).astype(np.float32)
+    b = np.maximum(0, rng.gamma(0.5, 4.0, (Q, N)) - 2).astype(np.float32)
+    ids = np.arange(7, 7 + N)
+    sa, sb = _rank_scores(dev(a), ids, None), _rank_scores(dev(b), ids, None)
+    _, _, ra = oracle.sort_rows_desc(a, want_rank=True); oa, _ = oracle.sort_rows_desc(a)
+    _, _, rb = oracle.sort_rows_desc(b, want_rank=True)
+    for method, norm in (("rrf", None), ("nsf", "min-max")):
+        fused = Aggregator.fuse_device({"a": sa, "b": sb}, method, norm, {"a": 0.3, "b": 0.7}, {})
+        f = oracle.fuse_rank([ra, rb], np.full((2, Q), N, dtype=np.int32), "rrf") if method == "rrf" else oracle.fuse_nsf([a, b], None, [0.3, 0.7], "min-max")
+        e_order, e_keys = oracle.sort_rows_desc(f, init_order=oa)
+        np.testing.assert_array_equal(fused.order.cpu().numpy(), e_order)
+        np.testing.assert_array_equal(fused.scores.cpu().numpy(), e_keys)
