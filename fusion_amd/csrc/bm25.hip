@@ -121,11 +121,8 @@ extern "C" int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, cons
     if (!toff || !idf || !doc_len || !qoff || !scores) return FZ_ERR_ARG;
     Bm25Args a{toff, pdoc, ptf, idf, doc_len, doc_norm, avgdl, k1, b, qoff, qterms, N, scores, lds};
     constexpr size_t lds_bytes = (size_t)BM25_SLICE * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        FZ_HIP_TRY(hipFuncSetAttribute((const void*)bm25_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
-    }
+    static unsigned long long lds_set = 0ull;
+    if (int rc = raise_lds_limit((const void*)bm25_kernel, lds_bytes, lds_set)) return rc;
     dim3 grid((unsigned)((N + BM25_SLICE - 1) / BM25_SLICE), (unsigned)Q);
     bm25_kernel<<<grid, 1024, lds_bytes, as_stream(stream)>>>(a);
     FZ_LAUNCH_CHECK();

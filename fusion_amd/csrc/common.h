@@ -32,6 +32,17 @@ inline int hip_fail(hipError_t e) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: remember per device (bit mask, one per call site)
+// where it has been set; devices >= 64 set it on every call.  Returns FZ_OK or FZ_ERR_HIP.
+inline int raise_lds_limit(const void* kernel, size_t bytes, unsigned long long& done_mask) {
+    int dev = 0;
+    FZ_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 64 && ((done_mask >> dev) & 1ull)) return FZ_OK;
+    FZ_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (dev < 64) done_mask |= 1ull << dev;
+    return FZ_OK;
+}
+
 template <typename T, int N>
 struct PtrPack {
     T p[N];

@@ -68,24 +68,13 @@ struct AttnArgs {
 // NQ = 16-query sub-strips per wave.  NQ = 2: every K/V tile a wave loads serves 32 queries -- half the re-reads of the
 // sequence's K/V rows through the load path (the kernel's bound, see above) for 112 instead of 72 VGPRs.
 template <int NQ>
-#ifdef FZ_ABL_ATTN_PREFETCH
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void attn_varlen_kernel(AttnArgs a) {
-#else
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7 : 4, 8))) void attn_varlen_kernel(AttnArgs a) {
-#endif
     __shared__ __attribute__((aligned(16))) float lds[4 * 16 * ATT_LDT];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-#ifdef FZ_ABL_ATTN_HEADS4   // ablation: a workgroup = one strip x four consecutive heads (1 KiB contiguous per row)
-    const int hgroups = (a.H + 3) >> 2;
-    const int strip = blockIdx.x / hgroups;
-    const int h = (blockIdx.x - strip * hgroups) * 4 + wave;
-    if (h >= a.H) return;
-#else
     const int grp = blockIdx.x / a.H;
     const int h = blockIdx.x - grp * a.H;
     const int strip = grp * 4 + wave;
     if (strip >= a.n_strips) return;
-#endif
     const int4 st = a.strips[strip];
     const int tok0 = st.x, L = st.y, q0 = st.z;
     if (q0 >= L) return;
@@ -127,39 +116,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7
         for (int t = 0; t < 4; ++t) o[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-#ifdef FZ_ABL_ATTN_PREFETCH   // ablation: the next tile's K (raw) and V are fetched before this tile's products
-    i32x4 kraw[4];
-    f32x4 vnext[4];
-    auto fetch_kv = [&](int j) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) kraw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_t, (j + 4 * i) * ldb + hid * 4, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) vnext[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_v, (j + i) * ldb + 2 * hid * 4, 0));
-    };
-    fetch_kv(0);
-#endif
     for (int j0 = 0; j0 < L; j0 += 16) {
         float kf[16];
         f32x4 v[4];      // [step]; component t feeds dim tile t
-#ifdef FZ_ABL_ATTN_PREFETCH
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(wr + 4 * i * ATT_LDT) = kraw[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 t = *reinterpret_cast<const float4*>(rd + 4 * i);
-            kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = vnext[i];
-        if (j0 + 16 < L) fetch_kv(j0 + 16);
-#else
         load_tile(j0, hid * 4, kf);
         // V: one 16-byte load per key and lane -- lane (r, kg) takes dims 4r..4r+3 of key 4 kg + i, i.e. output tile t holds the
         // dims 4 r + t (any assignment of dims to MFMA rows is as good as another; this one reads whole 256-B head rows)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_v, (j0 + i) * ldb + 2 * hid * 4, 0));
-#endif
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             if (u == 1 && !second) break;
@@ -209,11 +174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7
         for (int i = 0; i < 4; ++i) {
             const int row = 4 * i + kg;
             const float4 t4 = *reinterpret_cast<const float4*>(my + row * ATT_LDT + r * 4);
-#ifndef FZ_ABL_ATTN_NOSTORE   // ablation: what the output stores cost
             if (q0 + 16 * u + row < L) *reinterpret_cast<float4*>(op + (size_t)row * a.ldo) = t4;
-#else
-            if (q0 + 16 * u + row < L && t4.x == 123.456f) *reinterpret_cast<float4*>(op + (size_t)row * a.ldo) = t4;
-#endif
         }
     }
 }
@@ -386,11 +347,7 @@ extern "C" int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strip
     if ((ld & 3) || (ldo & 3) || !aligned16(qkv) || !aligned16(out) || !aligned16(strips)) return FZ_ERR_UNSUPPORTED;
     if ((long long)ld * 4 * 16384 > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;   // in-sequence byte offsets are 32-bit
     AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(strips), n_strips, H, out, ldo, scale * 1.4426950408889634f};
-#ifdef FZ_ABL_ATTN_HEADS4
-    const long long grid = (long long)n_strips * ((H + 3) / 4);
-#else
     const long long grid = (long long)((n_strips + 3) / 4) * H;
-#endif
     if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
     attn_varlen_kernel<FZ_ATTN_NQ><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
     FZ_LAUNCH_CHECK();

@@ -812,11 +812,9 @@ extern "C" int fz_row_stats_f32(const float* scores, const int32_t* rank, int ro
 template <int NORM, int TT, int E4, bool VEC, bool VALID, bool DMA>
 static int launch_nsf_cfg(const NsfArgs& a, int Q, float* fused, hipStream_t st) {
     constexpr size_t lds = (DMA ? (size_t)TT * E4 * 16 : 0) + 2 * 3 * (TT / 64) * (sizeof(double) + sizeof(float)) + 64;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        FZ_HIP_TRY(hipFuncSetAttribute((const void*)fuse_nsf_row_kernel<NORM, TT, E4, VEC, VALID, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static unsigned long long lds_set = 0ull;   // per instantiation
+    if (lds > 48 * 1024)
+        if (int rc = raise_lds_limit((const void*)fuse_nsf_row_kernel<NORM, TT, E4, VEC, VALID, DMA>, lds, lds_set)) return rc;
     // DMA variants are persistent: one workgroup per CU (256 CUs) walks the rows; the others launch one per row
     const int grid = DMA ? (Q < 256 ? Q : 256) : Q;
     fuse_nsf_row_kernel<NORM, TT, E4, VEC, VALID, DMA><<<grid, TT, lds, st>>>(a, fused);

@@ -207,22 +207,16 @@ extern "C" int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int 
     g.QB = (Q + BM - 1) / BM;
     g.TN = (N + 127) / 128;
     const long B = 8L * g.QB * ((g.TN + 7) / 8);        // block ids of whole tiles (incl. the XCD padding, which exits at once)
-    static int single = -1;
-    if (single < 0) { const char* e = getenv("FZ_GEMM_SINGLE_BUFFER"); single = (e && e[0] == '1') ? 1 : 0; }
-    const long slots = single ? 768 : 512;               // resident workgroups on 256 CUs
+    const long slots = 512;                              // resident workgroups on 256 CUs (two double-buffered workgroups per CU)
     long R = B % slots;                                  // the partial last round ...
     if (R > slots / 2 || B < slots) R = 0;               // ... is only worth halving when it is at most half full
     g.full = (int)(B - R);
     const long nblk = (B - R) + 2 * R;
     if (nblk > 0x7fffffffL) return FZ_ERR_UNSUPPORTED;
-    constexpr size_t lds_db = 2 * (BM + 128) * LDT * sizeof(float), lds_sb = (BM + 128) * LDT * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        FZ_HIP_TRY(hipFuncSetAttribute((const void*)dot_scores_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_db));
-        attr_set = true;
-    }
-    if (single) dot_scores_kernel<false><<<(unsigned)nblk, 256, lds_sb, as_stream(stream)>>>(g);
-    else dot_scores_kernel<true><<<(unsigned)nblk, 256, lds_db, as_stream(stream)>>>(g);
+    constexpr size_t lds_db = 2 * (BM + 128) * LDT * sizeof(float);
+    static unsigned long long lds_set = 0ull;
+    if (int rc = raise_lds_limit((const void*)dot_scores_kernel<true>, lds_db, lds_set)) return rc;
+    dot_scores_kernel<true><<<(unsigned)nblk, 256, lds_db, as_stream(stream)>>>(g);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

@@ -824,15 +824,10 @@ template <int T, int E, int KW>
 static int launch_cfg(const SortArgs& a, int prows, hipStream_t st) {
     constexpr size_t lds = ((size_t)T * E + (T / 64) * 256 + 32) * 4 + (KW == 2 ? (size_t)T * E : 0);   // fp64: + one move byte per slot
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
-    int dev = 0;
-    FZ_HIP_TRY(hipGetDevice(&dev));
-    static unsigned long long attr_set = 0ull;   // per (T,E,KW) instantiation, one bit per device (the attribute is per device)
-    if (dev >= 64 || !((attr_set >> dev) & 1ull)) {
-        FZ_HIP_TRY(hipFuncSetAttribute((const void*)sort_rows_kernel<T, E, KW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if constexpr (KW == 2)
-            FZ_HIP_TRY(hipFuncSetAttribute((const void*)sort_rows_kernel<T, E, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev < 64) attr_set |= 1ull << dev;
-    }
+    static unsigned long long lds_set = 0ull, lds_set_gen = 0ull;   // per (T,E,KW) instantiation
+    if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, KW, false>, lds, lds_set)) return rc;
+    if constexpr (KW == 2)
+        if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, 2, true>, lds, lds_set_gen)) return rc;
     if (KW == 2 && !a.row_flags) return FZ_ERR_WORKSPACE;
     sort_rows_kernel<T, E, KW, false><<<prows, T, lds, st>>>(a);
     FZ_LAUNCH_CHECK();
