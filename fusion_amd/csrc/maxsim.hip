@@ -10,11 +10,18 @@
 //     max over document tokens = in-lane max of 16 registers (+ one exchange between lane l and l^32),
 //     sum over query tokens    = a wave reduction over 32 lanes, once per (query, document).
 // A workgroup = 8 waves; every wave keeps the B fragments of 4 query blocks (2 queries x 64 tokens)
-// in 128 VGPRs for the whole kernel, and all 8 waves consume the same document tile, which is staged
-// global -> LDS once per workgroup (16-B chunks XOR-swizzled by row so that ds_read_b128 of 32 rows is
-// conflict-free) and double-buffered.  Tiles are aligned to document starts (rows past the end are masked
+// in 128 VGPRs for the whole kernel, and all 8 waves consume the same document tile, which goes
+// global -> LDS once per workgroup by LDS-DMA (16-B chunks XOR-swizzled by row so that ds_read_b128 of
+// 32 rows is conflict-free), a group of four tiles ahead.  Tiles are aligned to document starts (rows past the end are masked
 // to -inf).  Workgroups that share a 32-document range run back-to-back on one XCD, so the range (about
 // 2.4 MB) is fetched from HBM once and served from that XCD's L2 to the other query groups.
+//
+// Where it stands (profiles/r02_pmc_maxsim.json, Q = 195): 9.1e8 MFMAs per launch (0.89 useful: query-block and tile
+// padding), SQ_VALU_MFMA_BUSY_CYCLES = 64 % of the SIMD cycles at an effective clock of 1.99 GHz (GRBM_GUI_ACTIVE / 8 /
+// time) -- 1.12-1.21 PFLOP/s = 45-48 % of the 2.5 PF nominal peak, 90-97 % of the 1,247 TFLOP/s MI355X_MICROARCH.md
+// measures for a dense bf16 MFMA loop on random data (same busy fraction, same clock: the chip holds its clock down under
+// matrix load).  Measured and without effect on the time: barrier every 2 / 4 / 8 tiles, register staging vs LDS-DMA,
+// A fragments refilled in place under the last MFMA chain (slower: 0.39), waves 4-7 staggered by s_sleep 4..24.
 #include <hip/hip_fp16.h>
 
 #include "common.h"
@@ -30,6 +37,8 @@ constexpr int MS_BLOCKS_PER_WAVE = 4;   // query blocks of 32 tokens held per wa
 constexpr int MS_DOCS_PER_WG = 32;
 constexpr int MS_TILE_BYTES = 32 * MS_DIM * 2;  // 8 KiB
 constexpr int MS_TABLE = MS_DOCS_PER_WG * 16;   // tile-table entries per workgroup (32 documents x 512 tokens)
+constexpr int MS_GROUP = 4;                     // tiles per group: one workgroup barrier per group
+constexpr int MS_RING = 2 * MS_GROUP;           // LDS tile slots: the group being read + the group being filled
 
 struct MaxSimArgs {
     const _Float16* Qtok;   // [Q][Lq][128]
@@ -46,7 +55,7 @@ struct MaxSimArgs {
 };
 
 __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char tile[4][MS_TILE_BYTES];   // ring of 4 x 8 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char tile[MS_RING][MS_TILE_BYTES];   // ring of 8 KiB tiles
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int qg = idx % a.QG;
@@ -76,15 +85,6 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
     const int d_end = (d_begin + a.docs_per_wg < a.N) ? d_begin + a.docs_per_wg : a.N;
 
     // ---- tile walk: tiles are aligned to document starts -------------------------------
-    // staging: 512 threads x one 16-B chunk = one 32-token tile; thread -> (row = tid/16, chunk = tid%16)
-    const int srow = tid >> 4, schunk = tid & 15;
-    const int swz = (srow * 256) + ((schunk ^ (srow & 15)) << 4);
-    auto stage_load = [&](int64_t tok0) -> uint4 {
-        int64_t t = tok0 + srow;
-        t = t < a.sumL ? t : a.sumL - 1;   // rows past the end of the corpus: clamp (they are masked)
-        return *reinterpret_cast<const uint4*>(a.Dtok + (size_t)t * MS_DIM + schunk * 8);
-    };
-
     // vals[b]: per-block sums already reduced over the wave; lane 0 writes one score per query.
     // An empty document scores 0 for every query (sum of an empty max := 0, as in the oracle).
     auto write_scores = [&](int d, const float* vals) {
@@ -134,34 +134,75 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
         if (s_len[i] == 0) write_scores(d_begin + i, zeros);   // empty documents
     if (ntiles == 0) return;   // block-uniform
 
-    // ---- tile ring.  Tile k lives in slot k % 4.  Tile k+3 is fetched (global -> registers) during iteration k
-    // and written to its slot at the start of iteration k+1, i.e. two tiles ahead of its use, so ONE workgroup
-    // barrier every SECOND tile orders both the RAW (slot written -> read two iterations later) and the WAR
-    // (slot read -> overwritten two iterations later) hazards.
-    *reinterpret_cast<uint4*>(&tile[0][swz]) = stage_load(s_tok[0]);
-    if (ntiles > 1) *reinterpret_cast<uint4*>(&tile[1][swz]) = stage_load(s_tok[1]);
-    uint4 stage = make_uint4(0, 0, 0, 0);
-    if (ntiles > 2) stage = stage_load(s_tok[2]);
+    // ---- tile ring, filled by LDS-DMA.  Tile k lives in slot k % MS_RING; a tile is 32 rows x 256 B, row r's 16-B chunks
+    // XOR-swizzled by r & 15 (conflict-free ds_read_b128 of 32 rows).  global_load_lds writes lane l of a wave to
+    // (wave-uniform LDS base) + 16 l, so the swizzle is applied on the GLOBAL side: wave w fills rows 4w .. 4w+3, lane l sits
+    // at chunk position l & 15 of row 4w + (l >> 4) and fetches the chunk whose swizzled position that is.  No staging
+    // registers, no ds_write, and the loads of a whole group are in flight for a whole group of MFMA work:
+    //     start of group g:  issue the DMA of group g + 1 (its slots held group g - 1, which every wave has left);
+    //     end of group g:    __syncthreads() (= vmcnt(0) + barrier): group g + 1 has landed and is visible to all waves.
+    // hipcc drains vmcnt before every LDS access it can see while a DMA is pending (it cannot tell the slots apart), which
+    // would put the whole L2 / HBM latency back in front of every tile.  So inside a group NO LDS access is visible to it:
+    // the group's tile metadata and the next group's token offsets are read before the DMAs are issued, and the A
+    // fragments are fetched by ds_read_b128 written as inline asm, with their own s_waitcnt lgkmcnt(0).
+    auto dma_tile = [&](int64_t tok0, int slot) {
+        const int row = 4 * w + (lane >> 4), cpos = lane & 15;
+        int64_t tok = tok0 + row;
+        tok = tok < a.sumL ? tok : a.sumL - 1;   // rows past the end of the corpus: clamp (they are masked)
+        const _Float16* g = a.Dtok + (size_t)tok * MS_DIM + ((cpos ^ (row & 15)) << 3);
+        __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)(&tile[slot][w * 1024]), 16, 0, 0);
+    };
+    {
+        int64_t toks[MS_GROUP];
+#pragma unroll
+        for (int i = 0; i < MS_GROUP; ++i) toks[i] = s_tok[i < ntiles ? i : 0];
+#pragma unroll
+        for (int i = 0; i < MS_GROUP; ++i) if (i < ntiles) dma_tile(toks[i], i);
+    }
     __syncthreads();
+    const uint32_t tile_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&tile[0][0]);
 
     float run[MS_BLOCKS_PER_WAVE];
 #pragma unroll
     for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) run[b] = -INFINITY;
 
-    for (int k = 0; k < ntiles; ++k) {
-        const int meta = __builtin_amdgcn_readfirstlane(s_meta[k]);
+    for (int k0 = 0; k0 < ntiles; k0 += MS_GROUP) {
+      int metas[MS_GROUP];
+      {
+        int64_t toks[MS_GROUP];
+#pragma unroll
+        for (int i = 0; i < MS_GROUP; ++i) {
+            metas[i] = __builtin_amdgcn_readfirstlane(s_meta[k0 + i < ntiles ? k0 + i : 0]);
+            toks[i] = s_tok[k0 + MS_GROUP + i < ntiles ? k0 + MS_GROUP + i : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < MS_GROUP; ++i)
+            if (k0 + MS_GROUP + i < ntiles) dma_tile(toks[i], ((k0 + MS_GROUP) & (MS_RING - 1)) + i);
+      }
+#pragma unroll
+      for (int gi = 0; gi < MS_GROUP; ++gi) {
+        const int k = k0 + gi;
+        if (k >= ntiles) break;
+        const int meta = metas[gi];
         const int rows_valid = (meta >> 8) & 0xff;
         const bool last_tile_of_doc = (meta >> 16) & 1;
-        if (k + 2 < ntiles) *reinterpret_cast<uint4*>(&tile[(k + 2) & 3][swz]) = stage;   // tile k+2: read at iteration k+2
-        if (k + 3 < ntiles) stage = stage_load(s_tok[k + 3]);
 
         // ---- A fragments from LDS: lane l -> row l&31, k = 16*ks + 8*(l>>5) .. +7 ------------
         f16x8 af[8];
         {
-            const int r = lane & 31, h = lane >> 5;
-            const unsigned char* base = &tile[k & 3][r * 256];
+            // the lane id is re-derived here (two v_mbcnt) rather than kept: at 256 registers one long-lived value more is a
+            // spill, and a spill's reload is a vmcnt(0) -- which would also wait for the DMAs in flight
+            uint32_t l;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            const uint32_t a_h = l >> 5, a_x = l & 15;
+            const uint32_t base = tile_lds + (l & 31) * 256 + (uint32_t)(((k0 & (MS_RING - 1)) + gi) * MS_TILE_BYTES);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const f16x8*>(base + (((2 * ks + h) ^ (r & 15)) << 4));
+            for (int ks = 0; ks < 8; ++ks) {
+                const uint32_t addr = base + (((2 * ks + a_h) ^ a_x) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(af[ks]) : "v"(addr));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]));
         }
         // ---- 4 query blocks x 8 k-steps, two accumulators in ping-pong: the 16-way max of block b runs on the
         //      VALU while the MFMA chain of block b+1 occupies the matrix pipe ---------------------------------
@@ -214,7 +255,8 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
             }
             write_scores(d_begin + (meta & 0xff), sums);
         }
-        if (k & 1) __syncthreads();   // every second tile (see the ring invariant above)
+      }
+      __syncthreads();   // group boundary: the next group's tiles have landed (vmcnt(0)) and everyone has left this group's
     }
 }
 

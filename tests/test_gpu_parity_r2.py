@@ -388,3 +388,36 @@ def test_pipeline_beyond_the_single_workgroup_row_limit(ops, oracle):
         e_order, e_keys = oracle.sort_rows_desc(f, init_order=oa)
         np.testing.assert_array_equal(fused.order.cpu().numpy(), e_order)
         np.testing.assert_array_equal(fused.scores.cpu().numpy(), e_keys)
+
+
+# ---- config 3 at full size: ColBERT MaxSim over the LLeQA-shaped corpus ---------------------------------------------------
+def test_maxsim_full_size_properties(ops):
+    """Q = 195, N = 27,942, L_d ~ clip(N(300, 120), 16, 512) with some empty documents, 64 x 128 fp16 unit query tokens:
+    every score within [-Lq, Lq], empty documents score 0, and a random sample of (query, document) pairs equals the fp32
+    torch evaluation of sum_i max_t <q_i, d_t> on the same fp16 inputs (tolerance 2e-3: fp32 accumulation order only)."""
+    rng = np.random.default_rng(0)
+    Q, N, Lq = 195, 27942, 64
+    lens = np.clip(rng.normal(300, 120, N), 16, 512).astype(np.int64)
+    empty = rng.choice(N, size=50, replace=False)
+    lens[empty] = 0
+    off = np.zeros(N + 1, dtype=np.int64); off[1:] = np.cumsum(lens)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    Dtok = torch.nn.functional.normalize(torch.randn((int(off[-1]), 128), generator=g, device="cuda"), dim=-1).half()
+    Qtok = torch.nn.functional.normalize(torch.randn((Q, Lq, 128), generator=g, device="cuda"), dim=-1).half()
+    S = ops.maxsim(Qtok, Dtok, torch.from_numpy(off).cuda(), max_doc_len=512)
+    assert S.shape == (Q, N)
+    Sh = S.cpu().numpy()
+    assert np.isfinite(Sh).all() and np.abs(Sh).max() <= Lq * 1.001
+    assert np.all(Sh[:, empty] == 0.0)
+    qs, ds = rng.integers(0, Q, 300), rng.integers(0, N, 300)
+    for q, d in zip(qs, ds):
+        if lens[d] == 0:
+            continue
+        ref = (Qtok[q].float() @ Dtok[off[d]: off[d + 1]].float().T).max(dim=1).values.sum().item()
+        assert abs(Sh[q, d] - ref) <= 2e-3, (q, d, Sh[q, d], ref)
+    # permuting the documents permutes the columns (tiles are aligned to document starts: no cross-document leakage)
+    perm = rng.permutation(N)[:2000]
+    off2 = np.zeros(len(perm) + 1, dtype=np.int64); off2[1:] = np.cumsum(lens[perm])
+    D2 = torch.cat([Dtok[off[d]: off[d + 1]] for d in perm])
+    S2 = ops.maxsim(Qtok[:16].contiguous(), D2, torch.from_numpy(off2).cuda(), max_doc_len=512).cpu().numpy()
+    np.testing.assert_array_equal(S2, Sh[:16][:, perm])
