@@ -262,8 +262,8 @@ def profiled_traffic(stage, st):
     shape it was collected on, otherwise None.  Returns (bytes, source file)."""
     if (st["Q"], st["N"], st["d"]) != (1024, 27942, 768):
         return None, None
-    pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1>", "bm25_rank": "sort_rows_kernel<1024, 28, 2>",
-            "final_order": "sort_rows_kernel<1024, 28, 2>", "fuse_rrf": "fuse_rank_kernel", "encode_attn": "attn_varlen_kernel",
+    pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1,", "bm25_rank": "sort_rows_kernel<1024, 28, 2, false",
+            "final_order": "sort_rows_kernel<1024, 28, 2, false", "fuse_rrf": "fuse_rank_kernel", "encode_attn": "attn_varlen_kernel",
             "encode_gelu": "gelu_kernel", "encode_ln": "add_layernorm_kernel"}
     for name in TRAFFIC_PROFILES:
         try:
