@@ -67,6 +67,7 @@ class ShardedDenseIndex:
 
     CHUNK = 8 * 28672   # documents per GEMM launch: 8 sort-kernel rows per query
     CAP = 7168          # candidate slots per row and chunk on the streaming path (k + CAP = one 8192-key sort row at k = 1024)
+    HEAD = 28672        # columns of the FIRST chunk that are sorted exactly (one sort-kernel row); the rest of it streams
 
     def __init__(self, Dn_local: torch.Tensor, id_base: int, group=None):
         self.Dn, self.id_base, self.group = Dn_local, int(id_base), group
@@ -84,7 +85,18 @@ class ShardedDenseIndex:
         for c0 in range(0, max(n, 1), self.CHUNK):
             c1 = min(n, c0 + self.CHUNK)
             S = ops.dot_scores(Qn, self.Dn[c0:c1]); mark("shard_gemm")
-            if best_s is None:
+            if best_s is None and streaming and k + self.CAP <= 35840 and c1 - c0 > self.HEAD and k <= self.HEAD // 8:
+                # first chunk: an exact top-k of its first HEAD columns gives a threshold, the rest streams through the filter in
+                # pieces that grow with what has been seen (expected survivors per row = k * piece / seen <= CAP / 2), instead
+                # of chunk-sorting all of it (2.6 -> ~0.8 ms at 229,376 columns, k = 1000)
+                best_s, best_i = ops.topk_rows(S[:, : self.HEAD], k, id_base=self.id_base + c0)
+                seen = self.HEAD
+                while seen < c1 - c0:
+                    piece = min(c1 - c0 - seen, max(4096, (self.CAP // 2) * seen // k) // 64 * 64)
+                    best_s, best_i, overflow = ops.topk_update(S[:, seen: seen + piece], self.id_base + c0 + seen, best_s, best_i, self.CAP, overflow)
+                    seen += piece
+                mark("shard_topk_first")
+            elif best_s is None:
                 best_s, best_i = ops.topk_rows(S, k, id_base=self.id_base + c0); mark("shard_topk_first")
             elif streaming and k + self.CAP <= 35840:
                 best_s, best_i, overflow = ops.topk_update(S, self.id_base + c0, best_s, best_i, self.CAP, overflow); mark("shard_topk_update")

@@ -421,3 +421,21 @@ def test_maxsim_full_size_properties(ops):
     D2 = torch.cat([Dtok[off[d]: off[d + 1]] for d in perm])
     S2 = ops.maxsim(Qtok[:16].contiguous(), D2, torch.from_numpy(off2).cuda(), max_doc_len=512).cpu().numpy()
     np.testing.assert_array_equal(S2, Sh[:16][:, perm])
+
+
+def test_sharded_search_first_chunk_streams_after_an_exact_head(ops, oracle):
+    """ShardedDenseIndex with its default 229,376-column chunks: the first chunk is an exact top-k of 28,672 columns + streaming
+    pieces; the result equals the oracle's top-k of the full score matrix (scores and ids, ties by ascending id)."""
+    from fusion_amd.distributed import ShardedDenseIndex
+    g = torch.Generator(device="cuda").manual_seed(1)
+    N, d, Q, k = 300000, 32, 5, 1000
+    Dn = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
+    Dn[1000:1040] = Dn[7]                                  # exact ties across the head / piece boundaries
+    Dn[50000:50040] = Dn[7]
+    Qn = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
+    idx = ShardedDenseIndex(Dn, id_base=123)
+    s, i = idx.local_topk(Qn, k)
+    S = ops.dot_scores(Qn, Dn).cpu().numpy()
+    es, ei = oracle.topk_rows(S, k, id_base=123)
+    np.testing.assert_array_equal(s.cpu().numpy(), es)
+    np.testing.assert_array_equal(i.cpu().numpy(), ei)
