@@ -72,14 +72,20 @@ class ShardedDenseIndex:
     def __init__(self, Dn_local: torch.Tensor, id_base: int, group=None):
         self.Dn, self.id_base, self.group = Dn_local, int(id_base), group
 
-    def local_topk(self, Qn: torch.Tensor, k: int, streaming: bool = True, mark=None):
+    def local_topk(self, Qn: torch.Tensor, k: int, streaming: bool = True, mark=None, overlap: bool | None = None):
         """Chunked score -> top-k over this shard.  First chunk: exact chunk-sort-truncate.  Later chunks: only scores
         above the running k-th best can enter, so they go through the streaming threshold filter (ops.topk_update);
         if any row overflowed its candidate buffer the search is redone on the exact path (flag read once, at the end).
-        `mark(name)`: optional instrumentation hook (bench.py records a HIP event per call)."""
+        `mark(name)`: optional instrumentation hook (bench.py records a HIP event per call).
+        `overlap` (default: on unless instrumented): the top-k of chunk c runs on a second HIP stream while the matrix cores
+        score chunk c + 1 into the other of two score planes (the GEMM is MFMA-bound, the filter HBM-bound)."""
         from . import ops
-        mark = mark or (lambda name: None)
+        if overlap is None:
+            overlap = mark is None
         n = self.Dn.shape[0]
+        if overlap and streaming and n > self.CHUNK and Qn.is_cuda:
+            return self._local_topk_overlapped(Qn, k)
+        mark = mark or (lambda name: None)
         best_s = best_i = None
         overflow = None
         for c0 in range(0, max(n, 1), self.CHUNK):
@@ -105,6 +111,55 @@ class ShardedDenseIndex:
                 best_s, best_i = ops.topk_merge(torch.stack([best_s, s]), torch.stack([best_i, i])); mark("shard_topk_exact")
         if overflow is not None and int(overflow.item()) != 0:
             return self.local_topk(Qn, k, streaming=False, mark=mark)
+        return best_s, best_i
+
+    def _topk_chunk(self, S, c0, k, best_s, best_i, overflow):
+        """Fold one chunk of scores (columns = documents c0 ..) into the running top-k (the streaming forms of local_topk)."""
+        from . import ops
+        w = S.shape[1]
+        if best_s is None:
+            if w > self.HEAD and k <= self.HEAD // 8:
+                best_s, best_i = ops.topk_rows(S[:, : self.HEAD], k, id_base=self.id_base + c0)
+                seen = self.HEAD
+                while seen < w:
+                    piece = min(w - seen, max(4096, (self.CAP // 2) * seen // k) // 64 * 64)
+                    best_s, best_i, overflow = ops.topk_update(S[:, seen: seen + piece], self.id_base + c0 + seen, best_s, best_i, self.CAP, overflow)
+                    seen += piece
+                return best_s, best_i, overflow
+            best_s, best_i = ops.topk_rows(S, k, id_base=self.id_base + c0)
+            return best_s, best_i, overflow
+        return ops.topk_update(S, self.id_base + c0, best_s, best_i, self.CAP, overflow)
+
+    def _local_topk_overlapped(self, Qn: torch.Tensor, k: int):
+        from . import ops
+        if k + self.CAP > 35840:
+            return self.local_topk(Qn, k, overlap=False)
+        n, Q = self.Dn.shape[0], Qn.shape[0]
+        main = torch.cuda.current_stream(Qn.device)
+        side = getattr(self, "_side", None)
+        if side is None or side.device != Qn.device:
+            side = self._side = torch.cuda.Stream(device=Qn.device)
+        planes = [ops.alloc_plane(Q, min(self.CHUNK, n), torch.float32, Qn.device) for _ in range(2)]
+        done_topk = [None, None]
+        best_s = best_i = overflow = None
+        for ci, c0 in enumerate(range(0, n, self.CHUNK)):
+            c1 = min(n, c0 + self.CHUNK)
+            buf = planes[ci & 1]
+            if done_topk[ci & 1] is not None:
+                main.wait_event(done_topk[ci & 1])              # the plane's previous chunk has been consumed
+            S = ops.dot_scores(Qn, self.Dn[c0:c1], out=buf[:, : c1 - c0])
+            scored = torch.cuda.Event(); scored.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(scored)
+                best_s, best_i, overflow = self._topk_chunk(S, c0, k, best_s, best_i, overflow)
+                ev = torch.cuda.Event(); ev.record(side)
+                done_topk[ci & 1] = ev
+        main.wait_stream(side)
+        for t in (best_s, best_i, overflow, *planes):
+            if t is not None:
+                t.record_stream(main)
+        if overflow is not None and int(overflow.item()) != 0:
+            return self.local_topk(Qn, k, streaming=False, overlap=False)
         return best_s, best_i
 
     def search(self, Qn: torch.Tensor, k: int = 1000, mark=None):
