@@ -503,47 +503,87 @@ __global__ __launch_bounds__(256) void fuse_nsf_elem4_kernel(NsfArgs a, const fl
 // kernel's path) 1.2 ms at P = 1001, and the NCE's double-precision erfinv per score another 6.5 ms.  Here every persistent
 // workgroup loads the S tables into LDS once and, for NCE, tabulates the value of every table INDEX next to them (the
 // transform depends on the score only through the index of its nearest entry), then streams (row, 1024-column) items.
-// Same search, same float expressions: bit-identical results.
+// Same nearest entry, same float expressions: bit-identical results.
 struct TableArgs {
     int off[FZ_MAX_SYSTEMS];   // start of system s's table in the LDS array
     int total;                 // sum of P
 };
 
-__device__ __forceinline__ int nearest_entry_lds(const float* __restrict__ tab, int P, float s) {
-    // first argmin_k |tab_k - s| on an ASCENDING table (hybrid.py:272-275), as percentile_rank() above
+// The search itself: binary search costs ~log2(P) + 3 DEPENDENT LDS reads per score (the kernel ran at 0.17 of HBM, bound
+// by that latency chain).  An equi-width look-up table over [tab[0], tab[P-1]] with LUT_B buckets per system brackets the
+// answer first:  lut[b] = #entries below the bucket's lower edge e_b = tab[0] + b * width.  A score whose bucket comes out
+// as b (at most one bucket off after rounding) has its "last entry <= s" in [lut[b-1] - 1, lut[b+2]), usually 2-3 slots;
+// the bracket is VERIFIED against the table (two of the reads the search needs anyway) and widened to the full table when
+// rounding broke it, so the result is that of the plain search in every case.  first[k] = index of the first entry equal
+// to tab[k] replaces the walk to the left over duplicated quantiles (first minimum of |tab - s|, hybrid.py:272-275).
+constexpr int LUT_B = 2048;
+
+struct TableSys {
+    const float* tab; const uint16_t* lut; const uint16_t* first;
+    float lo_v, inv_w; int P; bool use_lut;
+};
+
+__device__ __forceinline__ int nearest_entry_lut(const TableSys& y, float s) {
+    if (s != s || fabsf(s) == INFINITY) return 0;   // NaN: argmin of an all-NaN column; +-inf: every distance is inf -> first index
+    const int P = y.P;
     int lo = -1, hi = P;
+    if (y.use_lut) {
+        const float t = (s - y.lo_v) * y.inv_w;
+        if (t < 0.f) return 0;                       // below the first entry: it is the nearest
+        if (t < (float)LUT_B) {
+            const int b = (int)t;
+            lo = (int)y.lut[b > 0 ? b - 1 : 0] - 1;
+            hi = (int)y.lut[b + 2 < LUT_B ? b + 2 : LUT_B];
+            if (lo >= 0 && !(y.tab[lo] <= s)) lo = -1;   // rounding broke the bracket: widen (never seen, kept for exactness)
+            if (hi < P && !(y.tab[hi] > s)) hi = P;
+        } else lo = P - 1;                                // at or above the last entry
+    }
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (tab[mid] <= s) lo = mid; else hi = mid;
+        if (y.tab[mid] <= s) lo = mid; else hi = mid;
     }
-    int best;
-    float bd;
-    if (lo < 0) { best = 0; bd = fabsf(tab[0] - s); }
-    else {
-        best = lo; bd = fabsf(tab[lo] - s);
-        if (lo + 1 < P) { const float dh = fabsf(tab[lo + 1] - s); if (dh < bd) { best = lo + 1; bd = dh; } }
-    }
-    while (best > 0 && fabsf(tab[best - 1] - s) == bd) --best;
-    if (s != s) best = 0;
-    return best;
+    if (lo < 0) return 0;
+    const float dl = fabsf(y.tab[lo] - s);
+    if (lo + 1 < P && fabsf(y.tab[lo + 1] - s) < dl) return lo + 1;
+    return (int)y.first[lo];
 }
 
-// TPB: NCE runs 1024-thread workgroups -- the double-precision erfinv of the tabulation is the expensive part, and a
-// workgroup four times as large means a quarter of the entries per thread and a quarter of the workgroups repeating them.
 template <bool NCE, int TPB>
 __global__ __launch_bounds__(TPB) void fuse_nsf_table_kernel(NsfArgs a, TableArgs t, int Q, float* __restrict__ fused) {
-    extern __shared__ __attribute__((aligned(16))) float tabs[];   // [total] quantiles (+ [total] NCE values per index)
+    extern __shared__ __attribute__((aligned(16))) float tabs[];   // [total] quantiles, [total] values per index, then uint16: first[total], lut[S][LUT_B + 1]
+    float* val = tabs + t.total;                                     // value of every table INDEX: k / P, or its NCE transform
+    uint16_t* first = reinterpret_cast<uint16_t*>(tabs + 2 * t.total);
+    uint16_t* lut = first + ((t.total + 1) & ~1);
     for (int s = 0; s < a.S; ++s)
         for (int k = threadIdx.x; k < a.P[s]; k += TPB) {
             tabs[t.off[s] + k] = a.distr[s][k];
+            const float pr = (float)k / (float)a.P[s];                   // hybrid.py:275
             if (NCE) {   // transform<FZ_NORM_NCE> as a function of the index
-                const float pr = (float)k / (float)a.P[s];
                 const float p = pr / 100.0f;
                 const float y = 2.0f * p - 1.0f;
                 const float z = (float)(erfinv((double)y) * 1.4142135623730951);
-                tabs[t.total + t.off[s] + k] = z * 21.06f + 50.0f;
-            }
+                val[t.off[s] + k] = z * 21.06f + 50.0f;
+            } else val[t.off[s] + k] = pr;
         }
+    __syncthreads();
+    auto lower_bound = [&](const float* tab, int P, float x) -> int {   // #entries < x
+        int lo = 0, hi = P;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (tab[mid] < x) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    __shared__ float sys_lo[FZ_MAX_SYSTEMS], sys_inv[FZ_MAX_SYSTEMS];   // per system: first entry, buckets per unit (0 = no look-up table)
+    for (int s = 0; s < a.S; ++s) {
+        const float* tab = tabs + t.off[s];
+        const int P = a.P[s];
+        const float lo_v = tab[0], hi_v = tab[P - 1];
+        const float width = (hi_v - lo_v) / (float)LUT_B;
+        const bool ok = P >= 2 && width > 0.f && fabsf(width) != INFINITY && lo_v == lo_v && hi_v == hi_v;
+        if (threadIdx.x == 0) { sys_lo[s] = lo_v; sys_inv[s] = ok ? (float)LUT_B / (hi_v - lo_v) : 0.f; }
+        for (int k = threadIdx.x; k < P; k += TPB) first[t.off[s] + k] = (uint16_t)lower_bound(tab, P, tab[k]);
+        if (ok)
+            for (int b = threadIdx.x; b <= LUT_B; b += TPB)
+                lut[s * (LUT_B + 1) + b] = (uint16_t)(b == LUT_B ? P : lower_bound(tab, P, lo_v + (float)b * width));
+    }
     __syncthreads();
     const int chunks = (a.N + 4 * TPB - 1) / (4 * TPB);
     const long long items = (long long)Q * chunks;
@@ -561,14 +601,15 @@ __global__ __launch_bounds__(TPB) void fuse_nsf_table_kernel(NsfArgs a, TableArg
             const float v[4] = {f.x, f.y, f.z, f.w};
             int r[4] = {0, 0, 0, 0};
             if (a.ranks[s]) { const i4v rr = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(a.ranks[s] + rowoff + j0)); r[0] = rr.x; r[1] = rr.y; r[2] = rr.z; r[3] = rr.w; }
-            const float* tab = tabs + t.off[s];
             const int P = a.P[s];
             const float w = a.w[s];
+            const float inv_w = sys_inv[s];
+            const TableSys y{tabs + t.off[s], lut + s * (LUT_B + 1), first + t.off[s], sys_lo[s], inv_w, P, inv_w != 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (r[e] >= 0 && j0 + e < a.N) {
-                    const int k = nearest_entry_lds(tab, P, v[e]);
-                    const float tr = NCE ? tabs[t.total + t.off[s] + k] : (float)k / (float)P;
+                    const int k = nearest_entry_lut(y, v[e]);
+                    const float tr = val[t.off[s] + k];
                     const float prod = tr * w;
                     acc[e] = acc[e] + prod;
                     present[e] = true;
@@ -588,22 +629,24 @@ static int launch_nsf_tables(const NsfArgs& a, bool nce, int Q, float* fused, hi
     for (int s = 0; s < a.S; ++s) {
         t.off[s] = total;
         total += a.P[s];
+        if (a.P[s] > 65535) return 1;   // uint16 indices
         vec = vec && ((uintptr_t)a.planes[s] % 16 == 0) && (!a.ranks[s] || (uintptr_t)a.ranks[s] % 16 == 0);
     }
     t.total = total;
-    const size_t lds = (size_t)total * 4 * (nce ? 2 : 1);
-    if (!vec || lds > 64 * 1024) return 1;
-    const int tpb = nce ? 1024 : 256;
-    const int per_cu = (lds <= 16 * 1024 ? 8 : (lds <= 32 * 1024 ? 4 : 2)) * 256 / tpb;   // workgroups per CU by LDS and wave slots
+    const size_t lds = (size_t)total * 4 * 2 + (size_t)((total + 1) & ~1) * 2 + (size_t)a.S * (LUT_B + 1) * 2 + 16;
+    if (!vec || lds > 144 * 1024) return 1;
+    // one 1024-thread workgroup per CU: the tables, look-up tables and (NCE) per-index values are built once per workgroup and
+    // serve 16 waves
+    constexpr int tpb = 1024;
     const long long items = (long long)Q * ((a.N + 4 * tpb - 1) / (4 * tpb));
-    const long long want = 256LL * (per_cu < 1 ? 1 : per_cu);
-    const unsigned grid = (unsigned)(items < want ? items : want);
+    const unsigned grid = (unsigned)(items < 256 ? items : 256);
+    static unsigned long long set_nce = 0ull, set_pr = 0ull;
     if (nce) {
-        if (hipFuncSetAttribute((const void*)fuse_nsf_table_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        if (raise_lds_limit((const void*)fuse_nsf_table_kernel<true, 1024>, lds, set_nce) != FZ_OK) return 1;
         fuse_nsf_table_kernel<true, 1024><<<grid, 1024, lds, st>>>(a, t, Q, fused);
     } else {
-        if (hipFuncSetAttribute((const void*)fuse_nsf_table_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-        fuse_nsf_table_kernel<false, 256><<<grid, 256, lds, st>>>(a, t, Q, fused);
+        if (raise_lds_limit((const void*)fuse_nsf_table_kernel<false, 1024>, lds, set_pr) != FZ_OK) return 1;
+        fuse_nsf_table_kernel<false, 1024><<<grid, 1024, lds, st>>>(a, t, Q, fused);
     }
     return 0;
 }
