@@ -416,13 +416,15 @@ def measure_configs(dev, N=27942):
         fused = ops.alloc_plane(Q, N, torch.float32, dev)
         distr = [torch.quantile(p[:8].flatten()[:1000000].double(), torch.linspace(0, 1, 1001, device=dev, dtype=torch.float64)).float().contiguous()
                  for p in planes]
-        # algorithmic bytes: S score planes + the ONE rank plane that carries validity in, fused plane out
-        work = (4 + 1 + 1) * Q * N * 4
+        # algorithmic bytes: S score planes in, fused plane out (+ the partial system's validity, 1 bit per document)
+        work = (4 + 1) * Q * N * 4 + Q * N // 8
         orders = [s.order for s in systems.values()]
+        vbits = [s.valid_bits() for s in systems.values()]     # the partial list's validity as a bitmap, built once per system
         lens4 = torch.stack([s.lens for s in systems.values()]).contiguous()
         for norm in ("min-max", "z-score", "percentile-rank"):
             # called the way Aggregator.fuse_device calls it: min-max of score-sorted lists takes the statistics from the list ends
             kw = dict(orders=orders, lens=lens4) if norm == "min-max" else {}
+            kw["valid_bits"] = vbits
             ms = timeit_ms(lambda: ops.fuse_nsf(planes, ranks, w, norm, distr if norm == "percentile-rank" else None, out=fused, **kw), n=10)
             out.append(dict(config=f"4: nsf {norm} fusion, S=4, colbert 40% absent", shape=dict(Q=Q, N=N, S=4),
                             **roof("fuse_nsf kernels", ms, work, "hbm")))

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfusion_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 FZ_OK, FZ_ERR_ARG, FZ_ERR_UNSUPPORTED, FZ_ERR_HIP, FZ_ERR_WORKSPACE = 0, -1, -2, -3, -4
 NORMS = {"min-max": 1, "z-score": 2, "arctan": 3, "percentile-rank": 4, "normal-curve-equivalent": 5}
@@ -50,8 +50,9 @@ _PROTOS = {
     "fz_sort_rows_desc_placed": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_fuse_rank_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fz_row_stats_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "fz_fuse_nsf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "fz_fuse_nsf_stats_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fz_rank_to_bitmap": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "fz_fuse_nsf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "fz_fuse_nsf_stats_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "fz_minmax_from_orders_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "fz_minmax_from_order_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "fz_fuse_none_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

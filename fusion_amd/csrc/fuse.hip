@@ -155,6 +155,8 @@ __global__ __launch_bounds__(THREADS) void row_stats_kernel(const float* __restr
 struct NsfArgs {
     const float* planes[FZ_MAX_SYSTEMS];
     const int32_t* ranks[FZ_MAX_SYSTEMS];
+    const uint32_t* vbits[FZ_MAX_SYSTEMS];   // validity of system s as a bitmap [Q][ldb] (bit j & 31 of word j >> 5), built once per system
+    int ldb;                                 //   (fz_rank_to_bitmap): 1/32 of the bytes of the rank plane it replaces in the fusion passes
     const float* distr[FZ_MAX_SYSTEMS];
     int P[FZ_MAX_SYSTEMS];
     float w[FZ_MAX_SYSTEMS];
@@ -227,6 +229,14 @@ __device__ __forceinline__ void block_sum_n_nodrain(double (&v)[NV], double* red
     }
 }
 
+// validity of the 4 columns j0 .. j0+3 (j0 % 4 == 0) of row q as a nibble: from the bitmap when the system has one, else from its rank plane
+__device__ __forceinline__ uint32_t valid_nibble(const NsfArgs& a, int s, int q, size_t rowoff, int j0) {
+    if (a.vbits[s]) return (a.vbits[s][(size_t)q * a.ldb + (j0 >> 5)] >> (j0 & 31)) & 0xfu;
+    if (!a.ranks[s]) return 0xfu;
+    const int4 r = *reinterpret_cast<const int4*>(a.ranks[s] + rowoff + j0);
+    return (r.x >= 0 ? 1u : 0u) | (r.y >= 0 ? 2u : 0u) | (r.z >= 0 ? 4u : 0u) | (r.w >= 0 ? 8u : 0u);
+}
+
 // K4.  One workgroup of T threads per query; thread t owns columns {4*(t + T*i) .. +3}, i < E4.
 //   * the accumulator and the CURRENT system's row live in registers (2*4*E4 VGPRs);
 //   * DMA = true: the NEXT system's row streams HBM -> LDS by global_load_lds (no VGPRs, asynchronous) while the
@@ -281,7 +291,8 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
     };
     auto take_row = [&](int s) {   // current row -> registers (+ validity mask)
         const float* __restrict__ x = a.planes[s] + rowoff;
-        const int32_t* __restrict__ rk = (VALID && a.ranks[s]) ? a.ranks[s] + rowoff : nullptr;
+        const int32_t* __restrict__ rk = (VALID && a.ranks[s] && !a.vbits[s]) ? a.ranks[s] + rowoff : nullptr;
+        const bool partial = VALID && (a.ranks[s] || a.vbits[s]);
         ok = 0ull;
         if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own pieces have landed
 #pragma unroll
@@ -295,10 +306,7 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
                     v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
                     const int rem = N - j0;
                     m = rem >= 4 ? 0xfu : ((1u << rem) - 1u);
-                    if (VALID && rk) {
-                        const int4 r = *reinterpret_cast<const int4*>(rk + j0);
-                        m &= (r.x >= 0 ? 1u : 0u) | (r.y >= 0 ? 2u : 0u) | (r.z >= 0 ? 4u : 0u) | (r.w >= 0 ? 8u : 0u);
-                    }
+                    if (partial) m &= valid_nibble(a, s, q, rowoff, j0);
                 } else {
                     v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
                 }
@@ -307,7 +315,8 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
                 for (int c = 0; c < 4; ++c) {
                     const bool in = j0 + c < N;
                     v[i][c] = in ? x[j0 + c] : 0.0f;
-                    if (in && (!(VALID && rk) || rk[j0 + c] >= 0)) m |= 1u << c;
+                    const bool listed = !partial || (a.vbits[s] ? ((a.vbits[s][(size_t)q * a.ldb + ((j0 + c) >> 5)] >> ((j0 + c) & 31)) & 1u) != 0u : rk[j0 + c] >= 0);
+                    if (in && listed) m |= 1u << c;
                 }
             }
             ok |= (uint64_t)m << (4 * i);
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(256) void fuse_nsf_elem_kernel(NsfArgs a, const flo
         float acc = 0.0f;
         bool present = false;
         for (int s = 0; s < a.S; ++s) {
-            if (a.ranks[s] && a.ranks[s][rowoff + j] < 0) continue;
+            if (a.vbits[s] ? !((a.vbits[s][(size_t)q * a.ldb + (j >> 5)] >> (j & 31)) & 1u) : (a.ranks[s] && a.ranks[s][rowoff + j] < 0)) continue;
             float t = transform<NORM>(a.planes[s][rowoff + j], stat_a[s * Q + q], stat_b[s * Q + q], a.distr[s], a.P[s]);
             float prod = t * a.w[s];
             acc = acc + prod;
@@ -476,15 +485,13 @@ __global__ __launch_bounds__(256) void fuse_nsf_elem4_kernel(NsfArgs a, const fl
     bool present[4] = {false, false, false, false};
     for (int s = 0; s < a.S; ++s) {
         typedef float f4v __attribute__((ext_vector_type(4)));
-        typedef int i4v __attribute__((ext_vector_type(4)));
         const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.planes[s] + rowoff + j0));   // streamed once
         const float v[4] = {f.x, f.y, f.z, f.w};
-        int r[4] = {0, 0, 0, 0};
-        if (a.ranks[s]) { const i4v t = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(a.ranks[s] + rowoff + j0)); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+        const uint32_t nib = valid_nibble(a, s, q, rowoff, j0);
         const float sa = stat_a ? stat_a[s * Q + q] : 0.f, sb = stat_b ? stat_b[s * Q + q] : 0.f, w = a.w[s];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if (r[c] >= 0 && j0 + c < a.N) {
+            if (((nib >> c) & 1u) && j0 + c < a.N) {
                 const float t = transform<NORM>(v[c], sa, sb, a.distr[s], a.P[s]);
                 const float prod = t * w;
                 acc[c] = acc[c] + prod;
@@ -545,7 +552,11 @@ __device__ __forceinline__ int nearest_entry_lut(const TableSys& y, float s) {
     if (lo < 0) return 0;
     const float dl = fabsf(y.tab[lo] - s);
     if (lo + 1 < P && fabsf(y.tab[lo + 1] - s) < dl) return lo + 1;
-    return (int)y.first[lo];
+    // first minimum of the ROUNDED distances (torch.argmin over |distr - s| in float32): skip the duplicates of tab[lo] in one
+    // step, then keep walking while a smaller entry's distance rounds to the same float (|s| >> the table's spacing)
+    int k = (int)y.first[lo];
+    while (k > 0 && fabsf(y.tab[k - 1] - s) == dl) --k;
+    return k;
 }
 
 template <bool NCE, int TPB>
@@ -588,7 +599,6 @@ __global__ __launch_bounds__(TPB) void fuse_nsf_table_kernel(NsfArgs a, TableArg
     const int chunks = (a.N + 4 * TPB - 1) / (4 * TPB);
     const long long items = (long long)Q * chunks;
     typedef float f4v __attribute__((ext_vector_type(4)));
-    typedef int i4v __attribute__((ext_vector_type(4)));
     for (long long it = blockIdx.x; it < items; it += gridDim.x) {
         const int q = (int)(it / chunks), c = (int)(it - (long long)q * chunks);
         const size_t rowoff = (size_t)q * a.ld;
@@ -599,15 +609,14 @@ __global__ __launch_bounds__(TPB) void fuse_nsf_table_kernel(NsfArgs a, TableArg
         for (int s = 0; s < a.S; ++s) {
             const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.planes[s] + rowoff + j0));   // streamed once
             const float v[4] = {f.x, f.y, f.z, f.w};
-            int r[4] = {0, 0, 0, 0};
-            if (a.ranks[s]) { const i4v rr = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(a.ranks[s] + rowoff + j0)); r[0] = rr.x; r[1] = rr.y; r[2] = rr.z; r[3] = rr.w; }
+            const uint32_t nib = valid_nibble(a, s, q, rowoff, j0);
             const int P = a.P[s];
             const float w = a.w[s];
             const float inv_w = sys_inv[s];
             const TableSys y{tabs + t.off[s], lut + s * (LUT_B + 1), first + t.off[s], sys_lo[s], inv_w, P, inv_w != 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (r[e] >= 0 && j0 + e < a.N) {
+                if (((nib >> e) & 1u) && j0 + e < a.N) {
                     const int k = nearest_entry_lut(y, v[e]);
                     const float tr = val[t.off[s] + k];
                     const float prod = tr * w;
@@ -870,7 +879,7 @@ static int launch_nsf(const NsfArgs& a, int Q, float* fused, hipStream_t st) {
     bool valid = false;
     for (int s = 0; s < a.S; ++s) {
         al = al && ((uintptr_t)a.planes[s] % 16 == 0) && (!a.ranks[s] || (uintptr_t)a.ranks[s] % 16 == 0);
-        valid = valid || a.ranks[s];
+        valid = valid || a.ranks[s] || a.vbits[s];
     }
 #define FZ_NSF_CASE(TT, E4)                                                                           \
     if (a.N <= TT * E4 * 4) {                                                                         \
@@ -886,9 +895,32 @@ static int launch_nsf(const NsfArgs& a, int Q, float* fused, hipStream_t st) {
     return 1;  // row too long for the register-resident kernel
 }
 
+// one wave per 64 columns: ballot of "rank >= 0"
+__global__ __launch_bounds__(256) void rank_to_bitmap_kernel(const int32_t* __restrict__ rank, int N, int ld, uint32_t* __restrict__ bits, int ldb) {
+    const int row = blockIdx.y;
+    const int j = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63);
+    if ((j & ~63) >= ldb * 32) return;   // wave-uniform
+    const bool v = j < N && rank[(size_t)row * ld + j] >= 0;
+    const unsigned long long bal = __ballot(v);
+    if ((threadIdx.x & 63) == 0) {
+        bits[(size_t)row * ldb + (j >> 5)] = (uint32_t)bal;
+        if ((j >> 5) + 1 < ldb) bits[(size_t)row * ldb + (j >> 5) + 1] = (uint32_t)(bal >> 32);
+    }
+}
+
+extern "C" int fz_rank_to_bitmap(const int32_t* rank, int rows, int N, int ld, uint32_t* bits, int ldb, void* stream) {
+    if (rows < 0 || N < 0 || ld < N || ldb * 32 < N) return FZ_ERR_ARG;
+    if (rows == 0 || N == 0) return FZ_OK;
+    if (!rank || !bits) return FZ_ERR_ARG;
+    dim3 grid((unsigned)((ldb * 32 + 255) / 256), (unsigned)rows);
+    rank_to_bitmap_kernel<<<grid, 256, 0, as_stream(stream)>>>(rank, N, ld, bits, ldb);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
 extern "C" int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q,
-                               int N, int ld, int norm, const float* const* distr_h, const int32_t* P_h, float* fused,
-                               void* stream) {
+                               int N, int ld, int norm, const float* const* distr_h, const int32_t* P_h,
+                               const uint32_t* const* valid_bits_h, int ldb, float* fused, void* stream) {
     if (!planes_h || !w_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
     if (norm == FZ_NORM_NONE) return FZ_ERR_ARG;  // float64 passthrough lives in fz_fuse_none_f64
     if (norm < FZ_NORM_MINMAX || norm > FZ_NORM_NCE) return FZ_ERR_ARG;
@@ -902,11 +934,14 @@ extern "C" int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* cons
         if (!planes_h[s]) return FZ_ERR_ARG;
         a.planes[s] = planes_h[s];
         a.ranks[s] = ranks_h ? ranks_h[s] : nullptr;
+        a.vbits[s] = valid_bits_h ? valid_bits_h[s] : nullptr;
         a.distr[s] = needs_distr ? distr_h[s] : nullptr;
         a.P[s] = needs_distr ? P_h[s] : 0;
         if (needs_distr && (!a.distr[s] || a.P[s] <= 0)) return FZ_ERR_ARG;
         a.w[s] = (float)w_h[s];
     }
+    a.ldb = ldb;
+    if (valid_bits_h && ldb * 32 < N) return FZ_ERR_ARG;
     hipStream_t st = as_stream(stream);
     int too_long = 1;
     switch (norm) {
@@ -930,7 +965,8 @@ extern "C" int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* cons
 // general-N two-pass variant (statistics supplied by the caller, e.g. from fz_row_stats_f32)
 extern "C" int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S,
                                      int Q, int N, int ld, int norm, const float* const* distr_h, const int32_t* P_h,
-                                     const float* stat_a, const float* stat_b, float* fused, void* stream) {
+                                     const float* stat_a, const float* stat_b, const uint32_t* const* valid_bits_h, int ldb,
+                                     float* fused, void* stream) {
     if (!planes_h || !w_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
     if (norm < FZ_NORM_MINMAX || norm > FZ_NORM_NCE) return FZ_ERR_ARG;
     if (Q == 0 || N == 0) return FZ_OK;                 // empty tensors carry null pointers
@@ -946,10 +982,13 @@ extern "C" int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t
         if (!planes_h[s]) return FZ_ERR_ARG;
         a.planes[s] = planes_h[s];
         a.ranks[s] = ranks_h ? ranks_h[s] : nullptr;
+        a.vbits[s] = valid_bits_h ? valid_bits_h[s] : nullptr;
         a.distr[s] = needs_distr ? distr_h[s] : nullptr;
         a.P[s] = needs_distr ? P_h[s] : 0;
         a.w[s] = (float)w_h[s];
     }
+    a.ldb = ldb;
+    if (valid_bits_h && ldb * 32 < N) return FZ_ERR_ARG;
     hipStream_t st = as_stream(stream);
     bool vec = (ld % 4 == 0) && ((uintptr_t)fused % 16 == 0);
     for (int s = 0; s < S; ++s) vec = vec && ((uintptr_t)a.planes[s] % 16 == 0) && (!a.ranks[s] || (uintptr_t)a.ranks[s] % 16 == 0);

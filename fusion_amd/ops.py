@@ -321,12 +321,14 @@ def minmax_from_order(scores: torch.Tensor, order: torch.Tensor, lens: torch.Ten
 def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None, weights, norm: str,
              distr: list[torch.Tensor] | None = None, out: torch.Tensor | None = None,
              orders: list[torch.Tensor] | None = None, lens: torch.Tensor | None = None,
-             stats: tuple[torch.Tensor, torch.Tensor] | None = None) -> torch.Tensor:
+             stats: tuple[torch.Tensor, torch.Tensor] | None = None,
+             valid_bits: list[torch.Tensor | None] | None = None) -> torch.Tensor:
     """normalise -> weight -> sum in one HBM pass (hybrid.py:212-214,254-280,291,301-304).
     orders (+ lens [S, Q]): the systems' order planes, when they are ranked -- min-max then takes every list's minimum and
     maximum from its two ends and the fusion is one flat streaming pass (same bits as the reducing kernel).
     stats = (a, b): the row statistics [S*Q] fp32 each (min / max, or mean / unbiased std), when the caller has them -- e.g. from
-    the sort that ranked the systems (sort_rows_desc(stats_out=...)): the fusion is then one flat streaming pass."""
+    the sort that ranked the systems (sort_rows_desc(stats_out=...)): the fusion is then one flat streaming pass.
+    valid_bits[s] (optional): the validity of system s as a bitmap (rank_to_bitmap), read instead of its rank plane."""
     for p in planes:
         _dev(p, torch.float32, "fuse_nsf(planes)")
     S = len(planes)
@@ -347,6 +349,16 @@ def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None
         _need(tuple(out.shape) == (Q, N) and (Q <= 1 or _ld(out) == ld), f"fuse_nsf(out): expected a [{Q}, {N}] plane with row stride {ld}")
     fused = out if out is not None else torch.empty((max(Q, 1), ld), dtype=torch.float32, device=dev)[:Q, :N]
     w = (C.c_double * S)(*[float(x) for x in weights])
+    vb, ldb = None, 0
+    if valid_bits is not None and any(b is not None for b in valid_bits):
+        _need(len(valid_bits) == S, f"fuse_nsf: {S} planes but {len(valid_bits)} validity bitmaps")
+        for b in valid_bits:
+            if b is not None:
+                _dev(b, torch.int32, "fuse_nsf(valid_bits)")
+                _need(b.dim() == 2 and b.shape[0] == Q and b.is_contiguous() and b.shape[1] * 32 >= N, "fuse_nsf(valid_bits): expected contiguous [Q, >= N/32] int32 bitmaps")
+        ldbs = {int(b.shape[1]) for b in valid_bits if b is not None}
+        _need(len(ldbs) == 1, "fuse_nsf(valid_bits): bitmaps must share their row stride")
+        vb, ldb = _ptr_array(valid_bits), ldbs.pop()
     dptr, P = None, None
     if norm in ("percentile-rank", "normal-curve-equivalent"):
         if distr is None or any(d is None for d in distr):
@@ -362,7 +374,7 @@ def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None
             _dev(x, torch.float32, "fuse_nsf(stats)")
             _need(x.numel() == S * Q and x.is_contiguous(), f"fuse_nsf(stats): need contiguous tensors of {S * Q} entries")
         check(lib.fz_fuse_nsf_stats_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm],
-                                        dptr, P, _ptr(sa), _ptr(sb), _ptr(fused), _stream(planes[0])), "fz_fuse_nsf_stats_f32")
+                                        dptr, P, _ptr(sa), _ptr(sb), vb, ldb, _ptr(fused), _stream(planes[0])), "fz_fuse_nsf_stats_f32")
         return fused
     if norm == "min-max" and orders is not None and Q > 0 and N > 0:
         _need(len(orders) == S, f"fuse_nsf: {S} planes but {len(orders)} order planes")
@@ -386,23 +398,37 @@ def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None
         check(lib.fz_minmax_from_orders_f32(_ptr_array(planes), _ptr_array(orders), _ptr(lens), S, Q, N, ld, _ptr(sa), _ptr(sb), _stream(planes[0])),
               "fz_minmax_from_orders_f32")
         check(lib.fz_fuse_nsf_stats_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm],
-                                        dptr, P, _ptr(sa), _ptr(sb), _ptr(fused), _stream(planes[0])), "fz_fuse_nsf_stats_f32")
+                                        dptr, P, _ptr(sa), _ptr(sb), vb, ldb, _ptr(fused), _stream(planes[0])), "fz_fuse_nsf_stats_f32")
         return fused
     rc = lib.fz_fuse_nsf_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm], dptr, P,
-                             _ptr(fused), _stream(planes[0]))
+                             vb, ldb, _ptr(fused), _stream(planes[0]))
     if rc == _lib.FZ_ERR_UNSUPPORTED:
         # rows longer than the register-resident kernel holds (N > 32768): statistics pass + elementwise pass
         sa = torch.zeros(S * Q, dtype=torch.float32, device=dev)
         sb = torch.zeros(S * Q, dtype=torch.float32, device=dev)
         if norm in ("min-max", "z-score"):
             for s in range(S):
+                _need(vb is None or valid_bits[s] is None or (ranks is not None and ranks[s] is not None),
+                      "fuse_nsf: rows longer than 32768 take their statistics over the rank planes: pass ranks next to valid_bits")
                 a, b = row_stats(planes[s], None if ranks is None else ranks[s], norm)
                 sa[s * Q:(s + 1) * Q] = a
                 sb[s * Q:(s + 1) * Q] = b
         rc = lib.fz_fuse_nsf_stats_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm],
-                                       dptr, P, _ptr(sa), _ptr(sb), _ptr(fused), _stream(planes[0]))
+                                       dptr, P, _ptr(sa), _ptr(sb), vb, ldb, _ptr(fused), _stream(planes[0]))
     check(rc, "fz_fuse_nsf_f32")
     return fused
+
+
+def rank_to_bitmap(rank: torch.Tensor) -> torch.Tensor:
+    """Validity bitmap of a rank plane: [Q, ceil(N / 64) * 2] int32, bit (j & 31) of word j >> 5 = (rank[q, j] >= 0).  Built once per
+    partial system; the nsf fusion passes then read 1 bit per document instead of the 4-byte rank."""
+    _dev(rank, torch.int32, "rank_to_bitmap(rank)")
+    rank = as_plane(rank)
+    Q, N = rank.shape
+    ldb = max(2, (N + 63) // 64 * 2)
+    bits = torch.zeros((max(Q, 1), ldb), dtype=torch.int32, device=rank.device)[:Q]
+    check(_lib.lib().fz_rank_to_bitmap(_ptr(rank), Q, N, _ld(rank), _ptr(bits), ldb, _stream(rank)), "fz_rank_to_bitmap")
+    return bits
 
 
 def fuse_none(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None, weights) -> torch.Tensor:

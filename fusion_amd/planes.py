@@ -29,6 +29,15 @@ class RankedSystem:
     score_sorted: bool = False    # every list is in descending order of its float32 scores (rankers: yes; host lists: checked)
     zstats: tuple | None = None   # (mean [Q], unbiased std [Q]) fp32 of the FULL rows, a by-product of the ranking sort (z-score)
 
+    def valid_bits(self) -> torch.Tensor | None:
+        """Validity of a partial system as a bitmap (1 bit per document instead of the 4-byte rank), built once and kept."""
+        if self.full:
+            return None
+        if self.meta.get("valid_bits") is None:
+            from . import ops
+            self.meta["valid_bits"] = ops.rank_to_bitmap(self.rank)
+        return self.meta["valid_bits"]
+
     @property
     def Q(self) -> int:
         return self.scores.shape[0]

@@ -193,7 +193,8 @@ class Aggregator:
             raise ValueError("device systems must be planes over the same corpus")
         dev = S[0].scores.device
         all_full = all(s.full for s in S)
-        ranks = None if all_full else [None if s.full else s.rank for s in S]   # validity: only the partial lists need their rank plane read
+        ranks = None if all_full else [None if s.full else s.rank for s in S]   # validity: only the partial lists carry any
+        vbits = None if all_full else [s.valid_bits() for s in S]              # ... and the nsf passes read it as 1 bit per document
 
         if method in ("bcf", "rrf"):
             lens = torch.stack([s.lens for s in S]).contiguous()
@@ -217,9 +218,9 @@ class Aggregator:
                 elif normalization == "min-max" and all(s.score_sorted for s in S):
                     # score-sorted lists: min / max are the two ends of every list, no row reduction
                     fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, orders=[s.order for s in S],
-                                         lens=torch.stack([s.lens for s in S]).contiguous())
+                                         lens=torch.stack([s.lens for s in S]).contiguous(), valid_bits=vbits)
                 else:           # the statistics are taken over the VALUES, whatever the list order (hybrid.py:255-262)
-                    fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, distr)
+                    fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, distr, valid_bits=vbits)
             else:                                           # 'none' / unknown string: raw Python floats, float64 (hybrid.py:280)
                 fused = ops.fuse_wsum([s.scores if s.scores64 is None else s.scores64 for s in S], ranks, w)
         else:                                               # unknown method: raw scores are summed (hybrid.py:203-218)

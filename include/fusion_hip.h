@@ -129,14 +129,19 @@ int fz_row_stats_f32(const float* scores, const int32_t* rank, int rows, int N, 
  * nullable = all docs present; distr_h needed only for PERCENTILE/NCE: ascending fp32 tables of
  * P_h[s] entries, hybrid.py:272).  w_h: HOST fp64 weights (rounded to fp32 inside).
  * norm = FZ_NORM_NONE is rejected here: use fz_fuse_none_f64 (the reference stays in float64). */
+/* valid_bits_h (nullable, entries nullable): per system a validity BITMAP [Q][ldb] uint32 (bit j & 31 of word j >> 5 = doc j is in
+ * the list) from fz_rank_to_bitmap -- the fusion passes then read 1 bit instead of a 4-byte rank per document; a system with a
+ * bitmap needs no ranks_h entry. */
+int fz_rank_to_bitmap(const int32_t* rank, int rows, int N, int ld, uint32_t* bits, int ldb, void* stream);
 int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
-                    int ld, int norm, const float* const* distr_h, const int32_t* P_h, float* fused, void* stream);
+                    int ld, int norm, const float* const* distr_h, const int32_t* P_h, const uint32_t* const* valid_bits_h, int ldb,
+                    float* fused, void* stream);
 /* Same result for rows longer than the one-pass kernel holds in registers (N > 32768: fz_fuse_nsf_f32 returns
  * FZ_ERR_UNSUPPORTED): min-max / z-score statistics are supplied by the caller, [S][Q] fp32 each, from fz_row_stats_f32
  * (nullable for the other normalisations).  Two passes over HBM. */
 int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
                           int ld, int norm, const float* const* distr_h, const int32_t* P_h, const float* stat_a,
-                          const float* stat_b, float* fused, void* stream);
+                          const float* stat_b, const uint32_t* const* valid_bits_h, int ldb, float* fused, void* stream);
 /* min / max of RANKED lists without a reduction: a list sorted by score has its maximum first and its minimum last.
  * mn[row] = scores[row][order[row][len-1]], mx[row] = scores[row][order[row][0]], len = lens[row] (NULL = N); an empty list gives
  * 0, 0; a NaN at the head makes both NaN (torch.min / torch.max propagate it, hybrid.py:254-258).  With these,

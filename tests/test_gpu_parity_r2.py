@@ -439,3 +439,46 @@ def test_sharded_search_first_chunk_streams_after_an_exact_head(ops, oracle):
     es, ei = oracle.topk_rows(S, k, id_base=123)
     np.testing.assert_array_equal(s.cpu().numpy(), es)
     np.testing.assert_array_equal(i.cpu().numpy(), ei)
+
+
+# ---- partial lists: validity as a bitmap ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("Q,N", [(3, 70), (4, 1000), (2, 27942), (2, 40000)])
+@pytest.mark.parametrize("norm", ["min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent"])
+def test_fuse_nsf_validity_bitmap_equals_rank_planes(ops, oracle, Q, N, norm):
+    """The nsf fusion reading the partial systems' validity from bitmaps (fz_rank_to_bitmap) == reading their rank planes == the
+    oracle (bit for bit between the two device forms; oracle within the norm's tolerance)."""
+    rng = np.random.default_rng(Q * 31 + N)
+    S = 3
+    planes = [rng.normal(s, 1.0 + s, (Q, N)).astype(np.float32) for s in range(S)]
+    ranks = []
+    for s in range(S):
+        _, _, r = oracle.sort_rows_desc(planes[s], want_rank=True)
+        if s >= 1:
+            keep = int(N * (0.6 if s == 1 else 0.25)) or 1
+            r = np.where(r < keep, r, -1).astype(np.int32)
+        ranks.append(r)
+    P = 101
+    distr = [np.quantile(p, np.linspace(0, 1, P)).astype(np.float32) for p in planes]
+    w = [0.2, 0.5, 0.3]
+    tabled = norm in ("percentile-rank", "normal-curve-equivalent")
+    dp = [ops.alloc_plane(Q, N, torch.float32, "cuda") for _ in range(S)]
+    for t, p in zip(dp, planes):
+        t.copy_(torch.from_numpy(p))
+    dr = []
+    for r in ranks:
+        t = ops.alloc_plane(Q, N, torch.int32, "cuda"); t.copy_(torch.from_numpy(r)); dr.append(t)
+    dd = [dev(d) for d in distr] if tabled else None
+    a = ops.fuse_nsf(dp, [None, dr[1], dr[2]], w, norm, dd).cpu().numpy()
+    bits = [None, ops.rank_to_bitmap(dr[1]), ops.rank_to_bitmap(dr[2])]
+    for b, r in zip(bits[1:], ranks[1:]):
+        got = np.unpackbits(b.cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :N].astype(bool)
+        assert np.array_equal(got, r >= 0)
+    b = ops.fuse_nsf(dp, [None, dr[1], dr[2]], w, norm, dd, valid_bits=bits).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    if N <= 32768 or norm not in ("min-max", "z-score"):    # (the two-pass form for longer rows takes its statistics over the rank planes)
+        c = ops.fuse_nsf(dp, None, w, norm, dd, valid_bits=bits).cpu().numpy()     # no rank planes at all
+        np.testing.assert_array_equal(a, c)
+    e = oracle.fuse_nsf(planes, [None, ranks[1], ranks[2]], w, norm, distr if tabled else None)
+    tol = {"min-max": 0.0, "percentile-rank": 0.0, "z-score": 2e-6, "arctan": 1e-6, "normal-curve-equivalent": 1e-4}[norm]
+    fin = np.isfinite(e)
+    assert np.array_equal(np.isfinite(a), fin) and np.max(np.abs(a[fin] - e[fin]), initial=0.0) <= tol
