@@ -65,6 +65,8 @@ _PROTOS = {
     "fz_topk_update_workspace_bytes": (_sz, [_i, _i, _i]),
     "fz_topk_update_f32": (_i, [_vp, _i, _i, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "fz_topk_allgather_workspace_bytes": (_sz, [_i, _i, _i]),
+    "fz_topk_allgather": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "fz_bm25_doc_norms_f64": (_i, [_vp, _i, _d, _d, _d, _vp, _vp]),
     "fz_bm25_scores_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "fz_tune_max_gold": (_i, []),

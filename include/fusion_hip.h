@@ -193,6 +193,14 @@ int fz_topk_update_f32(const float* scores, int rows, int n, int ld, int64_t id_
 /* merge G per-shard lists [G][rows][k] (as all-gathered over RCCL) into the global top-k [rows][k] */
 int fz_topk_merge(const float* in_scores, const int64_t* in_ids, int G, int rows, int k, float* out_scores, int64_t* out_ids,
                   void* stream);
+/* C1 -- the ONE collective of the corpus-sharded configuration (spec: the heap merge across corpus chunks of
+ * sentence_transformers.py:346-364, here across GPUs): ncclAllGather of this rank's [Q][k] (fp32 score, int64 id) lists over
+ * `rccl_comm` (an ncclComm_t of `world` ranks, one per GPU) into the workspace, then the local G-way merge -- identical on
+ * every rank, ties by ascending global id.  RCCL is resolved at run time (the host process's copy first, then librccl.so);
+ * FZ_ERR_UNSUPPORTED when there is none.  Workspace: fz_topk_allgather_workspace_bytes(world, Q, k) device bytes. */
+size_t fz_topk_allgather_workspace_bytes(int world, int Q, int k);
+int fz_topk_allgather(const float* local_scores, const int64_t* local_ids, int Q, int k, void* rccl_comm, int world,
+                      float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- A1: BM25 scoring on device, bm25.py:149-156 -------------------------------------- */
 /* scores[q][j] (fp64) = sum over query terms in query order of idf*tf*(k1+1)/(tf+k1*(1-b+b*dl/avgdl)).

@@ -482,3 +482,50 @@ def test_fuse_nsf_validity_bitmap_equals_rank_planes(ops, oracle, Q, N, norm):
     tol = {"min-max": 0.0, "percentile-rank": 0.0, "z-score": 2e-6, "arctan": 1e-6, "normal-curve-equivalent": 1e-4}[norm]
     fin = np.isfinite(e)
     assert np.array_equal(np.isfinite(a), fin) and np.max(np.abs(a[fin] - e[fin]), initial=0.0) <= tol
+
+
+# ---- C1 behind the C ABI: fz_topk_allgather over a real RCCL communicator (one rank: all a one-GPU box can host) ----------
+def test_topk_allgather_c_abi_with_a_one_rank_rccl_communicator(ops, oracle):
+    import ctypes as C
+    import glob
+    from fusion_amd import _lib
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["librccl.so", "/opt/rocm/lib/librccl.so"]
+    rccl = None
+    for c in cands:
+        try:
+            rccl = C.CDLL(c, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    assert rccl is not None, "no RCCL library on this box"
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        rng = np.random.default_rng(9)
+        Q, k = 7, 50
+        sc = -np.sort(-rng.normal(0, 1, (Q, k)).astype(np.float32), axis=1)
+        ids = np.sort(rng.choice(10**6, (Q, k), replace=False), axis=1).astype(np.int64)
+        ls, li = dev(sc), dev(ids)
+        os_, oi = torch.empty_like(ls), torch.empty_like(li)
+        L = _lib.lib()
+        wsb = int(L.fz_topk_allgather_workspace_bytes(1, Q, k))
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = L.fz_topk_allgather(C.c_void_p(ls.data_ptr()), C.c_void_p(li.data_ptr()), Q, k, comm, 1, C.c_void_p(os_.data_ptr()),
+                                 C.c_void_p(oi.data_ptr()), C.c_void_p(ws.data_ptr()), wsb, st)
+        assert rc == 0, L.fz_strerror(rc)
+        torch.cuda.synchronize()
+        es, ei = oracle.topk_merge(sc[None], ids[None])
+        np.testing.assert_array_equal(os_.cpu().numpy(), es)
+        np.testing.assert_array_equal(oi.cpu().numpy(), ei)
+        assert L.fz_topk_allgather(None, None, 1, 1, comm, 1, None, None, None, 0, st) == _lib.FZ_ERR_ARG
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
