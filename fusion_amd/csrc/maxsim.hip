@@ -66,6 +66,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
     // lane l holds B[k = 8*(l>>5) + j][col = l&31] = Qtok[token l&31 of the block][dim 16*ks + 8*(l>>5) + j]
     const int blk0 = (qg * MS_WAVES + w) * MS_BLOCKS_PER_WAVE;   // global query-block index of this wave's first block
     const int nblk_total = a.Q * a.QB;
+    const bool wave_has_queries = blk0 < nblk_total;   // wave-uniform
     f16x8 bq[MS_BLOCKS_PER_WAVE][8];
 #pragma unroll
     for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) {
@@ -186,6 +187,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
         const int meta = metas[gi];
         const int rows_valid = (meta >> 8) & 0xff;
         const bool last_tile_of_doc = (meta >> 16) & 1;
+        // a wave whose four query blocks all lie past the last query (the tail of the last query group: at Q = 195, six of its
+        // eight waves) has nothing to multiply: it only keeps feeding the ring and meeting the barriers
+        if (!wave_has_queries) continue;
 
         // ---- A fragments from LDS: lane l -> row l&31, k = 16*ks + 8*(l>>5) .. +7 ------------
         f16x8 af[8];
