@@ -7,14 +7,16 @@
 //   fz_dot_scores_f32       S = Qn . Dn^T with v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate:
 //                           the 1e-4 score contract rules out bf16/fp16 inputs, SURVEY 7 "hard parts")
 //
-// GEMM structure: 128x128 output tile per 256-thread workgroup (2x2 waves, each 64x64 = 2x2 MFMA tiles,
-// 64 accumulator VGPRs), K-step 32, both operands K-contiguous ("NT").  Tiles are staged global -> registers
-// -> LDS (double-buffered, rows padded to 36 floats so that ds_read_b128 of 16 consecutive rows is
-// bank-conflict-free).  Within each group of 8 k's, lanes 0-31 take k 0..3 and lanes 32-63 take k 4..7 as one
-// ds_read_b128 per operand tile; MFMA #kk then contracts {k=kk, k=4+kk}: the permutation is the same on both
-// operands, so the sum is unchanged.  Workgroup -> tile mapping is XCD-aware: the QB query blocks of one
-// corpus tile run back-to-back on one XCD (blockIdx % 8), so a corpus tile is fetched from HBM once and hit
-// in that XCD's L2 afterwards.
+// GEMM structure: 128x128 output tile per 256-thread workgroup (2x2 waves, each 64x64 = 2x2 MFMA tiles, 64 accumulator
+// VGPRs), K-step 32, both operands K-contiguous ("NT").  The grid is persistent (two workgroups per CU) and each workgroup
+// runs its tiles as ONE stream of k-tiles: HBM -> registers two k-tiles ahead, registers -> LDS one k-tile ahead (rows padded
+// to 36 floats so that ds_read_b128 of 16 consecutive rows is bank-conflict-free), fragments LDS -> registers one group of 8
+// k's ahead of the MFMAs.  Within each group of 8 k's, lanes 0-31 take k 0..3 and lanes 32-63 take k 4..7 as one ds_read_b128
+// per operand tile; MFMA #kk then contracts {k=kk, k=4+kk}: the permutation is the same on both operands, so the sum is
+// unchanged.  The k-loop carries no vector ALU work besides one 64-bit pointer bump per load and pair of k-tiles (a kernel
+// instantiation without the ragged-d masks serves d % 64 == 0).  Workgroup -> tile mapping is XCD-aware: the QB query
+// blocks of one corpus tile run back-to-back on one XCD (workgroup id % 8), so a corpus tile is fetched from HBM once and hit
+// in that XCD's L2 afterwards.  What each of these steps bought is in DESIGN.md section 5 (K1).
 #include <stdlib.h>
 
 #include "common.h"
@@ -62,122 +64,207 @@ struct GemmArgs {
     const float* B; int ldb;   // corpus   [N][ldb]
     float* C; int ldc;         // scores   [Q][ldc]
     int Q, N, d, QB, TN;
-    int full;                  // block ids < full run whole 128x128 tiles, the others 128x64 halves
+    int full, halves;          // tile ids < full are whole 128x128 tiles; then `halves` 128x64 half tiles (at most one per workgroup)
 };
 
-template <int BN, bool DB /* double-buffered LDS (2 workgroups/CU) vs single buffer (3/CU) */>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int row0, const int col0, float* lds) {
-    constexpr int NI = BN / 64;          // MFMA tiles per wave along N (wave tile = 64 x BN/2)
+// One workgroup's share of the tiles: ids first, first + step, ... below `end`, all of one shape (128 x BN).  The k-tiles of
+// ALL those tiles form one stream through the software pipeline: the operand loads of a tile's first two k-tiles are issued
+// during the last two k-tiles of the tile before it, and its score stores drain under the next tile's MFMAs -- a workgroup
+// pays the pipeline fill once per launch, not once per tile.
+template <int BN, bool RAGGED /* d is not a whole number of k-tile pairs */>
+__device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int first, const int end, const int step) {
+    constexpr int NI = BN / 64;          // 32x32 MFMA tiles per wave along N (wave tile = 64 x BN/2)
     constexpr int BROWS = BN / 32;       // staging float4 per thread for the corpus tile
-    // [buf][A: 128 rows | B: BN rows][LDT]
+    // [stage][A: 128 rows | B: BN rows][LDT]
     constexpr int BUF = (BM + BN) * LDT;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
 
-    // staging: thread -> (row = tid/8 + 32*i, k4 = tid%8)
-    const int srow = tid >> 3, sk = (tid & 7) * 4;
-    float4 ra[4], rb[BROWS];
-    auto gload = [&](int kt) {
-        const int k = kt * BK + sk;
-        const bool kin = k < g.d;  // d % 4 == 0: a float4 is entirely inside or outside
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int qa = row0 + srow + 32 * i;
-            ra[i] = (kin && qa < g.Q) ? *reinterpret_cast<const float4*>(g.A + (size_t)qa * g.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // tile id -> (query row, corpus column) of its corner; ids of the XCD padding decode to nothing
+    auto decode = [&](int b, int& row0, int& col0) -> bool {
+        int half = 0;
+        if (BN == 64) {   // workgroup i of the half-tile round: tile (i/16)*8 + i%8 (same XCD as i), half (i/8)%2
+            const int h = b - g.full;
+            b = g.full + ((h >> 4) << 3 | (h & 7));
+            half = (h >> 3) & 1;
         }
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i) {
-            const int nb = col0 + srow + 32 * i;
-            rb[i] = (kin && nb < g.N) ? *reinterpret_cast<const float4*>(g.B + (size_t)nb * g.ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const int x = b & 7, idx = b >> 3;
+        const int dt = (idx / g.QB) * 8 + x;     // 128-wide corpus tile
+        row0 = (idx % g.QB) * BM;
+        col0 = dt * 128 + half * 64;
+        return dt < g.TN;
     };
-    auto sstore = [&](int buf) {
-        float* As = lds + buf * BUF;
+    auto next_tile = [&](int b, int& row0, int& col0) -> int {   // first decodable id >= b of this workgroup's sequence, or -1
+        for (; b < end; b += step)
+            if (decode(b, row0, col0)) return b;
+        return -1;
+    };
+    int crow, ccol, lrow, lcol;
+    int cur_b = next_tile(first, crow, ccol);
+    if (cur_b < 0) return;
+
+    // staging: thread -> (row = tid/8 + 32*i, k4 = tid%8).  Rows past the end are clamped to the last one: their products are
+    // computed and never stored.  Global loads carry no predicate and sit under no branch (after a conditional load hipcc waits
+    // for ALL outstanding loads at the next use of any staging register); a k-tile past d re-reads the row's last float4 and is
+    // zeroed on its way into LDS.  The k-tile count is rounded up to even so that the two register stages and the two LDS stages
+    // keep their roles from one tile to the next.
+    const int srow = tid >> 3, sk = (tid & 7) * 4;
+    // addresses = wave-uniform tile base (SGPRs, advanced per k-tile on the scalar unit) + a 32-bit per-lane offset that is fixed
+    // for the whole tile: the k-loop spends no vector instruction on addressing
+    const float* abase;
+    const float* bbase;
+    int32_t oa[4], ob[BROWS];
+    auto point_at = [&](int row0, int col0) {
+        row0 = min(row0, g.Q - 1);         // (a half tile may start past the last corpus row)
+        col0 = min(col0, g.N - 1);
+        abase = g.A + (size_t)row0 * g.lda;
+        bbase = g.B + (size_t)col0 * g.ldb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oa[i] = (min(srow + 32 * i, g.Q - 1 - row0) * g.lda + sk) * 4;
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) ob[i] = (min(srow + 32 * i, g.N - 1 - col0) * g.ldb + sk) * 4;
+    };
+    const int KT = ((g.d + 2 * BK - 1) / (2 * BK)) * 2;
+    struct Stage { float4 a[4], b[BROWS]; };
+    auto gload = [&](Stage& r, int kt) __attribute__((always_inline)) {
+        const char* ab = reinterpret_cast<const char*>(abase + kt * BK);
+        const char* bb = reinterpret_cast<const char*>(bbase + kt * BK);
+        // d % 4 == 0: a float4 is entirely inside or outside.  Outside: step back to the row's last float4 (zeroed in sstore)
+        const int32_t back = RAGGED ? max(0, kt * BK + sk + 4 - g.d) * 4 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.a[i] = *reinterpret_cast<const float4*>(ab + (ptrdiff_t)(oa[i] - back));
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) r.b[i] = *reinterpret_cast<const float4*>(bb + (ptrdiff_t)(ob[i] - back));
+    };
+    auto sstore = [&](const Stage& r, int kt) __attribute__((always_inline)) {   // kt: the k-tile the registers hold
+        float* As = lds + (kt & 1) * BUF;
         float* Bs = As + BM * LDT;
+        const uint32_t m = RAGGED && kt * BK + sk >= g.d ? 0u : ~0u;
+        auto keep = [&](float4 v) {
+            if (!RAGGED) return v;
+            return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
+                               __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
+        };
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDT + sk) = ra[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDT + sk) = keep(r.a[i]);
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDT + sk) = rb[i];
+        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDT + sk) = keep(r.b[i]);
     };
 
     f32x16 acc[2][NI];
+    auto clear = [&]() {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    };
 
-    const int KT = (g.d + BK - 1) / BK;
-    gload(0);
-    sstore(0);
-    __syncthreads();
+    // fragments of one group of 8 k's: lanes 0-31 hold k 0..3, lanes 32-63 k 4..7 (see the header)
+    struct Frag { float4 a[2], b[NI]; };
     const int fr = lane & 31, fh = (lane >> 5) * 4;
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = DB ? (kt & 1) : 0;
-        if (kt + 1 < KT) gload(kt + 1);
-        const float* As = lds + buf * BUF + (wr * 64 + fr) * LDT + fh;
-        const float* Bs = lds + buf * BUF + BM * LDT + (wc * (BN / 2) + fr) * LDT + fh;
+    const int aoff = (wr * 64 + fr) * LDT + fh, boff = BM * LDT + (wc * (BN / 2) + fr) * LDT + fh;
+    auto fread = [&](Frag& f, int buf, int kg) __attribute__((always_inline)) {
+        const float* As = lds + buf * BUF + aoff + kg * 8;
+        const float* Bs = lds + buf * BUF + boff + kg * 8;
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            float4 a[2], b[NI];
+        for (int mi = 0; mi < 2; ++mi) f.a[mi] = *reinterpret_cast<const float4*>(As + mi * 32 * LDT);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const float4*>(As + mi * 32 * LDT + kg * 8);
+        for (int ni = 0; ni < NI; ++ni) f.b[ni] = *reinterpret_cast<const float4*>(Bs + ni * 32 * LDT);
+    };
+    auto fmma = [&](const Frag& f) __attribute__((always_inline)) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const float4*>(Bs + ni * 32 * LDT + kg * 8);
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        const float av = kk == 0 ? a[mi].x : kk == 1 ? a[mi].y : kk == 2 ? a[mi].z : a[mi].w;
-                        const float bv = kk == 0 ? b[ni].x : kk == 1 ? b[ni].y : kk == 2 ? b[ni].z : b[ni].w;
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
-                    }
-        }
-        if (DB) {
-            if (kt + 1 < KT) sstore(buf ^ 1);
-            __syncthreads();
-        } else {
-            __syncthreads();                       // every wave is done reading the tile
-            if (kt + 1 < KT) sstore(0);
-            __syncthreads();
-        }
-    }
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float av = kk == 0 ? f.a[mi].x : kk == 1 ? f.a[mi].y : kk == 2 ? f.a[mi].z : f.a[mi].w;
+                    const float bv = kk == 0 ? f.b[ni].x : kk == 1 ? f.b[ni].y : kk == 2 ? f.b[ni].z : f.b[ni].w;
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
+                }
+    };
 
-    // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // One k-tile of the pipeline = four fragment groups.  HBM -> registers runs TWO k-tiles ahead (two register stages: operand
+    // lines that miss in L2 are missed by every workgroup of the XCD at once, so nobody is left to cover a late load), registers
+    // -> LDS one k-tile ahead (two LDS stages).  The one barrier of a k-tile sits BEFORE its last group of MFMAs: by then every
+    // wave has read all its fragments of the current stage into registers and written its part of the next one, so right after
+    // the barrier it fetches the next stage's first fragments and covers that latency with the MFMAs it still owes.
+    Frag f0, f1;
+    Stage r0, r1;
+    auto ktile = [&](const int kt /* being multiplied */, const int kload /* fetched into rl */, const int kstore /* held by rs */, Stage& rl, const Stage& rs) __attribute__((always_inline)) {
+        const int cur = kt & 1;
+        gload(rl, kload);
+        fread(f1, cur, 1);
+        fmma(f0);
+        fread(f0, cur, 2);
+        fmma(f1);
+        // ONE fence per k-tile, here: without it hipcc sinks the HBM loads to the end of the k-tile and hoists the waits for them
+        // to its start (a zero-deep prefetch); with more of them it can no longer run the fragment reads ahead of the MFMAs.
+        __builtin_amdgcn_sched_barrier(0);
+        sstore(rs, kstore);                  // k-tile kt + 1, or the next tile's 0: into the stage read one k-tile ago, whose reads
+        fread(f1, cur, 3);                   // all ended before the previous barrier
+        fmma(f0);
+        __syncthreads();
+        fread(f0, cur ^ 1, 0);
+        fmma(f1);
+    };
+
+    point_at(crow, ccol);
+    gload(r0, 0);
+    gload(r1, 1);
+    sstore(r0, 0);
+    __syncthreads();
+    fread(f0, 0, 0);
+    while (true) {
+        clear();
+        for (int kt = 0; kt + 2 < KT; kt += 2) {
+            ktile(kt, kt + 2, kt + 1, r0, r1);
+            ktile(kt + 1, kt + 3, kt + 2, r1, r0);
+        }
+        // the last two k-tiles fetch the first two of the next tile (after the last tile: of the same one again, unused)
+        const int nxt = next_tile(cur_b + step, lrow, lcol);
+        if (nxt >= 0) point_at(lrow, lcol);
+        ktile(KT - 2, 0, KT - 1, r0, r1);
+        ktile(KT - 1, 1, 0, r1, r0);
+
+        // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        const bool whole = crow + BM <= g.Q && ccol + BN <= g.N;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int c = col0 + wc * (BN / 2) + ni * 32 + (lane & 31);
-            if (c < g.N) {
+            for (int ni = 0; ni < NI; ++ni) {
+                const int c = ccol + wc * (BN / 2) + ni * 32 + (lane & 31);
+                const int q0 = crow + wr * 64 + mi * 32 + 4 * (lane >> 5);
+                float* cp = g.C + (size_t)q0 * g.ldc + c;
+                if (whole) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int q = row0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (q < g.Q) g.C[(size_t)q * g.ldc + c] = acc[mi][ni][r];
+                    for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[mi][ni][r];
+                } else if (c < g.N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (q0 + (r & 3) + 8 * (r >> 2) < g.Q) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[mi][ni][r];
                 }
             }
-        }
+        if (nxt < 0) break;
+        cur_b = nxt; crow = lrow; ccol = lcol;
+    }
 }
 
-// Workgroup -> tile map.  XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch), so the QB query blocks of
-// one corpus tile are consecutive block ids on one XCD and the corpus tile is fetched from HBM once.  Blocks are
-// dispatched in id order; the first `g.full` ids run 128x128 tiles, the rest are the LAST partial round of tiles
-// cut into 128x64 halves, so that the tail occupies every CU for half a tile time instead of half the CUs for a
-// whole one (1792 equal tiles on 512 resident slots otherwise cost 4 rounds for 3.5 rounds of work).
-template <bool DB>
-__global__ __launch_bounds__(256, DB ? 2 : 3) void dot_scores_kernel(GemmArgs g) {
+// Workgroup -> tile map.  The grid is PERSISTENT: two workgroups per CU (LDS-bound), workgroup i takes tile ids i, i + grid, ...
+// XCD-aware: workgroups i and i+8 share an XCD (round-robin dispatch) and grid % 8 == 0, so the QB query blocks of one corpus tile
+// are consecutive ids on one XCD, run at about the same time, and the corpus tile is fetched from HBM once.  The first `g.full`
+// ids are 128x128 tiles; the rest is the LAST partial round cut into 128x64 halves, so that the tail occupies every CU for half a
+// tile time instead of half the CUs for a whole one (1792 equal tiles on 512 slots otherwise cost 4 rounds for 3.5 of work).
+template <bool RAGGED>
+__global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    int b = blockIdx.x, half = -1;
-    if (b >= g.full) { const int h = b - g.full; b = g.full + (h >> 1); half = h & 1; }
-    const int x = b & 7, idx = b >> 3;
-    const int qb = idx % g.QB;
-    const int dt = (idx / g.QB) * 8 + x;     // 128-wide corpus tile
-    if (dt >= g.TN) return;
-    if (half < 0) gemm_tile<128, DB>(g, qb * BM, dt * 128, lds);
-    else gemm_tile<64, DB>(g, qb * BM, dt * 128 + half * 64, lds);
+    gemm_stream<128, RAGGED>(g, lds, blockIdx.x, g.full, gridDim.x);
+    if ((int)blockIdx.x < g.halves) {
+        __syncthreads();                     // the half tile restarts the pipeline in stage 0
+        gemm_stream<64, RAGGED>(g, lds, g.full + blockIdx.x, g.full + blockIdx.x + 1, 1);
+    }
 }
 
 }  // namespace fz
@@ -206,17 +293,30 @@ extern "C" int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int 
     g.Q = Q; g.N = N; g.d = d;
     g.QB = (Q + BM - 1) / BM;
     g.TN = (N + 127) / 128;
-    const long B = 8L * g.QB * ((g.TN + 7) / 8);        // block ids of whole tiles (incl. the XCD padding, which exits at once)
-    const long slots = 512;                              // resident workgroups on 256 CUs (two double-buffered workgroups per CU)
+    const long B = 8L * g.QB * ((g.TN + 7) / 8);        // ids of whole tiles (incl. the XCD padding, which decodes to nothing)
+    static int cus[64];
+    int dev = 0;
+    FZ_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 64) return FZ_ERR_UNSUPPORTED;
+    if (!cus[dev]) FZ_HIP_TRY(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    const long slots = 2L * cus[dev] / 8 * 8;            // resident workgroups (two per CU), a multiple of the 8 XCDs
+    if (slots <= 0 || B > 0x3fffffffL) return FZ_ERR_UNSUPPORTED;
     long R = B % slots;                                  // the partial last round ...
     if (R > slots / 2 || B < slots) R = 0;               // ... is only worth halving when it is at most half full
     g.full = (int)(B - R);
-    const long nblk = (B - R) + 2 * R;
-    if (nblk > 0x7fffffffL) return FZ_ERR_UNSUPPORTED;
+    g.halves = (int)(2 * R);
+    const long nblk = B < slots ? B : slots;
     constexpr size_t lds_db = 2 * (BM + 128) * LDT * sizeof(float);
-    static unsigned long long lds_set = 0ull;
-    if (int rc = raise_lds_limit((const void*)dot_scores_kernel<true>, lds_db, lds_set)) return rc;
-    dot_scores_kernel<true><<<(unsigned)nblk, 256, lds_db, as_stream(stream)>>>(g);
+    // per-lane offsets are signed 32-bit byte offsets inside one 128-row operand tile
+    if (128.0 * ldq * 4 >= 2147483648.0 || 128.0 * ldd * 4 >= 2147483648.0) return FZ_ERR_UNSUPPORTED;
+    static unsigned long long lds_set[2] = {0ull, 0ull};
+    if (d % (2 * BK)) {
+        if (int rc = raise_lds_limit((const void*)dot_scores_kernel<true>, lds_db, lds_set[1])) return rc;
+        dot_scores_kernel<true><<<(unsigned)nblk, 256, lds_db, as_stream(stream)>>>(g);
+    } else {
+        if (int rc = raise_lds_limit((const void*)dot_scores_kernel<false>, lds_db, lds_set[0])) return rc;
+        dot_scores_kernel<false><<<(unsigned)nblk, 256, lds_db, as_stream(stream)>>>(g);
+    }
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

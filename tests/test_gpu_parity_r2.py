@@ -529,3 +529,20 @@ def test_topk_allgather_c_abi_with_a_one_rank_rccl_communicator(ops, oracle):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+# ---- score GEMM: several tiles per (persistent) workgroup ------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("Q,N,d", [(300, 70001, 100), (1024, 40000, 64), (129, 140000, 36)])
+def test_dot_scores_tile_stream_across_tiles(ops, Q, N, d):
+    """More tiles than resident workgroups: every workgroup walks several tiles in one k-tile stream, the operand loads of a
+    tile's first k-tiles are issued while the previous tile is still being multiplied, and the last partial round runs as half
+    tiles.  d = 100 / 36 end in a partial k-tile (zero-filled in LDS), d = 36 also in a k-tile that lies entirely past d.
+    Against float64 torch on the same operands; 2e-6 is the scoring tolerance of DESIGN section 4."""
+    g = torch.Generator(device="cuda").manual_seed(Q + N + d)
+    A = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
+    B = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
+    S = ops.dot_scores(A, B)
+    for r0 in range(0, Q, 128):
+        ref = A[r0:r0 + 128].double() @ B.double().t()
+        torch.testing.assert_close(S[r0:r0 + 128].double(), ref, rtol=0, atol=2e-6)
