@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfusion_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 FZ_OK, FZ_ERR_ARG, FZ_ERR_UNSUPPORTED, FZ_ERR_HIP, FZ_ERR_WORKSPACE = 0, -1, -2, -3, -4
 NORMS = {"min-max": 1, "z-score": 2, "arctan": 3, "percentile-rank": 4, "normal-curve-equivalent": 5}
@@ -72,6 +72,7 @@ _PROTOS = {
     "fz_tune_max_gold": (_i, []),
     "fz_gold_ranks_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fz_gold_ranks_f64w": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "fz_tune_metrics_f64": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "fz_attn_varlen_f32": (_i, [_vp, _i, _vp, _i, _i, _i, C.c_float, _vp, _i, _vp]),
     "fz_add_layernorm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, C.c_float, _i, _i, _vp, _i, _vp]),
     "fz_gelu_f32": (_i, [_vp, _vp, _sz, _vp]),

@@ -539,6 +539,32 @@ def gold_ranks(T: list[torch.Tensor], pos: torch.Tensor, weights: torch.Tensor, 
     return out
 
 
+def tune_metrics(ranks: torch.Tensor, gold: torch.Tensor, pos: torch.Tensor, n_gold: torch.Tensor, idcg: torch.Tensor,
+                 disc: torch.Tensor, cuts: dict[str, list[int]]) -> torch.Tensor:
+    """run_evaluation's metrics for every weight vector from the gold ranks of gold_ranks(), on the device (N1).
+    ranks [W,Q,G] int32, gold [Q,G] int32, pos [Q,N] int32 plane, n_gold [Q] int32, idcg [Q] float64, disc [top+1] float64,
+    cuts = {"recall": [...], "map": [...], "mrr": [...], "ndcg": [...]} -> [W, M] float64, columns in that order + R-precision."""
+    _dev(ranks, torch.int32, "tune_metrics(ranks)"); _dev(gold, torch.int32, "tune_metrics(gold)")
+    _dev(pos, torch.int32, "tune_metrics(pos)"); _dev(n_gold, torch.int32, "tune_metrics(n_gold)")
+    _dev(idcg, torch.float64, "tune_metrics(idcg)"); _dev(disc, torch.float64, "tune_metrics(disc)")
+    lib = _lib.lib()
+    G = int(lib.fz_tune_max_gold())
+    W, Q = ranks.shape[0], ranks.shape[1]
+    if ranks.shape != (W, Q, G) or gold.shape != (Q, G) or pos.shape[0] != Q or n_gold.shape != (Q,) or idcg.shape != (Q,):
+        raise ValueError("tune_metrics: ranks [W,Q,G], gold [Q,G], pos [Q,N], n_gold [Q], idcg [Q] expected")
+    fam = [list(cuts.get(k, [])) for k in ("recall", "map", "mrr", "ndcg")]
+    flat = [int(k) for f in fam for k in f]
+    if disc.numel() < 1 or any(k < 0 for k in flat):
+        raise ValueError("tune_metrics: a discount table and non-negative cut-offs expected")
+    pos = as_plane(pos)
+    cuts_dev = torch.tensor(flat if flat else [0], dtype=torch.int32, device=ranks.device)
+    out = torch.empty((W, len(flat) + 1), dtype=torch.float64, device=ranks.device)
+    check(lib.fz_tune_metrics_f64(_ptr(ranks.contiguous()), _ptr(gold.contiguous()), _ptr(pos), pos.stride(0), _ptr(n_gold.contiguous()),
+                                  _ptr(idcg.contiguous()), _ptr(disc.contiguous()), int(disc.numel()) - 1, _ptr(cuts_dev), len(fam[0]),
+                                  len(fam[1]), len(fam[2]), len(fam[3]), W, Q, _ptr(out), _stream(ranks)), "fz_tune_metrics_f64")
+    return out
+
+
 # ---------------------------------------------------------------------------------------
 # top-k
 # ---------------------------------------------------------------------------------------

@@ -286,6 +286,20 @@ class Aggregator:
         G = int(ops._lib.lib().fz_tune_max_gold())
         Gmax = max((len(g) for g in gold_pos), default=0)
         W = len(weight_combinations)
+        n_gold = np.array([len(gl) for gl in labels], dtype=np.int64)          # the reference divides by len(ground_truths)
+        if Gmax <= G:
+            # every gold list fits one counting launch: ranks -> metrics stay on the device (csrc/tune.hip, tune_metrics_kernel);
+            # [W, 15] float64 come back instead of [W, Q, G] ranks and a NumPy evaluation that cost more than the sweep itself
+            from ..utils.metrics import MAP_KS, MRR_KS, NDCG_KS, RECALL_KS, gold_rank_tables
+            gold = np.full((Q, G), -1, dtype=np.int32)
+            for q, gl in enumerate(gold_pos):
+                gold[q, :len(gl)] = gl
+            gold_dev = torch.from_numpy(gold).to(dev)
+            table, idcg, mnames = gold_rank_tables(n_gold)
+            rk = ops.gold_ranks(T, pos, weights, gold_dev)
+            means = ops.tune_metrics(rk, gold_dev, pos, torch.from_numpy(n_gold.astype(np.int32)).to(dev), torch.from_numpy(idcg).to(dev),
+                                     torch.from_numpy(table).to(dev), dict(recall=RECALL_KS, map=MAP_KS, mrr=MRR_KS, ndcg=NDCG_KS)).cpu().numpy()
+            return [{n: float(means[w, i]) for i, n in enumerate(mnames)} for w in range(W)]
         ranks = np.full((W, Q, max(Gmax, 1)), np.iinfo(np.int64).max, dtype=np.int64)
         pos_host = None
         for g0 in range(0, Gmax, G):
@@ -299,7 +313,6 @@ class Aggregator:
             listed = (gold >= 0) & (np.take_along_axis(pos_host, np.maximum(gold, 0).astype(np.int64), axis=1) >= 0)
             blk = np.where(listed[None, :, :], out, np.iinfo(np.int64).max)   # never retrieved -> rank = infinity
             ranks[:, :, g0:g0 + G] = blk[:, :, : ranks.shape[2] - g0]
-        n_gold = np.array([len(gl) for gl in labels], dtype=np.int64)          # the reference divides by len(ground_truths)
         list_len = (pos_host >= 0).sum(1) if pos_host is not None else np.zeros(Q, dtype=np.int64)
         return metrics_from_gold_ranks(ranks, n_gold, list_len)
 

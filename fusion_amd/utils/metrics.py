@@ -73,6 +73,18 @@ class Metrics:
 RECALL_KS, MAP_KS, MRR_KS, NDCG_KS = [5, 10, 20, 50, 100, 200, 500, 1000], [10, 100], [10, 100], [10, 100]   # hybrid.py:28
 
 
+def gold_rank_tables(n_gold: np.ndarray):
+    """Host-side constants of the gold-rank metrics, computed the way metrics.py:100-118 computes them: the discount table
+    (1 at position 0, 1/log2(i+1) from position 1), the ideal DCG per query, and the metric names in output order."""
+    top = int(max(NDCG_KS))                                               # only ranks below the largest cut-off are ever discounted
+    table = np.ones(top + 1)
+    table[1:] = 1.0 / np.log2(np.arange(1, top + 1, dtype=np.float64) + 1.0)   # metrics.py:108: 1/log2(i+1) from position 1
+    idcg = np.array([1 + sum(1 / np.log2(i + 1) for i in range(1, int(n))) if n > 0 else 1.0 for n in n_gold], dtype=np.float64)
+    names = ([f"recall@{k}" for k in RECALL_KS] + [f"map@{k}" for k in MAP_KS] + [f"mrr@{k}" for k in MRR_KS]
+             + [f"ndcg@{k}" for k in NDCG_KS] + ["r-precision"])
+    return table, idcg, names
+
+
 def metrics_from_gold_ranks(ranks: np.ndarray, n_gold: np.ndarray, list_len: np.ndarray) -> list[dict]:
     """All metrics of run_evaluation (hybrid.py:24-42) from the 0-based ranks of the gold documents.
     ranks [W, Q, G] int64 (np.iinfo(int64).max = never retrieved), n_gold [Q] = len(ground_truths) as the reference
@@ -85,10 +97,9 @@ def metrics_from_gold_ranks(ranks: np.ndarray, n_gold: np.ndarray, list_len: np.
     r = np.ascontiguousarray(np.sort(ranks, axis=2).transpose(2, 1, 0))   # [G, Q, W], ascending gold ranks per (q, w)
     have = r < INF
     ng = np.maximum(n_gold, 1).astype(np.float64)[:, None]                # [Q, 1]
-    top = int(max(NDCG_KS))                                               # only ranks below the largest cut-off are ever discounted
-    table = np.ones(top + 1)
-    table[1:] = 1.0 / np.log2(np.arange(1, top + 1, dtype=np.float64) + 1.0)   # metrics.py:108: 1/log2(i+1) from position 1
-    idcg = np.array([1 + sum(1 / np.log2(i + 1) for i in range(1, int(n))) if n > 0 else 1.0 for n in n_gold], dtype=np.float64)[:, None]
+    table, idcg, _ = gold_rank_tables(n_gold)
+    top = len(table) - 1
+    idcg = idcg[:, None]
     per_query: dict[str, np.ndarray] = {}                                 # each [Q, W]
     for k in RECALL_KS:
         per_query[f"recall@{k}"] = (r < k).sum(0) / ng                    # r < k implies retrieved

@@ -228,6 +228,16 @@ int fz_gold_ranks_f32(const float* const* T_h, const int32_t* pos, const float* 
  * products and sums (NumPy promotion of np.float32 * np.float64), ranks by the float64 fused score. */
 int fz_gold_ranks_f64w(const float* const* T_h, const int32_t* pos, const double* weights, const int32_t* gold, int S, int W,
                        int Q, int N, int ld, int32_t* out_ranks, void* stream);
+/* The metrics of run_evaluation (hybrid.py:24-42 over metrics.py:40-136) of every weight vector, from those ranks, on the device:
+ * per query in float64 and in the reference's operation order -- recall@k, MAP@k, MRR@k, nDCG@k (its shifted discount,
+ * metrics.py:108), R-precision -- and the mean over the Q queries as an exactly accumulated sum rounded once.
+ * ranks [W][Q][G], gold [Q][G], pos [Q][ld] as above (G = fz_tune_max_gold(); a gold document with pos < 0 is in no list and never
+ * counts); n_gold [Q] = len(ground_truths), the reference's divisor; idcg [Q] and disc [top+1] (disc[0] = 1, disc[i] = 1/log2(i+1))
+ * come from the host, computed as the reference computes them; cuts = the n_recall + n_map + n_mrr + n_ndcg cut-offs in that
+ * order.  out [W][M] float64, M = that count + 1 (R-precision last), M <= 24. */
+int fz_tune_metrics_f64(const int32_t* ranks, const int32_t* gold, const int32_t* pos, int ld, const int32_t* n_gold, const double* idcg,
+                        const double* disc, int top, const int32_t* cuts, int n_recall, int n_map, int n_mrr, int n_ndcg, int W, int Q,
+                        double* out, void* stream);
 
 /* ---- encoder side: the per-sequence parts of SentenceTransformer.encode (hybrid.py:97-102) on PACKED token rows -- */
 /* Self-attention of a BERT/CamemBERT layer for ragged sequences without padding: for every sequence and head,

@@ -546,3 +546,37 @@ def test_dot_scores_tile_stream_across_tiles(ops, Q, N, d):
     for r0 in range(0, Q, 128):
         ref = A[r0:r0 + 128].double() @ B.double().t()
         torch.testing.assert_close(S[r0:r0 + 128].double(), ref, rtol=0, atol=2e-6)
+
+
+# ---- N1: metrics of the sweep on the device -------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("Q", [1, 7, 195, 700])
+def test_tune_metrics_kernel_equals_host_evaluation(ops, Q):
+    """fz_tune_metrics_f64 against metrics_from_gold_ranks (itself checked against the Metrics class and, through tune(), against
+    the reference's loop): random gold ranks incl. rank 0, ranks around every cut-off, unlisted golds, padded slots, queries
+    with no gold at all and with repeated gold ids (len(ground_truths) > number of distinct golds).  Per-query values are the
+    same float64 operations in the same order; the means are exactly accumulated on both sides -> equal to the last bit."""
+    from fusion_amd.utils.metrics import MAP_KS, MRR_KS, NDCG_KS, RECALL_KS, gold_rank_tables, metrics_from_gold_ranks
+    rng = np.random.default_rng(Q)
+    W, N, G = 13, 3000, 8
+    pos = rng.permutation(N).astype(np.int32)[None, :].repeat(Q, 0)
+    pos[:, ::11] = -1                                            # documents in no list
+    gold = np.full((Q, G), -1, dtype=np.int32)
+    n_gold = np.zeros(Q, dtype=np.int64)
+    for q in range(Q):
+        k = int(rng.integers(0, G + 1))
+        gold[q, :k] = rng.choice(N, size=k, replace=False)
+        n_gold[q] = k + int(rng.integers(0, 3)) * (k > 0)        # repeated ids in the label list
+    special = np.array([0, 1, 4, 5, 9, 10, 19, 20, 99, 100, 199, 200, 499, 500, 999, 1000, 1001, 2500])
+    ranks = np.where(rng.random((W, Q, G)) < 0.5, rng.choice(special, size=(W, Q, G)), rng.integers(0, N, size=(W, Q, G))).astype(np.int32)
+    listed = (gold >= 0) & (np.take_along_axis(pos, np.maximum(gold, 0).astype(np.int64), axis=1) >= 0)
+    host_ranks = np.where(listed[None], ranks.astype(np.int64), np.iinfo(np.int64).max)
+    exp = metrics_from_gold_ranks(host_ranks, n_gold, np.full(Q, N))
+    table, idcg, names = gold_rank_tables(n_gold)
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    got = ops.tune_metrics(dev(ranks), dev(gold), ops.as_plane(dev(pos)), dev(n_gold.astype(np.int32)), dev(idcg), dev(table),
+                           dict(recall=RECALL_KS, map=MAP_KS, mrr=MRR_KS, ndcg=NDCG_KS)).cpu().numpy()
+    assert list(exp[0]) == names
+    E = np.array([[e[n] for n in names] for e in exp])
+    assert got.shape == E.shape
+    assert np.array_equal(got, E), float(np.max(np.abs(got - E)))

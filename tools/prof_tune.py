@@ -29,4 +29,7 @@ t_d2h, o2 = tm(lambda: out.cpu().numpy().astype(np.int64))
 t_pos, ph = tm(lambda: pos.cpu().numpy())
 ranks = o2
 t_m, res = tm(lambda: M.metrics_from_gold_ranks(ranks, (gold >= 0).sum(1).astype(np.int64), np.full(Q, N)))
+w64 = weights.double()
+t_k64, out64 = tm(lambda: ops.gold_ranks(T, pos, w64, gd))
+print(json.dumps(dict(kernel_f64w_ms=t_k64 * 1e3)))
 print(json.dumps(dict(kernel_ms=t_k * 1e3, out_d2h_ms=t_d2h * 1e3, pos_d2h_ms=t_pos * 1e3, metrics_ms=t_m * 1e3)))
