@@ -563,11 +563,9 @@ def bench_sharded(args, dev, rank, world, dist):
     if "shard_gemm" in per_launch:
         rl_all["shard_gemm"] = roof("dot_scores_kernel", per_launch["shard_gemm"], 2.0 * Q * (hi - lo) * d / cnt["shard_gemm"] * args.steps, "mfma_f32",
                                     launches_per_step=cnt["shard_gemm"] // args.steps)
-    if "shard_topk_update" in per_launch:   # one streaming pass over the chunk's scores
-        rl_all["shard_topk_update"] = roof("topk_filter + sort_rows (streaming update)", per_launch["shard_topk_update"], Q * chunk * 4, "hbm",
-                                           launches_per_step=cnt["shard_topk_update"] // args.steps)
-    if "shard_topk_first" in per_launch:
-        rl_all["shard_topk_first"] = roof("topk_rows (chunk-sort-truncate)", per_launch["shard_topk_first"], Q * chunk * 4, "hbm", launches_per_step=1)
+    if "shard_topk_stream" in stages:   # per step: one streaming pass over all the shard's scores (+ the exact head, + a few row sorts)
+        rl_all["shard_topk_stream"] = roof("topk_filter (threshold filter, append) + topk_rows head + sort_rows folds", stages["shard_topk_stream"],
+                                           Q * (hi - lo) * 4, "hbm", launches_per_step=1)
     dom = max((kx for kx in rl_all), key=lambda kx: stages.get(kx, 0.0))
     rl = dict(rl_all[dom], stage=dom, traffic=None, traffic_source=None)
     res = {"metric": METRIC, "value": Q * args.steps / el, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

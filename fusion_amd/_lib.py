@@ -64,6 +64,9 @@ _PROTOS = {
     "fz_topk_rows_f32": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "fz_topk_update_workspace_bytes": (_sz, [_i, _i, _i]),
     "fz_topk_update_f32": (_i, [_vp, _i, _i, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fz_topk_filter_append_f32": (_i, [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "fz_topk_fold_workspace_bytes": (_sz, [_i, _i, _i]),
+    "fz_topk_fold_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "fz_topk_allgather_workspace_bytes": (_sz, [_i, _i, _i]),
     "fz_topk_allgather": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -669,54 +669,111 @@ struct FilterArgs {
     float* buf_scores; int64_t* buf_ids;     // [rows][k + cap]: running list copied to the front, survivors behind
     int32_t* buf_len;                        // [rows] = k + survivors
     int32_t* overflow;                       // set to 1 if any row exceeded cap
+    // append form (fz_topk_filter_append_f32): tau != null -> the threshold comes from tau[row], nothing is copied, survivors go
+    // behind the buf_len[row] candidates already in buf_* ([rows][cap], k = 0) and buf_len[row] grows by their number
+    const float* tau;
 };
 
-__global__ __launch_bounds__(1024) void topk_filter_kernel(FilterArgs a) {
-    constexpr int T = 1024, NW = T / 64;
+// Each of the 4 waves owns a CONTIGUOUS stretch of the row (of a round of 65,536 columns), so "ascending column" = wave order, then step order, then lane order:
+// pass 1 streams the stretch from HBM and only counts (a 64-bit mask remembers which 256-column steps had a survivor at all);
+// one barrier and a 4-entry scan give every wave its output offset; pass 2 revisits the marked steps (L2 / Infinity-Cache hits)
+// and writes.  No barrier and no scan inside the streaming loop.
+__global__ __launch_bounds__(256) void topk_filter_kernel(FilterArgs a) {
+    constexpr int T = 256, NW = T / 64, STEP = 256, SPAN = NW * 64 * STEP;   // columns per outer round: 64 steps per wave
     __shared__ int wtot[NW];
     const int row = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* __restrict__ x = a.scores + (size_t)row * a.ld;
     float* __restrict__ bs = a.buf_scores + (size_t)row * (a.k + a.cap);
     int64_t* __restrict__ bi = a.buf_ids + (size_t)row * (a.k + a.cap);
-    for (int i = threadIdx.x; i < a.k; i += T) { bs[i] = a.run_scores[(size_t)row * a.k + i]; bi[i] = a.run_ids[(size_t)row * a.k + i]; }
-    const float tau = a.run_scores[(size_t)row * a.k + a.k - 1];   // k-th best so far (-inf while the list is short)
-    const bool vec = (a.ld % 4 == 0) && ((uintptr_t)a.scores % 16 == 0);
+    float tau;
     int base = 0;
+    if (a.tau) { tau = a.tau[row]; base = a.buf_len[row]; }
+    else {
+        for (int i = threadIdx.x; i < a.k; i += T) { bs[i] = a.run_scores[(size_t)row * a.k + i]; bi[i] = a.run_ids[(size_t)row * a.k + i]; }
+        tau = a.run_scores[(size_t)row * a.k + a.k - 1];   // k-th best so far (-inf while the list is short)
+    }
+    const bool vec = (a.ld % 4 == 0) && ((uintptr_t)a.scores % 16 == 0);
     bool over = false;
-    for (int c0 = 0; c0 < a.n; c0 += 4 * T) {
-        const int j0 = c0 + 4 * threadIdx.x;
-        float v[4];
+    auto load4 = [&](int j0, float (&v)[4]) {
         if (vec && j0 + 3 < a.n) { const float4 f = *reinterpret_cast<const float4*>(x + j0); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
         else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = (j0 + c < a.n) ? x[j0 + c] : -INFINITY;
         }
+    };
+    for (int r0 = 0; r0 < a.n; r0 += SPAN) {
+        const int nr = min(a.n - r0, SPAN);
+        const int steps = (nr + NW * STEP - 1) / (NW * STEP);      // per wave, <= 64
+        const int w0 = r0 + w * steps * STEP;                      // this wave's stretch: steps * 256 columns from w0
+        // ---- pass 1: count
         int cnt = 0;
-        bool keep[4];
+        unsigned long long marked = 0ull;
+        for (int s0 = 0; s0 < steps; s0 += 2) {                    // two 16-byte loads in flight per lane (and 32 waves per CU)
+            float v[2][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { keep[c] = (j0 + c < a.n) && (v[c] > tau || v[c] != v[c]); cnt += keep[c] ? 1 : 0; }
-        // stable block-wide exclusive prefix of cnt
-        int incl = cnt;
+            for (int u = 0; u < 2; ++u) load4(w0 + (s0 + u) * STEP + lane * 4, v[u]);   // a step past the stretch reads the next wave's (or -inf)
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        __syncthreads();
-        if (lane == 63) wtot[w] = incl;
-        __syncthreads();
-        int woff = 0, tot = 0;
+            for (int u = 0; u < 2; ++u) {
+                const int j0 = w0 + (s0 + u) * STEP + lane * 4;
+                int c = 0;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) { const int c = wtot[i]; if (i < w) woff += c; tot += c; }
-        int pos = base + woff + incl - cnt;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (keep[c]) {
-                if (pos < a.cap) { bs[a.k + pos] = v[c]; bi[a.k + pos] = a.id_base + j0 + c; }
-                else over = true;
-                ++pos;
+                for (int e = 0; e < 4; ++e) c += ((s0 + u < steps) && (j0 + e < a.n) && !(v[u][e] <= tau)) ? 1 : 0;   // s > tau, or NaN (sorts first)
+                cnt += c;
+                if (__ballot(c != 0)) marked |= 1ull << (s0 + u);  // wave-uniform
             }
+        }
+        cnt = wave_reduce_sum(cnt);
+        __syncthreads();                                           // (the previous round's wtot has been read)
+        if (lane == 0) wtot[w] = cnt;
+        __syncthreads();
+        int off = base, tot = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { const int c = wtot[i]; if (i < w) off += c; tot += c; }
+        // ---- pass 2: the marked steps again, survivors to their slots
+        while (marked) {
+            const int st = __builtin_ctzll(marked);
+            marked &= marked - 1;
+            const int j0 = w0 + st * STEP + lane * 4;
+            float v[4];
+            load4(j0, v);
+            bool keep[4];
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { keep[e] = (j0 + e < a.n) && !(v[e] <= tau); c += keep[e] ? 1 : 0; }
+            const int incl = (int)wave_incl_scan_u32((uint32_t)c, lane);
+            int pos = off + incl - c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (keep[e]) {
+                    if (pos < a.cap) { bs[a.k + pos] = v[e]; bi[a.k + pos] = a.id_base + j0 + e; }
+                    else over = true;
+                    ++pos;
+                }
+            off += __shfl(incl, 63, 64);
+        }
         base += tot;
     }
+    __syncthreads();   // (append form: every thread has read buf_len[row])
     if (threadIdx.x == 0) a.buf_len[row] = a.k + (base < a.cap ? base : a.cap);
     if (over) atomicExch(a.overflow, 1);
+}
+
+// fold: [running k | candidates] of every row side by side for the row sort; afterwards the new threshold and empty candidate lists
+__global__ void topk_concat_kernel(const float* run_scores, const int64_t* run_ids, int k, const float* cand_scores, const int64_t* cand_ids,
+                                   const int32_t* cand_len, int cap, float* buf_scores, int64_t* buf_ids, int32_t* buf_len) {
+    const int row = blockIdx.x;
+    const int len = min(cand_len[row], cap);
+    float* bs = buf_scores + (size_t)row * (k + cap);
+    int64_t* bi = buf_ids + (size_t)row * (k + cap);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) { bs[i] = run_scores[(size_t)row * k + i]; bi[i] = run_ids[(size_t)row * k + i]; }
+    for (int i = threadIdx.x; i < len; i += blockDim.x) { bs[k + i] = cand_scores[(size_t)row * cap + i]; bi[k + i] = cand_ids[(size_t)row * cap + i]; }
+    if (threadIdx.x == 0) buf_len[row] = k + len;
+}
+__global__ void topk_fold_done_kernel(const float* new_scores, int rows, int k, float* tau, int32_t* cand_len) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    if (tau) tau[row] = new_scores[(size_t)row * k + k - 1];
+    cand_len[row] = 0;
 }
 
 
@@ -1060,13 +1117,57 @@ extern "C" int fz_topk_update_f32(const float* scores, int rows, int n, int ld, 
     f.buf_scores = reinterpret_cast<float*>(ws); ws += (size_t)rows * (k + cap) * 4;
     f.buf_len = reinterpret_cast<int32_t*>(ws);
     f.overflow = overflow;
-    topk_filter_kernel<<<rows, 1024, 0, st>>>(f);
+    topk_filter_kernel<<<rows, 256, 0, st>>>(f);
     FZ_LAUNCH_CHECK();
     SortArgs a{};
     a.keys = f.buf_scores; a.row_len = f.buf_len; a.n_total = k + cap; a.key_row_stride = k + cap; a.seg_len = k + cap;
     a.chunks = 1; a.chunk_len = k + cap;
     a.sorted_keys = new_scores; a.out_ids = new_ids; a.idmap = f.buf_ids; a.out_row_stride = k; a.out_limit = k;
     return launch_sort(a, 1, rows, k + cap, st);
+}
+
+/* The streaming step in two halves, so that several chunks can share one sort: fz_topk_filter_append_f32 appends the chunk's
+ * scores above tau[row] (or NaN) to the row's candidate list (ascending id inside the chunk; chunks must be fed in ascending id
+ * order); fz_topk_fold_f32 merges [running k | candidates] into the new running list, writes the new threshold
+ * tau[row] = k-th best and empties the candidate lists.  cand_* [rows][cap], cand_len [rows] (zeroed before the first call). */
+extern "C" int fz_topk_filter_append_f32(const float* scores, int rows, int n, int ld, int64_t id_base, const float* tau, float* cand_scores,
+                                         int64_t* cand_ids, int32_t* cand_len, int cap, int32_t* overflow, void* stream) {
+    if (rows < 0 || n < 0 || ld < n || cap <= 0) return FZ_ERR_ARG;
+    if (rows == 0 || n == 0) return FZ_OK;
+    if (!scores || !tau || !cand_scores || !cand_ids || !cand_len || !overflow) return FZ_ERR_ARG;
+    FilterArgs f{};
+    f.scores = scores; f.n = n; f.ld = ld; f.id_base = id_base; f.k = 0; f.cap = cap; f.tau = tau;
+    f.buf_scores = cand_scores; f.buf_ids = cand_ids; f.buf_len = cand_len; f.overflow = overflow;
+    topk_filter_kernel<<<rows, 256, 0, as_stream(stream)>>>(f);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+extern "C" size_t fz_topk_fold_workspace_bytes(int rows, int k, int cap) { return fz_topk_update_workspace_bytes(rows, k, cap); }
+
+extern "C" int fz_topk_fold_f32(const float* run_scores, const int64_t* run_ids, int rows, int k, const float* cand_scores, const int64_t* cand_ids,
+                                int32_t* cand_len, int cap, float* new_scores, int64_t* new_ids, float* tau_out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (rows < 0 || k <= 0 || cap <= 0) return FZ_ERR_ARG;
+    if ((long)k + cap > 35840) return FZ_ERR_UNSUPPORTED;
+    if (rows == 0) return FZ_OK;
+    if (!run_scores || !run_ids || !cand_scores || !cand_ids || !cand_len || !new_scores || !new_ids) return FZ_ERR_ARG;
+    if (!workspace || workspace_bytes < fz_topk_fold_workspace_bytes(rows, k, cap)) return FZ_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    char* ws = reinterpret_cast<char*>(workspace);
+    int64_t* buf_ids = reinterpret_cast<int64_t*>(ws); ws += (size_t)rows * (k + cap) * 8;
+    float* buf_scores = reinterpret_cast<float*>(ws); ws += (size_t)rows * (k + cap) * 4;
+    int32_t* buf_len = reinterpret_cast<int32_t*>(ws);
+    topk_concat_kernel<<<rows, 256, 0, st>>>(run_scores, run_ids, k, cand_scores, cand_ids, cand_len, cap, buf_scores, buf_ids, buf_len);
+    FZ_LAUNCH_CHECK();
+    SortArgs a{};
+    a.keys = buf_scores; a.row_len = buf_len; a.n_total = k + cap; a.key_row_stride = k + cap; a.seg_len = k + cap;
+    a.chunks = 1; a.chunk_len = k + cap;
+    a.sorted_keys = new_scores; a.out_ids = new_ids; a.idmap = buf_ids; a.out_row_stride = k; a.out_limit = k;
+    if (int rc = launch_sort(a, 1, rows, k + cap, st)) return rc;
+    topk_fold_done_kernel<<<(rows + 255) / 256, 256, 0, st>>>(new_scores, rows, k, tau_out, cand_len);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
 }
 
 extern "C" int fz_topk_merge(const float* in_scores, const int64_t* in_ids, int G, int rows, int k, float* out_scores,

@@ -72,94 +72,39 @@ class ShardedDenseIndex:
     def __init__(self, Dn_local: torch.Tensor, id_base: int, group=None):
         self.Dn, self.id_base, self.group = Dn_local, int(id_base), group
 
-    def local_topk(self, Qn: torch.Tensor, k: int, streaming: bool = True, mark=None, overlap: bool | None = None):
-        """Chunked score -> top-k over this shard.  First chunk: exact chunk-sort-truncate.  Later chunks: only scores
-        above the running k-th best can enter, so they go through the streaming threshold filter (ops.topk_update);
-        if any row overflowed its candidate buffer the search is redone on the exact path (flag read once, at the end).
+    def local_topk(self, Qn: torch.Tensor, k: int, streaming: bool = True, mark=None):
+        """Chunked score -> top-k over this shard.  The first HEAD documents get an exact top-k (one sort-kernel row per query);
+        after that only scores above a query's running k-th best can enter, so every later chunk goes through the streaming
+        threshold filter and the candidates are folded into the list a few times per shard (ops.TopkStream).  If any row
+        overflowed its candidate buffer the search is redone on the exact path (flag read once, at the end).
         `mark(name)`: optional instrumentation hook (bench.py records a HIP event per call).
-        `overlap` (default: on unless instrumented): the top-k of chunk c runs on a second HIP stream while the matrix cores
-        score chunk c + 1 into the other of two score planes (the GEMM is MFMA-bound, the filter HBM-bound)."""
+        Everything runs on ONE stream: issuing the top-k work of chunk c on a second stream under the GEMM of chunk c + 1 was
+        measured twice and lost both times (17.3 vs 15.5 ms per 1.1 M-document shard in round 2: the persistent GEMM owns every
+        CU, and what squeezes in next to it costs the matrix pipe more than it hides)."""
         from . import ops
-        if overlap is None:
-            overlap = mark is None
-        n = self.Dn.shape[0]
-        if overlap and streaming and n > self.CHUNK and Qn.is_cuda:
-            return self._local_topk_overlapped(Qn, k)
         mark = mark or (lambda name: None)
-        best_s = best_i = None
-        overflow = None
+        n = self.Dn.shape[0]
+        streaming = streaming and k + self.CAP <= 35840 and k <= self.HEAD // 8 and n > self.HEAD
+        best_s = best_i = stream = None
         for c0 in range(0, max(n, 1), self.CHUNK):
             c1 = min(n, c0 + self.CHUNK)
             S = ops.dot_scores(Qn, self.Dn[c0:c1]); mark("shard_gemm")
-            if best_s is None and streaming and k + self.CAP <= 35840 and c1 - c0 > self.HEAD and k <= self.HEAD // 8:
-                # first chunk: an exact top-k of its first HEAD columns gives a threshold, the rest streams through the filter in
-                # pieces that grow with what has been seen (expected survivors per row = k * piece / seen <= CAP / 2), instead
-                # of chunk-sorting all of it (2.6 -> ~0.8 ms at 229,376 columns, k = 1000)
-                best_s, best_i = ops.topk_rows(S[:, : self.HEAD], k, id_base=self.id_base + c0)
-                seen = self.HEAD
-                while seen < c1 - c0:
-                    piece = min(c1 - c0 - seen, max(4096, (self.CAP // 2) * seen // k) // 64 * 64)
-                    best_s, best_i, overflow = ops.topk_update(S[:, seen: seen + piece], self.id_base + c0 + seen, best_s, best_i, self.CAP, overflow)
-                    seen += piece
-                mark("shard_topk_first")
+            if streaming:
+                lo = 0
+                if stream is None:
+                    lo = min(self.HEAD, c1 - c0)
+                    bs, bi = ops.topk_rows(S[:, :lo], k, id_base=self.id_base + c0)
+                    stream = ops.TopkStream(bs, bi, seen=lo, cap=self.CAP)
+                stream.feed(S[:, lo:], self.id_base + c0 + lo); mark("shard_topk_stream")
             elif best_s is None:
-                best_s, best_i = ops.topk_rows(S, k, id_base=self.id_base + c0); mark("shard_topk_first")
-            elif streaming and k + self.CAP <= 35840:
-                best_s, best_i, overflow = ops.topk_update(S, self.id_base + c0, best_s, best_i, self.CAP, overflow); mark("shard_topk_update")
+                best_s, best_i = ops.topk_rows(S, k, id_base=self.id_base + c0); mark("shard_topk_exact")
             else:   # exact path: per-chunk top-k, then merge two id-ascending lists (chunks arrive in id order)
                 s, i = ops.topk_rows(S, k, id_base=self.id_base + c0)
                 best_s, best_i = ops.topk_merge(torch.stack([best_s, s]), torch.stack([best_i, i])); mark("shard_topk_exact")
-        if overflow is not None and int(overflow.item()) != 0:
-            return self.local_topk(Qn, k, streaming=False, mark=mark)
-        return best_s, best_i
-
-    def _topk_chunk(self, S, c0, k, best_s, best_i, overflow):
-        """Fold one chunk of scores (columns = documents c0 ..) into the running top-k (the streaming forms of local_topk)."""
-        from . import ops
-        w = S.shape[1]
-        if best_s is None:
-            if w > self.HEAD and k <= self.HEAD // 8:
-                best_s, best_i = ops.topk_rows(S[:, : self.HEAD], k, id_base=self.id_base + c0)
-                seen = self.HEAD
-                while seen < w:
-                    piece = min(w - seen, max(4096, (self.CAP // 2) * seen // k) // 64 * 64)
-                    best_s, best_i, overflow = ops.topk_update(S[:, seen: seen + piece], self.id_base + c0 + seen, best_s, best_i, self.CAP, overflow)
-                    seen += piece
-                return best_s, best_i, overflow
-            best_s, best_i = ops.topk_rows(S, k, id_base=self.id_base + c0)
-            return best_s, best_i, overflow
-        return ops.topk_update(S, self.id_base + c0, best_s, best_i, self.CAP, overflow)
-
-    def _local_topk_overlapped(self, Qn: torch.Tensor, k: int):
-        from . import ops
-        if k + self.CAP > 35840:
-            return self.local_topk(Qn, k, overlap=False)
-        n, Q = self.Dn.shape[0], Qn.shape[0]
-        main = torch.cuda.current_stream(Qn.device)
-        side = getattr(self, "_side", None)
-        if side is None or side.device != Qn.device:
-            side = self._side = torch.cuda.Stream(device=Qn.device)
-        planes = [ops.alloc_plane(Q, min(self.CHUNK, n), torch.float32, Qn.device) for _ in range(2)]
-        done_topk = [None, None]
-        best_s = best_i = overflow = None
-        for ci, c0 in enumerate(range(0, n, self.CHUNK)):
-            c1 = min(n, c0 + self.CHUNK)
-            buf = planes[ci & 1]
-            if done_topk[ci & 1] is not None:
-                main.wait_event(done_topk[ci & 1])              # the plane's previous chunk has been consumed
-            S = ops.dot_scores(Qn, self.Dn[c0:c1], out=buf[:, : c1 - c0])
-            scored = torch.cuda.Event(); scored.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(scored)
-                best_s, best_i, overflow = self._topk_chunk(S, c0, k, best_s, best_i, overflow)
-                ev = torch.cuda.Event(); ev.record(side)
-                done_topk[ci & 1] = ev
-        main.wait_stream(side)
-        for t in (best_s, best_i, overflow, *planes):
-            if t is not None:
-                t.record_stream(main)
-        if overflow is not None and int(overflow.item()) != 0:
-            return self.local_topk(Qn, k, streaming=False, overlap=False)
+        if stream is not None:
+            best_s, best_i, overflow = stream.result(); mark("shard_topk_stream")
+            if int(overflow.item()) != 0:
+                return self.local_topk(Qn, k, streaming=False, mark=mark)
         return best_s, best_i
 
     def search(self, Qn: torch.Tensor, k: int = 1000, mark=None):

@@ -608,6 +608,68 @@ def topk_update(scores: torch.Tensor, id_base: int, run_scores: torch.Tensor, ru
     return ns, ni, overflow
 
 
+class TopkStream:
+    """Running per-row top-k over a stream of score chunks (documents in ascending id order): only scores above a row's
+    threshold (its k-th best when the list was last folded) are kept as candidates (fz_topk_filter_append_f32), and candidates
+    are folded into the list (fz_topk_fold_f32: one row sort) only when their EXPECTED number -- k * (documents since the fold) /
+    (documents before it), for scores in no particular order -- reaches half the candidate capacity.  The windows between folds
+    therefore grow geometrically: 3 folds for a 1.1 M-document shard at k = 1000, cap = 7168, however the scoring is chunked.
+    `overflow` (device int32) becomes 1 if a row ever had more than `cap` candidates: the caller redoes the search exactly."""
+
+    def __init__(self, run_scores: torch.Tensor, run_ids: torch.Tensor, seen: int, cap: int = 7168):
+        _dev(run_scores, torch.float32, "TopkStream(run_scores)"); _dev(run_ids, torch.int64, "TopkStream(run_ids)")
+        rows, k = run_scores.shape
+        _need(tuple(run_ids.shape) == (rows, k) and seen > 0 and cap > 0, "TopkStream: lists [rows, k], seen > 0, cap > 0 expected")
+        dev = run_scores.device
+        self.rows, self.k, self.cap = rows, k, int(cap)
+        self.best_s, self.best_i = run_scores.contiguous(), run_ids.contiguous()
+        self.tau = self.best_s[:, k - 1].contiguous()
+        self.cand_s = torch.empty((rows, cap), dtype=torch.float32, device=dev)
+        self.cand_i = torch.empty((rows, cap), dtype=torch.int64, device=dev)
+        self.cand_len = torch.zeros(rows, dtype=torch.int32, device=dev)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.seen = int(seen)            # documents folded into (best_s, tau)
+        self.pending = 0                 # documents filtered against tau since
+        wsb = int(_lib.lib().fz_topk_fold_workspace_bytes(rows, k, cap))
+        self._ws, self._wsb = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev), wsb
+
+    def _window(self) -> int:
+        """documents one threshold may serve: expected candidates k * window / seen <= cap / 2"""
+        return max(64, (self.cap // 2) * self.seen // self.k // 64 * 64)
+
+    def feed(self, scores: torch.Tensor, id_base: int):
+        """scores [rows, n] of documents id_base .. id_base + n - 1"""
+        _dev(scores, torch.float32, "TopkStream.feed(scores)")
+        _need(scores.shape[0] == self.rows, "TopkStream.feed: one row per running list")
+        lib = _lib.lib()
+        n, lo = scores.shape[1], 0
+        while lo < n:
+            hi = min(n, lo + self._window() - self.pending)
+            piece = scores[:, lo:hi]
+            check(lib.fz_topk_filter_append_f32(_ptr(piece), self.rows, hi - lo, _ld(scores), int(id_base) + lo, _ptr(self.tau), _ptr(self.cand_s),
+                                                _ptr(self.cand_i), _ptr(self.cand_len), self.cap, _ptr(self.overflow), _stream(scores)),
+                  "fz_topk_filter_append_f32")
+            self.pending += hi - lo
+            lo = hi
+            if self.pending >= self._window():
+                self.fold()
+
+    def fold(self):
+        if self.pending == 0:
+            return
+        ns, ni = torch.empty_like(self.best_s), torch.empty_like(self.best_i)
+        check(_lib.lib().fz_topk_fold_f32(_ptr(self.best_s), _ptr(self.best_i), self.rows, self.k, _ptr(self.cand_s), _ptr(self.cand_i),
+                                          _ptr(self.cand_len), self.cap, _ptr(ns), _ptr(ni), _ptr(self.tau), _ptr(self._ws), self._wsb,
+                                          _stream(self.best_s)), "fz_topk_fold_f32")
+        self.best_s, self.best_i = ns, ni
+        self.seen += self.pending
+        self.pending = 0
+
+    def result(self):
+        self.fold()
+        return self.best_s, self.best_i, self.overflow
+
+
 def topk_merge(in_scores: torch.Tensor, in_ids: torch.Tensor):
     """[G,rows,k] per-shard lists -> global top-k [rows,k] (after the RCCL all-gather)."""
     _dev(in_scores, torch.float32, "topk_merge(in_scores)")

@@ -190,6 +190,18 @@ size_t fz_topk_update_workspace_bytes(int rows, int k, int cap);
 int fz_topk_update_f32(const float* scores, int rows, int n, int ld, int64_t id_base, const float* run_scores,
                        const int64_t* run_ids, int k, int cap, float* new_scores, int64_t* new_ids, int32_t* overflow,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The same step in two halves, so that several chunks share ONE sort (the sharded search folds 3 times per 1.1 M-document shard
+ * instead of once per chunk): fz_topk_filter_append_f32 appends the chunk's scores above tau[row] (or NaN) to the row's candidate
+ * list -- ascending id inside the chunk, chunks fed in ascending id order; fz_topk_fold_f32 merges [running k | candidates] into
+ * the new running list (ties: running entries first, then ascending id), writes the new threshold tau_out[row] = k-th best
+ * (nullable) and empties the candidate lists.  cand_scores / cand_ids [rows][cap], cand_len [rows] int32 (zero before the first
+ * call); *overflow becomes 1 if a row's list would exceed cap (the caller then redoes the search exactly).  k + cap <= 35840. */
+int fz_topk_filter_append_f32(const float* scores, int rows, int n, int ld, int64_t id_base, const float* tau, float* cand_scores,
+                              int64_t* cand_ids, int32_t* cand_len, int cap, int32_t* overflow, void* stream);
+size_t fz_topk_fold_workspace_bytes(int rows, int k, int cap);
+int fz_topk_fold_f32(const float* run_scores, const int64_t* run_ids, int rows, int k, const float* cand_scores, const int64_t* cand_ids,
+                     int32_t* cand_len, int cap, float* new_scores, int64_t* new_ids, float* tau_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
 /* merge G per-shard lists [G][rows][k] (as all-gathered over RCCL) into the global top-k [rows][k] */
 int fz_topk_merge(const float* in_scores, const int64_t* in_ids, int G, int rows, int k, float* out_scores, int64_t* out_ids,
                   void* stream);

@@ -580,3 +580,44 @@ def test_tune_metrics_kernel_equals_host_evaluation(ops, Q):
     E = np.array([[e[n] for n in names] for e in exp])
     assert got.shape == E.shape
     assert np.array_equal(got, E), float(np.max(np.abs(got - E)))
+
+
+# ---- streaming top-k: several chunks per fold ---------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,cap,head", [(100, 2000, 4096), (1000, 7168, 28672), (7, 256, 512)])
+def test_topk_stream_equals_oracle_topk_of_the_whole_matrix(ops, oracle, k, cap, head):
+    """ops.TopkStream fed with chunks of irregular widths (the windows between folds are the stream's own business) == the oracle's
+    top-k of the full score matrix: scores and ids, ties by ascending id -- incl. planted ties inside a chunk, across chunks and
+    across folds, a row of identical scores and a NaN."""
+    rng = np.random.default_rng(k)
+    rows, n = 5, 150_000
+    S = np.round(rng.normal(0, 1, (rows, n)), 3).astype(np.float32)        # 3 decimals: ties everywhere
+    S[1, :] = 0.25
+    S[2, 77_777] = np.nan
+    S[3, 60_000:60_050] = S[3].max()
+    Sd = ops.as_plane(torch.from_numpy(S).cuda())
+    bs, bi = ops.topk_rows(Sd[:, :head], k, id_base=1_000)
+    st = ops.TopkStream(bs, bi, seen=head, cap=cap)
+    lo = head
+    for w in [1, 63, 4096, 5000, 64, 30_001, 17, 50_000, 10**9]:
+        hi = min(n, lo + w)
+        if hi > lo:
+            st.feed(Sd[:, lo:hi], 1_000 + lo)
+        lo = hi
+    gs, gi, flag = st.result()
+    assert int(flag.item()) == 0
+    es, ei = oracle.topk_rows(S, k, id_base=1_000)
+    np.testing.assert_array_equal(gs.cpu().numpy(), es)
+    np.testing.assert_array_equal(gi.cpu().numpy(), ei)
+
+
+@pytest.mark.gpu
+def test_topk_stream_flags_candidate_overflow(ops):
+    """Ascending scores: every new document beats the threshold; a window holds more than `cap` of them -> the flag the caller
+    checks before trusting the lists (ShardedDenseIndex then redoes the search on the exact path)."""
+    rows, n, k = 3, 40_000, 50
+    S = ops.as_plane((torch.arange(rows * n, device="cuda", dtype=torch.float32).reshape(rows, n) / 7.0).contiguous())
+    bs, bi = ops.topk_rows(S[:, :4096], k)
+    st = ops.TopkStream(bs, bi, seen=4096, cap=500)
+    st.feed(S[:, 4096:], 4096)
+    assert int(st.result()[2].item()) == 1
