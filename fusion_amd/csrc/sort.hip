@@ -708,19 +708,30 @@ __global__ __launch_bounds__(256) void topk_filter_kernel(FilterArgs a) {
         // ---- pass 1: count
         int cnt = 0;
         unsigned long long marked = 0ull;
-        for (int s0 = 0; s0 < steps; s0 += 2) {                    // two 16-byte loads in flight per lane (and 32 waves per CU)
-            float v[2][4];
+        constexpr int UNR = 8;                                     // 16-byte loads in flight per lane
+        auto count_step = [&](int st, const float (&v)[4]) {
+            const int j0 = w0 + st * STEP + lane * 4;
+            int c = 0;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) load4(w0 + (s0 + u) * STEP + lane * 4, v[u]);   // a step past the stretch reads the next wave's (or -inf)
+            for (int e = 0; e < 4; ++e) c += ((j0 + e < a.n) && !(v[e] <= tau)) ? 1 : 0;   // s > tau, or NaN (sorts first in this build)
+            cnt += c;
+            if (__ballot(c != 0)) marked |= 1ull << st;            // wave-uniform
+        };
+        int s0 = 0;
+        // whole groups of UNR steps inside the row: plain 16-byte loads under no branch (behind a conditional load hipcc waits
+        // for every outstanding one, which turns the group into a chain of single round trips)
+        if (vec)
+            for (; s0 + UNR <= steps && w0 + (s0 + UNR) * STEP <= a.n; s0 += UNR) {
+                float4 f[UNR];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int j0 = w0 + (s0 + u) * STEP + lane * 4;
-                int c = 0;
+                for (int u = 0; u < UNR; ++u) f[u] = *reinterpret_cast<const float4*>(x + w0 + (s0 + u) * STEP + lane * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) c += ((s0 + u < steps) && (j0 + e < a.n) && !(v[u][e] <= tau)) ? 1 : 0;   // s > tau, or NaN (sorts first)
-                cnt += c;
-                if (__ballot(c != 0)) marked |= 1ull << (s0 + u);  // wave-uniform
+                for (int u = 0; u < UNR; ++u) { const float v[4] = {f[u].x, f[u].y, f[u].z, f[u].w}; count_step(s0 + u, v); }
             }
+        for (; s0 < steps; ++s0) {                                 // the ragged end (or unaligned rows)
+            float v[4];
+            load4(w0 + s0 * STEP + lane * 4, v);
+            count_step(s0, v);
         }
         cnt = wave_reduce_sum(cnt);
         __syncthreads();                                           // (the previous round's wtot has been read)

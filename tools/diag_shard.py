@@ -13,14 +13,17 @@ for c0 in range(0, N, 1 << 19):
     Dn[c0:c1] = ops.normalize_rows(torch.randn((c1 - c0, d), generator=g, device="cuda"))
 Qn = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
 idx = ShardedDenseIndex(Dn, 0)
-for rep in range(3):
-    evs = []
-    def mark(name):
-        e = torch.cuda.Event(enable_timing=True); e.record(); evs.append((name, e))
-    mark("start")
-    idx.local_topk(Qn, k, mark=mark)
-    torch.cuda.synchronize()
-    tot = collections.OrderedDict()
-    for (n0, e0), (n1, e1) in zip(evs[:-1], evs[1:]):
-        tot[n1] = tot.get(n1, 0.0) + e0.elapsed_time(e1)
-    print({k_: round(v, 3) for k_, v in tot.items()}, "total", round(sum(tot.values()), 3), flush=True)
+for chunk in [int(x) for x in sys.argv[1:]] or [ShardedDenseIndex.CHUNK]:
+  idx.CHUNK = chunk
+  print('CHUNK', chunk)
+  for rep in range(3):
+      evs = []
+      def mark(name):
+          e = torch.cuda.Event(enable_timing=True); e.record(); evs.append((name, e))
+      mark("start")
+      idx.local_topk(Qn, k, mark=mark)
+      torch.cuda.synchronize()
+      tot = collections.OrderedDict()
+      for (n0, e0), (n1, e1) in zip(evs[:-1], evs[1:]):
+          tot[n1] = tot.get(n1, 0.0) + e0.elapsed_time(e1)
+      print({k_: round(v, 3) for k_, v in tot.items()}, "total", round(sum(tot.values()), 3), flush=True)
