@@ -18,6 +18,7 @@
 // blocks of one corpus tile run back-to-back on one XCD (workgroup id % 8), so a corpus tile is fetched from HBM once and hit
 // in that XCD's L2 afterwards.  What each of these steps bought is in DESIGN.md section 5 (K1).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -126,22 +127,23 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
     };
     const int KT = ((g.d + 2 * BK - 1) / (2 * BK)) * 2;
     struct Stage { float4 a[4], b[BROWS]; };
-    auto gload = [&](Stage& r, int kt) __attribute__((always_inline)) {
+    // `edge` (compile time): this k-tile may reach past d -- only the last two of a tile can; all the others take the plain path
+    auto gload = [&](Stage& r, int kt, auto edge) __attribute__((always_inline)) {
         const char* ab = reinterpret_cast<const char*>(abase + kt * BK);
         const char* bb = reinterpret_cast<const char*>(bbase + kt * BK);
         // d % 4 == 0: a float4 is entirely inside or outside.  Outside: step back to the row's last float4 (zeroed in sstore)
-        const int32_t back = RAGGED ? max(0, kt * BK + sk + 4 - g.d) * 4 : 0;
+        const int32_t back = (RAGGED && decltype(edge)::value) ? max(0, kt * BK + sk + 4 - g.d) * 4 : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) r.a[i] = *reinterpret_cast<const float4*>(ab + (ptrdiff_t)(oa[i] - back));
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) r.b[i] = *reinterpret_cast<const float4*>(bb + (ptrdiff_t)(ob[i] - back));
     };
-    auto sstore = [&](const Stage& r, int kt) __attribute__((always_inline)) {   // kt: the k-tile the registers hold
+    auto sstore = [&](const Stage& r, int kt, auto edge) __attribute__((always_inline)) {   // kt: the k-tile the registers hold
         float* As = lds + (kt & 1) * BUF;
         float* Bs = As + BM * LDT;
         const uint32_t m = RAGGED && kt * BK + sk >= g.d ? 0u : ~0u;
         auto keep = [&](float4 v) {
-            if (!RAGGED) return v;
+            if (!(RAGGED && decltype(edge)::value)) return v;
             return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
                                __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
         };
@@ -193,9 +195,9 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
     // the barrier it fetches the next stage's first fragments and covers that latency with the MFMAs it still owes.
     Frag f0, f1;
     Stage r0, r1;
-    auto ktile = [&](const int kt /* being multiplied */, const int kload /* fetched into rl */, const int kstore /* held by rs */, Stage& rl, const Stage& rs) __attribute__((always_inline)) {
+    auto ktile = [&](const int kt /* being multiplied */, const int kload /* fetched into rl */, const int kstore /* held by rs */, Stage& rl, const Stage& rs, auto edge) __attribute__((always_inline)) {
         const int cur = kt & 1;
-        gload(rl, kload);
+        gload(rl, kload, edge);
         fread(f1, cur, 1);
         fmma(f0);
         fread(f0, cur, 2);
@@ -203,7 +205,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
         // ONE fence per k-tile, here: without it hipcc sinks the HBM loads to the end of the k-tile and hoists the waits for them
         // to its start (a zero-deep prefetch); with more of them it can no longer run the fragment reads ahead of the MFMAs.
         __builtin_amdgcn_sched_barrier(0);
-        sstore(rs, kstore);                  // k-tile kt + 1, or the next tile's 0: into the stage read one k-tile ago, whose reads
+        sstore(rs, kstore, edge);            // k-tile kt + 1, or the next tile's 0: into the stage read one k-tile ago, whose reads
         fread(f1, cur, 3);                   // all ended before the previous barrier
         fmma(f0);
         __syncthreads();
@@ -211,23 +213,30 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
         fmma(f1);
     };
 
+    constexpr std::true_type EDGE{};
+    constexpr std::false_type PLAIN{};
     point_at(crow, ccol);
-    gload(r0, 0);
-    gload(r1, 1);
-    sstore(r0, 0);
+    gload(r0, 0, EDGE);
+    gload(r1, 1, EDGE);
+    sstore(r0, 0, EDGE);
     __syncthreads();
     fread(f0, 0, 0);
     while (true) {
         clear();
-        for (int kt = 0; kt + 2 < KT; kt += 2) {
-            ktile(kt, kt + 2, kt + 1, r0, r1);
-            ktile(kt + 1, kt + 3, kt + 2, r1, r0);
+        int kt = 0;
+        for (; kt + 4 < KT; kt += 2) {
+            ktile(kt, kt + 2, kt + 1, r0, r1, PLAIN);
+            ktile(kt + 1, kt + 3, kt + 2, r1, r0, PLAIN);
+        }
+        if (kt + 2 < KT) {                   // loads and stores k-tiles KT-2 and KT-1: the ones a ragged d reaches into
+            ktile(kt, kt + 2, kt + 1, r0, r1, EDGE);
+            ktile(kt + 1, kt + 3, kt + 2, r1, r0, EDGE);
         }
         // the last two k-tiles fetch the first two of the next tile (after the last tile: of the same one again, unused)
         const int nxt = next_tile(cur_b + step, lrow, lcol);
         if (nxt >= 0) point_at(lrow, lcol);
-        ktile(KT - 2, 0, KT - 1, r0, r1);
-        ktile(KT - 1, 1, 0, r1, r0);
+        ktile(KT - 2, 0, KT - 1, r0, r1, EDGE);
+        ktile(KT - 1, 1, 0, r1, r0, EDGE);
 
         // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
         const bool whole = crow + BM <= g.Q && ccol + BN <= g.N;
