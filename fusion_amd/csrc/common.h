@@ -68,6 +68,16 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
     return v;
 }
 
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
 // ---- VALU-only cross-lane steps (no ds_bpermute round trip through the LDS pipe) ------------------------------
 // DPP controls: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_mirror = 0x140, row_half_mirror = 0x141.
 template <int CTRL>

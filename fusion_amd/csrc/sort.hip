@@ -49,15 +49,6 @@ struct SortArgs {
     float* row_std;              //   of having the row in registers (the z-score statistics of hybrid.py:261-262); plain rows only
 };
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
-
 // GEN (fp64 only): the generic eight-pass form, run as a second launch for the rows the fast form flags (see below).
 template <int T, int E, int KW, bool GEN>
 __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {

@@ -621,3 +621,49 @@ def test_topk_stream_flags_candidate_overflow(ops):
     st = ops.TopkStream(bs, bi, seen=4096, cap=500)
     st.feed(S[:, 4096:], 4096)
     assert int(st.result()[2].item()) == 1
+
+
+# ---- percentile-rank / NCE: the windowed nearest-entry look-up against the plain first-argmin ------------------------------------------
+def _nearest_first_argmin(tab, x):
+    """hybrid.py:272-275 in NumPy: index of the FIRST minimum of |tab - x| computed in float32 (NaN distances: argmin's rule)."""
+    d = np.abs(tab[None, :].astype(np.float32) - x.reshape(-1, 1).astype(np.float32))
+    return np.argmin(d, axis=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["mass_points", "huge_offset", "tiny_table", "wide_magnitudes", "exact_hits_and_midpoints", "two_values"])
+def test_percentile_rank_window_lookup_edge_cases(ops, case):
+    """The table kernel's look-up (bucket guess + window of eight distinct values, exact search when the window cannot prove its
+    answer) must give torch's first-argmin index for every score: repeated quantiles (mass points), scores far outside the table
+    (all distances round to one float), tables with fewer than eight distinct values, magnitudes where float32 spacing exceeds the
+    table's, scores on entries and on midpoints between them (ties -> lower index), +-inf and NaN."""
+    rng = np.random.default_rng(len(case))
+    P = 1001
+    if case == "mass_points":
+        tab = np.sort(np.concatenate([np.zeros(400), rng.normal(5, 2, 300).clip(0), np.full(200, 7.5), rng.normal(9, 1, 101)])).astype(np.float32)
+        x = np.concatenate([rng.normal(5, 4, 5000), np.zeros(50), np.full(50, 7.5), [1e-30, -1e-30, 7.4999995, 7.5000005]])
+    elif case == "huge_offset":
+        tab = np.sort(rng.normal(0, 1, P)).astype(np.float32)
+        x = np.concatenate([rng.normal(0, 1, 3000), [1e9, -1e9, 3e38, -3e38, 1e6, -1e6, 50.0, -50.0, np.inf, -np.inf, np.nan]])
+    elif case == "tiny_table":
+        tab = np.array([-1.0, 0.0, 0.0, 2.0, 2.5], dtype=np.float32)
+        x = np.concatenate([rng.normal(0.5, 2, 2000), [-1, 0, 2, 2.5, 1.0, -0.5, 2.25]])
+    elif case == "wide_magnitudes":
+        tab = np.sort(1e6 + rng.integers(0, 4000, P) * 0.0625).astype(np.float32)        # float32 spacing at 1e6 is 0.0625: neighbours collide
+        x = np.concatenate([1e6 + rng.uniform(-10, 260, 4000), [0.0, 2e6]])
+    elif case == "exact_hits_and_midpoints":
+        tab = np.sort(rng.integers(-500, 500, P) * 0.25).astype(np.float32)
+        mids = (tab[:-1].astype(np.float64) + tab[1:]) / 2
+        x = np.concatenate([tab, mids, rng.uniform(-130, 130, 2000)])
+    else:
+        tab = np.sort(np.concatenate([np.full(500, -3.0), np.full(501, 4.0)])).astype(np.float32)
+        x = np.concatenate([rng.normal(0.5, 3, 3000), [0.5, 0.49999997, 0.50000006]])
+    x = x.astype(np.float32)
+    Q = 3
+    n = len(x)
+    S = np.stack([x, x[::-1], np.roll(x, 7)]).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        k = np.stack([_nearest_first_argmin(tab, r) for r in S])
+    exp = (k.astype(np.float32) / np.float32(len(tab))) * np.float32(1.0) + np.float32(0.0)
+    got = ops.fuse_nsf([ops.as_plane(torch.from_numpy(S).cuda())], None, [1.0], "percentile-rank", [torch.from_numpy(tab).cuda()]).cpu().numpy()
+    np.testing.assert_array_equal(got, exp)

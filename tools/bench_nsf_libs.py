@@ -18,3 +18,8 @@ out = ops.alloc_plane(Q, N, torch.float32, "cuda")
 for lib in sys.argv[1:]:
     _lib._lib = None; _lib.LIB_PATH = os.path.abspath(lib)
     print(os.path.basename(lib), {n: round(timeit(lambda: ops.fuse_nsf(planes, None, [0.25] * S, n, out=out)), 4) for n in ("min-max", "z-score", "arctan")}, flush=True)
+    import numpy as np
+    P = 1001
+    distr = [torch.quantile(p[:64].flatten()[:1 << 20].double(), torch.linspace(0, 1, P, device="cuda", dtype=torch.float64)).float() for p in planes]
+    print(os.path.basename(lib), {n: round(timeit(lambda: ops.fuse_nsf(planes, None, [0.25] * S, n, distr, out=out)), 4)
+                                  for n in ("percentile-rank", "normal-curve-equivalent")}, flush=True)
