@@ -65,6 +65,8 @@ def parse():
                    help="leave the encoder's fp32 Linears to the library heuristics instead of PyTorch TunableOp (fusion_amd/tuned/gemm_gfx950.csv)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-configs", action="store_true", help="skip the configs_measured block (configs 2-5 timed live after the headline region)")
+    p.add_argument("--no-one-gpu-reference", action="store_true",
+                   help="sharded workload at N > 1: skip the same workload on rank 0 alone (whole corpus on one GPU), reported next to the N-GPU value")
     p.add_argument("--mmarco-docs", type=int, default=8841823)
     p.add_argument("--topk", type=int, default=1000)
     p.add_argument("--rehearsal", action="store_true",
@@ -583,6 +585,39 @@ def bench_sharded(args, dev, rank, world, dist):
            "ranks": devs, "shard_rows": hi - lo,
            "sharded_equals_single_gpu": {"equal": same, "corpus": Ns, "queries": 64, "k": k,
                                          "what": "ShardedDenseIndex.search over this world's shards vs one-GPU local_topk of the whole corpus, scores and ids bit for bit"}}
+    if rank == 0 and world > 1 and not args.no_one_gpu_reference:
+        # the SAME workload on this GPU alone (all queries encoded here, the whole corpus searched here, no collective): what the
+        # N-GPU value is to be held against -- the default one-GPU bench line is the LLeQA workload, a different job
+        try:
+            whole = torch.empty((N, d), dtype=torch.float32, device=dev)
+            whole[lo:hi] = Dn
+            for r in range(world):
+                if r == rank:
+                    continue
+                rlo, rhi = shard_bounds(N, world, r)
+                gr = torch.Generator(device=dev).manual_seed(1000 + r)
+                for c0 in range(rlo, rhi, 1 << 20):
+                    c1 = min(rhi, c0 + (1 << 20))
+                    whole[c0:c1] = ops.normalize_rows(torch.randn((c1 - c0, d), generator=gr, device=dev))
+            widx = ShardedDenseIndex(whole, 0, None)
+            ids_all = torch.from_numpy(ids).to(dev) if enc is not None else None
+
+            def step1():
+                e = enc.encode_ids_packed(ids_all, qlen_all) if enc is not None else q_emb
+                return widx.local_topk(ops.normalize_rows(e), k)
+            n1 = max(1, min(args.steps, 3))
+            step1(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n1):
+                step1()
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            res["same_workload_one_gpu"] = {"n_gpus": 1, "value": Q * n1 / e1, "unit": "queries/s", "ms_per_step": 1e3 * e1 / n1, "steps": n1,
+                                            "what": "rank 0 alone: all queries encoded and the whole corpus searched on one GPU, no collective; "
+                                                    "timed after the N-GPU region while the other ranks idle"}
+            del whole, widx
+        except RuntimeError as ex:   # e.g. out of memory on a smaller part
+            res["same_workload_one_gpu"] = {"error": str(ex)[:200]}
     if rank == 0 and not args.no_cpu_baseline:
         # the oracle's search (cos -> top-k) on a bounded sample: 16 queries x 1/8 of this rank's shard, OpenMP
         from oracle import oracle
