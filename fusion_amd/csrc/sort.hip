@@ -731,19 +731,21 @@ __global__ __launch_bounds__(256) void topk_filter_kernel(FilterArgs a) {
         int off = base, tot = 0;
 #pragma unroll
         for (int i = 0; i < NW; ++i) { const int c = wtot[i]; if (i < w) off += c; tot += c; }
-        // ---- pass 2: the marked steps again, survivors to their slots
-        while (marked) {
-            const int st = __builtin_ctzll(marked);
-            marked &= marked - 1;
+        // ---- pass 2: the marked steps again, survivors to their slots.  Four marked steps at a time, their loads issued together
+        // (one step at a time is a chain of L2 round trips: at 0.4 % survivors two thirds of the steps are marked and this pass
+        // took as long as the HBM pass)
+        auto place = [&](int st, const float (&v)[4]) {
             const int j0 = w0 + st * STEP + lane * 4;
-            float v[4];
-            load4(j0, v);
+            // survivors of lower lanes + own earlier ones, from four ballots (no shuffle chain: this runs once per marked step)
             bool keep[4];
-            int c = 0;
+            int pos = off, tot_st = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { keep[e] = (j0 + e < a.n) && !(v[e] <= tau); c += keep[e] ? 1 : 0; }
-            const int incl = (int)wave_incl_scan_u32((uint32_t)c, lane);
-            int pos = off + incl - c;
+            for (int e = 0; e < 4; ++e) {
+                keep[e] = (j0 + e < a.n) && !(v[e] <= tau);
+                const unsigned long long bal = __ballot(keep[e]);
+                pos += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                tot_st += __popcll(bal);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (keep[e]) {
@@ -751,7 +753,32 @@ __global__ __launch_bounds__(256) void topk_filter_kernel(FilterArgs a) {
                     else over = true;
                     ++pos;
                 }
-            off += __shfl(incl, 63, 64);
+            off += tot_st;
+        };
+        // a step is "inner" when all its 256 columns exist: plain 16-byte loads; the (at most one) ragged step goes last, guarded
+        const int inner = vec ? max(0, min(steps, (a.n - w0) / STEP)) : 0;
+        unsigned long long in_m = inner >= 64 ? marked : (marked & ((1ull << inner) - 1ull));
+        unsigned long long rest = marked & ~in_m;
+        while (in_m) {
+            int st[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {          // the group's steps; a short last group repeats its last step (loaded, not placed)
+                st[u] = in_m ? __builtin_ctzll(in_m) : st[u > 0 ? u - 1 : 0];
+                if (in_m) in_m &= in_m - 1; else st[u] |= 0x40000000;
+            }
+            float4 f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f[u] = *reinterpret_cast<const float4*>(x + w0 + (st[u] & 0xffff) * STEP + lane * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (!(st[u] & 0x40000000)) { const float v[4] = {f[u].x, f[u].y, f[u].z, f[u].w}; place(st[u], v); }
+        }
+        while (rest) {
+            const int st = __builtin_ctzll(rest);
+            rest &= rest - 1;
+            float v[4];
+            load4(w0 + st * STEP + lane * 4, v);
+            place(st, v);
         }
         base += tot;
     }
