@@ -671,7 +671,10 @@ def main():
             res["rehearsal"] = "ranks share devices: control-flow rehearsal only, the numbers mean nothing"
         if rank == 0:
             print(json.dumps(res))
-        if dist: dist.destroy_process_group()
+        if dist:
+            torch.cuda.synchronize()
+            dist.barrier()                      # rank 0's extras (one-GPU reference, CPU baseline) end before any rank tears the group down
+            dist.destroy_process_group()
         return
 
     st = build_lleqa(args, dev, rank)
