@@ -131,6 +131,16 @@ def case_topk(rng):
 
 def case_cos(rng):
     Q, N, d = int(rng.integers(1, 300)), int(rng.integers(1, 3000)), int(rng.integers(1, 200) * 4)
+    if rng.random() < 0.25:   # more tiles than resident workgroups: several tiles per workgroup, half tiles in the last round
+        Q, N, d = int(rng.integers(1, 700)), int(rng.integers(30000, 120000)), int(rng.integers(1, 24) * 4)
+        g = torch.Generator(device="cuda").manual_seed(int(rng.integers(0, 1 << 30)))
+        A = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
+        B = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
+        S = ops.dot_scores(A, B)
+        for r0 in range(0, Q, 256):
+            ref = A[r0:r0 + 256].double() @ B.double().t()
+            assert (S[r0:r0 + 256].double() - ref).abs().max().item() <= 2e-6
+        return f"cos (tile stream) Q={Q} N={N} d={d}"
     A, B = rng.normal(0, 1, (Q, d)).astype(np.float32), rng.normal(0, 1, (N, d)).astype(np.float32)
     got = ops.cos_scores(dev(A), dev(B)).cpu().numpy()
     assert np.max(np.abs(got - oracle.cos_scores(A, B))) <= 2e-6
