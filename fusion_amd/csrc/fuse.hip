@@ -92,7 +92,9 @@ __device__ __forceinline__ float tmin(float a, float b) { return (a != a || b !=
 __device__ __forceinline__ float tmax(float a, float b) { return (a != a || b != b) ? __uint_as_float(0x7fc00000u) : fmaxf(a, b); }
 
 // -------------------------------------------------------------------------------------
-// K3: row statistics.  One workgroup per row; streaming 16-B loads; fp64 accumulation.
+// K3: row statistics.  One workgroup per row; fp64 accumulation.  Rows of up to 32,768 aligned columns are read ONCE with 16-byte
+// loads and kept in registers for the second (centred) pass of the z-score; longer or unaligned rows stream twice (second time
+// from cache) with 4-byte loads.
 // -------------------------------------------------------------------------------------
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void row_stats_kernel(const float* __restrict__ scores, const int32_t* __restrict__ rank,
@@ -103,6 +105,69 @@ __global__ __launch_bounds__(THREADS) void row_stats_kernel(const float* __restr
     const int row = blockIdx.x;
     const float* x = scores + (size_t)row * ld;
     const int32_t* v = rank ? rank + (size_t)row * ld : nullptr;
+    constexpr int E4 = 8;   // float4 per thread held in registers on the one-pass path
+    const bool resident = THREADS == 1024 && N <= THREADS * E4 * 4 && ld % 4 == 0 && ((uintptr_t)scores % 16 == 0) && (!rank || (uintptr_t)rank % 16 == 0);
+    if (resident && (norm == FZ_NORM_MINMAX || norm == FZ_NORM_ZSCORE)) {   // block-uniform
+        float4 r[E4];
+        uint32_t ok = 0u;                                       // bit 4*i + e: element e of r[i] is a listed column
+#pragma unroll
+        for (int i = 0; i < E4; ++i) {
+            const int j0 = 4 * (i * THREADS + threadIdx.x);
+            r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j0 < N) {
+                r[i] = *reinterpret_cast<const float4*>(x + j0);  // columns [N, ld) of the last float4 are plane padding
+                int4 vv = make_int4(0, 0, 0, 0);
+                if (v) vv = *reinterpret_cast<const int4*>(v + j0);
+                const int vr[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ok |= (uint32_t)((j0 + e < N) && vr[e] >= 0) << (4 * i + e);
+            }
+        }
+        if (norm == FZ_NORM_MINMAX) {
+            float mn = INFINITY, mx = -INFINITY;
+            bool nan = false;
+#pragma unroll
+            for (int i = 0; i < E4; ++i) {
+                const float f[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((ok >> (4 * i + e)) & 1u) { nan |= (f[e] != f[e]); mn = fminf(mn, f[e]); mx = fmaxf(mx, f[e]); }
+            }
+            block_minmax<THREADS>(mn, mx, red_f);
+            const int anynan = __syncthreads_or(nan ? 1 : 0);
+            if (threadIdx.x == 0) {
+                stat_a[row] = anynan ? __uint_as_float(0x7fc00000u) : mn;
+                stat_b[row] = anynan ? __uint_as_float(0x7fc00000u) : mx;
+            }
+        } else {
+            double sum = 0.0, cnt = 0.0;
+#pragma unroll
+            for (int i = 0; i < E4; ++i) {
+                const float f[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((ok >> (4 * i + e)) & 1u) { sum += (double)f[e]; cnt += 1.0; }
+            }
+            sum = block_sum<THREADS>(sum, red_d);
+            cnt = block_sum<THREADS>(cnt, red_d);
+            const double mean = cnt > 0.0 ? sum / cnt : (double)NAN;
+            double ss = 0.0;
+#pragma unroll
+            for (int i = 0; i < E4; ++i) {
+                const float f[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((ok >> (4 * i + e)) & 1u) { const double d = (double)f[e] - mean; ss += d * d; }
+            }
+            ss = block_sum<THREADS>(ss, red_d);
+            if (threadIdx.x == 0) {
+                const double var = cnt > 1.0 ? ss / (cnt - 1.0) : (double)NAN;
+                stat_a[row] = (float)mean;
+                stat_b[row] = (float)sqrt(var);
+            }
+        }
+        return;
+    }
     if (norm == FZ_NORM_MINMAX) {
         float mn = INFINITY, mx = -INFINITY;
         bool nan = false;
@@ -930,7 +995,7 @@ extern "C" int fz_row_stats_f32(const float* scores, const int32_t* rank, int ro
     if (rows < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
     if (rows == 0) return FZ_OK;                   // empty tensors carry null pointers
     if (!scores || !stat_a || !stat_b) return FZ_ERR_ARG;
-    row_stats_kernel<512><<<rows, 512, 0, as_stream(stream)>>>(scores, rank, N, ld, norm, stat_a, stat_b);
+    row_stats_kernel<1024><<<rows, 1024, 0, as_stream(stream)>>>(scores, rank, N, ld, norm, stat_a, stat_b);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }
