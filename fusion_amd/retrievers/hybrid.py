@@ -215,6 +215,12 @@ class Aggregator:
                     # ranked systems bring their row statistics along (by-product of the ranking sort): one flat pass
                     fused = ops.fuse_nsf([s.scores for s in S], None, w, normalization,
                                          stats=(torch.cat([s.zstats[0] for s in S]), torch.cat([s.zstats[1] for s in S])))
+                elif normalization == "z-score" and all(s.zstats is not None for s in S if s.full):
+                    # some lists are partial: their statistics (over the listed documents only) take one small reduction each, the
+                    # full systems bring theirs, and the fusion is the same flat pass with the validity read as bitmaps
+                    st = [s.zstats if s.full else ops.row_stats(s.scores, s.rank, "z-score") for s in S]
+                    fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization,
+                                         stats=(torch.cat([a for a, _ in st]), torch.cat([b for _, b in st])), valid_bits=vbits)
                 elif normalization == "min-max" and all(s.score_sorted for s in S):
                     # score-sorted lists: min / max are the two ends of every list, no row reduction
                     fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, orders=[s.order for s in S],
