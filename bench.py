@@ -404,7 +404,8 @@ def measure_configs(dev, N=27942):
         planes = [rand_plane(ops, Q, N, g, s + 1.0, float(s)) for s in range(4)]
         systems = {}
         for i, (n, p) in enumerate(zip(names, planes)):
-            od, sk, rk = ops.sort_rows_desc(p, want_rank=True)
+            zst = (torch.empty(Q, dtype=torch.float32, device=dev), torch.empty(Q, dtype=torch.float32, device=dev))
+            od, sk, rk = ops.sort_rows_desc(p, want_rank=True, stats_out=zst)   # mean / std fall out of the ranking sort (hybrid._rank_scores)
             if n == "colbert":   # PLAID-style short lists: the last 40 % of every ranking is absent
                 k = int(0.6 * N)
                 rk = torch.where(rk < k, rk, torch.full_like(rk, -1)); od = od.clone(); od[:, k:] = -1
@@ -412,7 +413,7 @@ def measure_configs(dev, N=27942):
                                           ids=np.arange(N), full=False, score_sorted=True)
             else:
                 systems[n] = RankedSystem(scores=p, order=od, rank=rk, lens=torch.full((Q,), N, dtype=torch.int32, device=dev),
-                                          ids=np.arange(N), full=True, score_sorted=True)
+                                          ids=np.arange(N), full=True, score_sorted=True, zstats=zst)
         ranks = [None if s.full else s.rank for s in systems.values()]   # what Aggregator.fuse_device passes: validity of the partial list only
         w = [0.25] * 4
         fused = ops.alloc_plane(Q, N, torch.float32, dev)
@@ -427,7 +428,13 @@ def measure_configs(dev, N=27942):
             # called the way Aggregator.fuse_device calls it: min-max of score-sorted lists takes the statistics from the list ends
             kw = dict(orders=orders, lens=lens4) if norm == "min-max" else {}
             kw["valid_bits"] = vbits
-            ms = timeit_ms(lambda: ops.fuse_nsf(planes, ranks, w, norm, distr if norm == "percentile-rank" else None, out=fused, **kw), n=10)
+
+            def call():
+                if norm == "z-score":   # as fuse_device: the full systems' statistics come from their ranking, the partial list's from one reduction
+                    st = [s.zstats if s.full else ops.row_stats(s.scores, s.rank, "z-score") for s in systems.values()]
+                    return ops.fuse_nsf(planes, ranks, w, norm, out=fused, stats=(torch.cat([a for a, _ in st]), torch.cat([b for _, b in st])), **kw)
+                return ops.fuse_nsf(planes, ranks, w, norm, distr if norm == "percentile-rank" else None, out=fused, **kw)
+            ms = timeit_ms(call, n=10)
             out.append(dict(config=f"4: nsf {norm} fusion, S=4, colbert 40% absent", shape=dict(Q=Q, N=N, S=4),
                             **roof("fuse_nsf kernels", ms, work, "hbm")))
         ms = timeit_ms(lambda: Aggregator.fuse_device(systems, "nsf", "min-max", dict(zip(names, w)), {}), n=5)
