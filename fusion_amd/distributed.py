@@ -67,7 +67,7 @@ class ShardedDenseIndex:
 
     CHUNK = 8 * 28672   # documents per GEMM launch: 8 sort-kernel rows per query
     CAP = 7168          # candidate slots per row and chunk on the streaming path (k + CAP = one 8192-key sort row at k = 1024)
-    HEAD = 28672        # columns of the FIRST chunk that are sorted exactly (one sort-kernel row); the rest of it streams
+    HEAD = 28672        # at most this many leading documents get the exact top-k (one sort-kernel row); 8 k of them (>= 8192) are enough
 
     def __init__(self, Dn_local: torch.Tensor, id_base: int, group=None):
         self.Dn, self.id_base, self.group = Dn_local, int(id_base), group
@@ -84,7 +84,8 @@ class ShardedDenseIndex:
         from . import ops
         mark = mark or (lambda name: None)
         n = self.Dn.shape[0]
-        streaming = streaming and k + self.CAP <= 35840 and k <= self.HEAD // 8 and n > self.HEAD
+        head = min(self.HEAD, max(8192, -(-8 * k // 4096) * 4096))   # 8192 at k = 1000: a 0.09 ms sort instead of 0.35, one fold more
+        streaming = streaming and k + self.CAP <= 35840 and k <= head // 8 and n > head
         best_s = best_i = stream = None
         for c0 in range(0, max(n, 1), self.CHUNK):
             c1 = min(n, c0 + self.CHUNK)
@@ -92,7 +93,7 @@ class ShardedDenseIndex:
             if streaming:
                 lo = 0
                 if stream is None:
-                    lo = min(self.HEAD, c1 - c0)
+                    lo = min(head, c1 - c0)
                     bs, bi = ops.topk_rows(S[:, :lo], k, id_base=self.id_base + c0)
                     stream = ops.TopkStream(bs, bi, seen=lo, cap=self.CAP)
                 stream.feed(S[:, lo:], self.id_base + c0 + lo); mark("shard_topk_stream")

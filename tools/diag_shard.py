@@ -13,9 +13,9 @@ for c0 in range(0, N, 1 << 19):
     Dn[c0:c1] = ops.normalize_rows(torch.randn((c1 - c0, d), generator=g, device="cuda"))
 Qn = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
 idx = ShardedDenseIndex(Dn, 0)
-for chunk in [int(x) for x in sys.argv[1:]] or [ShardedDenseIndex.CHUNK]:
-  idx.CHUNK = chunk
-  print('CHUNK', chunk)
+for head in [int(x) for x in sys.argv[1:]] or [ShardedDenseIndex.HEAD]:
+  idx.HEAD = head
+  print('HEAD', head)
   for rep in range(3):
       evs = []
       def mark(name):
