@@ -15,7 +15,6 @@ Ties are broken by ascending global document id everywhere, so the result does n
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 

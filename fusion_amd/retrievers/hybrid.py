@@ -22,7 +22,6 @@ from __future__ import annotations
 import argparse
 import itertools
 import os
-import sys
 from os.path import join
 
 import numpy as np
