@@ -408,7 +408,7 @@ def measure_configs(dev, N=27942):
             od, sk, rk = ops.sort_rows_desc(p, want_rank=True, stats_out=zst)   # mean / std fall out of the ranking sort (hybrid._rank_scores)
             if n == "colbert":   # PLAID-style short lists: the last 40 % of every ranking is absent
                 k = int(0.6 * N)
-                rk = torch.where(rk < k, rk, torch.full_like(rk, -1)); od = od.clone(); od[:, k:] = -1
+                rk = ops.as_plane(torch.where(rk < k, rk, torch.full_like(rk, -1))); od = od.clone(); od[:, k:] = -1   # planes, as _rank_scores hands them on
                 systems[n] = RankedSystem(scores=p, order=od, rank=rk, lens=torch.full((Q,), k, dtype=torch.int32, device=dev),
                                           ids=np.arange(N), full=False, score_sorted=True)
             else:

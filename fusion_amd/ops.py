@@ -290,6 +290,7 @@ def row_stats(scores: torch.Tensor, rank: torch.Tensor | None, norm: str):
     if rank is not None:
         _dev(rank, torch.int32, "row_stats(rank)")
         _same_shape([scores, rank], "row_stats")
+        scores, rank = harmonise([scores, rank])
         _same_ld(scores, rank)
     check(_lib.lib().fz_row_stats_f32(_ptr(scores), _ptr(rank), rows, N, _ld(scores), NORMS[norm], _ptr(a), _ptr(b), _stream(scores)),
           "fz_row_stats_f32")

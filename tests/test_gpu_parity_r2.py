@@ -667,3 +667,16 @@ def test_percentile_rank_window_lookup_edge_cases(ops, case):
     exp = (k.astype(np.float32) / np.float32(len(tab))) * np.float32(1.0) + np.float32(0.0)
     got = ops.fuse_nsf([ops.as_plane(torch.from_numpy(S).cuda())], None, [1.0], "percentile-rank", [torch.from_numpy(tab).cuda()]).cpu().numpy()
     np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.gpu
+def test_row_stats_accepts_a_rank_tensor_with_its_own_row_stride(ops, oracle):
+    """ops.row_stats(scores plane, rank as a plain contiguous tensor): the odd stride is copied out, as fuse_nsf does."""
+    rng = np.random.default_rng(3)
+    Q, N = 3, 1001
+    p = rng.normal(0, 1, (Q, N)).astype(np.float32)
+    r = np.where(rng.random((Q, N)) < 0.6, 1, -1).astype(np.int32)
+    mean, std = ops.row_stats(ops.as_plane(torch.from_numpy(p).cuda()), torch.from_numpy(r).cuda(), "z-score")
+    for q in range(Q):
+        v = p[q][r[q] >= 0].astype(np.float64)
+        assert abs(float(mean[q]) - v.mean()) <= 1e-6 and abs(float(std[q]) - v.std(ddof=1)) <= 1e-6
