@@ -569,10 +569,15 @@ def bench_sharded(args, dev, rank, world, dist):
 
     chunk = min(ShardedDenseIndex.CHUNK, hi - lo)
     rl_all = {}
-    if "shard_gemm" in per_launch:
+    if "shard_gemm_filter" in per_launch:   # the shard's GEMM with the threshold filter as its epilogue (everything behind the exact head)
+        head_docs = min(hi - lo, max(8192, -(-8 * k // 4096) * 4096))
+        rl_all["shard_gemm_filter"] = roof("dot_scores_kernel<filter epilogue>", per_launch["shard_gemm_filter"],
+                                           2.0 * Q * (hi - lo - head_docs) * d / cnt["shard_gemm_filter"] * args.steps, "mfma_f32",
+                                           launches_per_step=cnt["shard_gemm_filter"] // args.steps)
+    elif "shard_gemm" in per_launch:
         rl_all["shard_gemm"] = roof("dot_scores_kernel", per_launch["shard_gemm"], 2.0 * Q * (hi - lo) * d / cnt["shard_gemm"] * args.steps, "mfma_f32",
                                     launches_per_step=cnt["shard_gemm"] // args.steps)
-    if "shard_topk_stream" in stages:   # per step: one streaming pass over all the shard's scores (+ the exact head, + a few row sorts)
+    if "shard_topk_stream" in stages and "shard_gemm_filter" not in per_launch:   # unfused: one streaming pass over all the shard's scores
         rl_all["shard_topk_stream"] = roof("topk_filter (threshold filter, append) + topk_rows head + sort_rows folds", stages["shard_topk_stream"],
                                            Q * (hi - lo) * 4, "hbm", launches_per_step=1)
     dom = max((kx for kx in rl_all), key=lambda kx: stages.get(kx, 0.0))
@@ -582,7 +587,7 @@ def bench_sharded(args, dev, rank, world, dist):
            "data": "synthetic",
            "config": {"workload": f"mMARCO-fr-shaped sharded DPR encode+score (BASELINE.json configs[4]): N={N} passages x d={d} fp32 row-sharded x{world}, "
                                   f"Q={Q} queries per step, top-{k}; data-parallel CamemBERT-base-shaped fp32 query encoder + all-gather of embeddings, "
-                                  "chunked fp32-MFMA cos-sim GEMM -> streaming top-k per shard, ONE RCCL all-gather of per-shard top-k + local merge",
+                                  "chunked fp32-MFMA cos-sim GEMM with the streaming top-k's threshold filter as its epilogue (no score plane), ONE RCCL all-gather of per-shard top-k + local merge",
                       "corpus": N, "dim": d, "queries_per_step": Q, "topk": k, "encode_in_step": enc is not None,
                       "parallelism": f"corpus row-sharded x{world} (RCCL all-gather of [Q,k] lists), encoder data-parallel x{world}"},
            "stages_ms": stages, "roofline": rl, "roofline_all": rl_all,

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfusion_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 FZ_OK, FZ_ERR_ARG, FZ_ERR_UNSUPPORTED, FZ_ERR_HIP, FZ_ERR_WORKSPACE = 0, -1, -2, -3, -4
 NORMS = {"min-max": 1, "z-score": 2, "arctan": 3, "percentile-rank": 4, "normal-curve-equivalent": 5}
@@ -42,6 +42,7 @@ _PROTOS = {
     "fz_abi_version": (_i, []),
     "fz_normalize_rows_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "fz_dot_scores_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "fz_dot_scores_filter_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "fz_maxsim_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "fz_sort_max_n": (_i, []),
     "fz_sort_max_n_f64": (_i, []),
@@ -66,7 +67,7 @@ _PROTOS = {
     "fz_topk_update_f32": (_i, [_vp, _i, _i, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_topk_filter_append_f32": (_i, [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "fz_topk_fold_workspace_bytes": (_sz, [_i, _i, _i]),
-    "fz_topk_fold_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fz_topk_fold_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "fz_topk_allgather_workspace_bytes": (_sz, [_i, _i, _i]),
     "fz_topk_allgather": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -66,13 +66,21 @@ struct GemmArgs {
     float* C; int ldc;         // scores   [Q][ldc]
     int Q, N, d, QB, TN;
     int full, halves;          // tile ids < full are whole 128x128 tiles; then `halves` 128x64 half tiles (at most one per workgroup)
+    // FILTER form (fz_dot_scores_filter_f32): no score plane; what beats a query's threshold goes to its candidate list
+    const float* tau;          // [QB * 128]: tau[q] for q < Q, +inf beyond
+    float* cand_s;             // [Q][cap]
+    int64_t* cand_i;           // [Q][cap]
+    int32_t* cand_len;         // [Q] number of candidates so far (may run past cap: the excess is dropped and *overflow set)
+    int32_t* overflow;
+    int cap;
+    int64_t id_base;           // document id of corpus row 0
 };
 
 // One workgroup's share of the tiles: ids first, first + step, ... below `end`, all of one shape (128 x BN).  The k-tiles of
 // ALL those tiles form one stream through the software pipeline: the operand loads of a tile's first two k-tiles are issued
 // during the last two k-tiles of the tile before it, and its score stores drain under the next tile's MFMAs -- a workgroup
 // pays the pipeline fill once per launch, not once per tile.
-template <int BN, bool RAGGED /* d is not a whole number of k-tile pairs */>
+template <int BN, bool RAGGED /* d is not a whole number of k-tile pairs */, bool FILTER>
 __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int first, const int end, const int step) {
     constexpr int NI = BN / 64;          // 32x32 MFMA tiles per wave along N (wave tile = 64 x BN/2)
     constexpr int BROWS = BN / 32;       // staging float4 per thread for the corpus tile
@@ -239,6 +247,75 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
         ktile(KT - 1, 1, 0, r1, r0, EDGE);
 
         // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        if constexpr (FILTER) {
+            // Threshold filter in the epilogue: a score enters its query's candidate list iff it beats tau[q] (or is NaN) -- the
+            // score plane is never written.  One accumulator register of the wave = 32 documents x 2 queries (lane halves), a "step".
+            // Pass A counts per step and half by ballot and parks the counts in lane `step` of one register; then the lanes reserve
+            // their steps' slots with ONE round of atomics (64 steps in parallel); pass B recomputes the ballots and stores.
+            // Candidates of one (query, step) are in document order; ACROSS steps, waves and workgroups the order is arbitrary:
+            // fz_topk_fold_f32(unordered) re-establishes "ties by ascending id".
+            constexpr int STEPS = 2 * NI * 16;
+            const int h = lane >> 5;
+            const int qw = crow + wr * 64 + 4 * h;                      // + mi*32 + (r&3) + 8*(r>>2)
+            const int dw = ccol + wc * (BN / 2) + (lane & 31);          // + ni*32
+            auto beats = [&](int mi, int ni, int r, const float4& t4) __attribute__((always_inline)) -> bool {
+                const float tq = (r & 3) == 0 ? t4.x : (r & 3) == 1 ? t4.y : (r & 3) == 2 ? t4.z : t4.w;
+                // (rows past Q carry tau = +inf, but a NaN score beats even that: the row check stays)
+                return !(acc[mi][ni][r] <= tq) && dw + ni * 32 < g.N && qw + mi * 32 + (r & 3) + 8 * (r >> 2) < g.Q;
+            };
+            uint32_t counts = 0u;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(g.tau + qw + mi * 32 + 8 * rg);   // this lane half's thresholds, 4 rows
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int r = rg * 4 + rr;
+                            const unsigned long long bal = __ballot(beats(mi, ni, r, t4));
+                            const uint32_t c = (uint32_t)__popc((uint32_t)bal) | ((uint32_t)__popc((uint32_t)(bal >> 32)) << 16);
+                            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(counts) : "s"(c), "i"((mi * NI + ni) * 16 + r));   // c is wave-uniform
+                        }
+                }
+            // lane s owns step s = (mi*NI + ni)*16 + r: queries qa (lanes 0-31 of the step) and qa + 4 (lanes 32-63)
+            int base_lo = 0, base_hi = 0;
+            if (lane < STEPS) {
+                const int r = lane & 15, mi = lane / (16 * NI);
+                const int qa = crow + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2);
+                const int c_lo = counts & 0xffff, c_hi = counts >> 16;
+                if (c_lo) base_lo = atomicAdd(&g.cand_len[qa], c_lo);
+                if (c_hi) base_hi = atomicAdd(&g.cand_len[qa + 4], c_hi);
+            }
+            bool over = false;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(g.tau + qw + mi * 32 + 8 * rg);   // (again: 32 registers are not to spare)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int r = rg * 4 + rr, step = (mi * NI + ni) * 16 + r;
+                            const bool keep = beats(mi, ni, r, t4);
+                            const unsigned long long bal = __ballot(keep);
+                            if (bal == 0ull) continue;                     // wave-uniform
+                            const int b_lo = __builtin_amdgcn_readlane(base_lo, step), b_hi = __builtin_amdgcn_readlane(base_hi, step);
+                            const uint32_t mine = h ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                            const int pos = (h ? b_hi : b_lo) + __popc(mine & ((1u << (lane & 31)) - 1u));
+                            if (keep) {
+                                const int q = qw + mi * 32 + (r & 3) + 8 * (r >> 2);
+                                if (pos < g.cap) {
+                                    g.cand_s[(size_t)q * g.cap + pos] = acc[mi][ni][r];
+                                    g.cand_i[(size_t)q * g.cap + pos] = g.id_base + dw + ni * 32;
+                                } else over = true;
+                            }
+                        }
+                }
+            if (over) atomicExch(g.overflow, 1);
+        } else {
         const bool whole = crow + BM <= g.Q && ccol + BN <= g.N;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -256,6 +333,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
                         if (q0 + (r & 3) + 8 * (r >> 2) < g.Q) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[mi][ni][r];
                 }
             }
+        }
         if (nxt < 0) break;
         cur_b = nxt; crow = lrow; ccol = lcol;
     }
@@ -266,13 +344,13 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
 // are consecutive ids on one XCD, run at about the same time, and the corpus tile is fetched from HBM once.  The first `g.full`
 // ids are 128x128 tiles; the rest is the LAST partial round cut into 128x64 halves, so that the tail occupies every CU for half a
 // tile time instead of half the CUs for a whole one (1792 equal tiles on 512 slots otherwise cost 4 rounds for 3.5 of work).
-template <bool RAGGED>
+template <bool RAGGED, bool FILTER>
 __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    gemm_stream<128, RAGGED>(g, lds, blockIdx.x, g.full, gridDim.x);
+    gemm_stream<128, RAGGED, FILTER>(g, lds, blockIdx.x, g.full, gridDim.x);
     if ((int)blockIdx.x < g.halves) {
         __syncthreads();                     // the half tile restarts the pipeline in stage 0
-        gemm_stream<64, RAGGED>(g, lds, g.full + blockIdx.x, g.full + blockIdx.x + 1, 1);
+        gemm_stream<64, RAGGED, FILTER>(g, lds, g.full + blockIdx.x, g.full + blockIdx.x + 1, 1);
     }
 }
 
@@ -290,18 +368,9 @@ extern "C" int fz_normalize_rows_f32(const float* X, int rows, int d, int ldx, f
     return FZ_OK;
 }
 
-extern "C" int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int ldd, int Q, int N, int d, float* scores, int lds,
-                                 void* stream) {
-    if (Q < 0 || N < 0 || d <= 0 || ldq < d || ldd < d || lds < N) return FZ_ERR_ARG;
-    if (Q == 0 || N == 0) return FZ_OK;           // empty tensors carry null pointers
-    if (!Qn || !Dn || !scores) return FZ_ERR_ARG;
-    // 16-byte vector staging: the Python binding pads embeddings to a multiple of 4 floats
-    if ((d % 4) || (ldq % 4) || (ldd % 4) || ((uintptr_t)Qn % 16) || ((uintptr_t)Dn % 16)) return FZ_ERR_UNSUPPORTED;
-    GemmArgs g{};
-    g.A = Qn; g.lda = ldq; g.B = Dn; g.ldb = ldd; g.C = scores; g.ldc = lds;
-    g.Q = Q; g.N = N; g.d = d;
-    g.QB = (Q + BM - 1) / BM;
-    g.TN = (N + 127) / 128;
+static int launch_gemm(GemmArgs& g, bool filter, hipStream_t st) {
+    g.QB = (g.Q + BM - 1) / BM;
+    g.TN = (g.N + 127) / 128;
     const long B = 8L * g.QB * ((g.TN + 7) / 8);        // ids of whole tiles (incl. the XCD padding, which decodes to nothing)
     static int cus[64];
     int dev = 0;
@@ -317,15 +386,46 @@ extern "C" int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int 
     const long nblk = B < slots ? B : slots;
     constexpr size_t lds_db = 2 * (BM + 128) * LDT * sizeof(float);
     // per-lane offsets are signed 32-bit byte offsets inside one 128-row operand tile
-    if (128.0 * ldq * 4 >= 2147483648.0 || 128.0 * ldd * 4 >= 2147483648.0) return FZ_ERR_UNSUPPORTED;
-    static unsigned long long lds_set[2] = {0ull, 0ull};
-    if (d % (2 * BK)) {
-        if (int rc = raise_lds_limit((const void*)dot_scores_kernel<true>, lds_db, lds_set[1])) return rc;
-        dot_scores_kernel<true><<<(unsigned)nblk, 256, lds_db, as_stream(stream)>>>(g);
-    } else {
-        if (int rc = raise_lds_limit((const void*)dot_scores_kernel<false>, lds_db, lds_set[0])) return rc;
-        dot_scores_kernel<false><<<(unsigned)nblk, 256, lds_db, as_stream(stream)>>>(g);
+    if (128.0 * g.lda * 4 >= 2147483648.0 || 128.0 * g.ldb * 4 >= 2147483648.0) return FZ_ERR_UNSUPPORTED;
+    static unsigned long long lds_set[4] = {0ull, 0ull, 0ull, 0ull};
+    const bool ragged = g.d % (2 * BK) != 0;
+#define FZ_GEMM_LAUNCH(RG, FL)                                                                                                   \
+    {                                                                                                                            \
+        if (int rc = raise_lds_limit((const void*)dot_scores_kernel<RG, FL>, lds_db, lds_set[2 * RG + FL])) return rc;           \
+        dot_scores_kernel<RG, FL><<<(unsigned)nblk, 256, lds_db, st>>>(g);                                                       \
     }
+    if (ragged && filter) FZ_GEMM_LAUNCH(true, true)
+    else if (ragged) FZ_GEMM_LAUNCH(true, false)
+    else if (filter) FZ_GEMM_LAUNCH(false, true)
+    else FZ_GEMM_LAUNCH(false, false)
+#undef FZ_GEMM_LAUNCH
     FZ_LAUNCH_CHECK();
     return FZ_OK;
+}
+
+extern "C" int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int ldd, int Q, int N, int d, float* scores, int lds,
+                                 void* stream) {
+    if (Q < 0 || N < 0 || d <= 0 || ldq < d || ldd < d || lds < N) return FZ_ERR_ARG;
+    if (Q == 0 || N == 0) return FZ_OK;           // empty tensors carry null pointers
+    if (!Qn || !Dn || !scores) return FZ_ERR_ARG;
+    // 16-byte vector staging: the Python binding pads embeddings to a multiple of 4 floats
+    if ((d % 4) || (ldq % 4) || (ldd % 4) || ((uintptr_t)Qn % 16) || ((uintptr_t)Dn % 16)) return FZ_ERR_UNSUPPORTED;
+    GemmArgs g{};
+    g.A = Qn; g.lda = ldq; g.B = Dn; g.ldb = ldd; g.C = scores; g.ldc = lds;
+    g.Q = Q; g.N = N; g.d = d;
+    return launch_gemm(g, false, as_stream(stream));
+}
+
+extern "C" int fz_dot_scores_filter_f32(const float* Qn, int ldq, const float* Dn, int ldd, int Q, int N, int d, int64_t id_base,
+                                        const float* tau_padded, float* cand_scores, int64_t* cand_ids, int32_t* cand_len, int cap,
+                                        int32_t* overflow, void* stream) {
+    if (Q < 0 || N < 0 || d <= 0 || ldq < d || ldd < d || cap <= 0) return FZ_ERR_ARG;
+    if (Q == 0 || N == 0) return FZ_OK;
+    if (!Qn || !Dn || !tau_padded || !cand_scores || !cand_ids || !cand_len || !overflow) return FZ_ERR_ARG;
+    if ((d % 4) || (ldq % 4) || (ldd % 4) || ((uintptr_t)Qn % 16) || ((uintptr_t)Dn % 16) || ((uintptr_t)tau_padded % 16)) return FZ_ERR_UNSUPPORTED;
+    GemmArgs g{};
+    g.A = Qn; g.lda = ldq; g.B = Dn; g.ldb = ldd;
+    g.Q = Q; g.N = N; g.d = d;
+    g.tau = tau_padded; g.cand_s = cand_scores; g.cand_i = cand_ids; g.cand_len = cand_len; g.cap = cap; g.id_base = id_base; g.overflow = overflow;
+    return launch_gemm(g, true, as_stream(stream));
 }

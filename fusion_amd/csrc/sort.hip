@@ -1172,28 +1172,80 @@ extern "C" int fz_topk_filter_append_f32(const float* scores, int rows, int n, i
     return FZ_OK;
 }
 
-extern "C" size_t fz_topk_fold_workspace_bytes(int rows, int k, int cap) { return fz_topk_update_workspace_bytes(rows, k, cap); }
+// Candidates that arrive in no particular order (the GEMM's filter epilogue appends them as its waves finish): the score sort is
+// stable, so equal scores come out in ARRIVAL order.  The sort therefore writes the first k + TIE_MARGIN entries to a scratch
+// list and this pass puts every run of equal scores that reaches into the first k into ascending id order (running-list entries
+// have smaller ids than any later candidate, so they stay in front).  A run still open at the end of the scratch list, or longer
+// than TIE_RUN_MAX, sets *overflow: the caller redoes the search on the exact path.
+constexpr int TIE_MARGIN = 64, TIE_RUN_MAX = 512;
+
+__global__ __launch_bounds__(256) void topk_tiefix_kernel(const float* tmp_s, const int64_t* tmp_i, const int32_t* buf_len, int k, int stride,
+                                                          float* out_s, int64_t* out_i, int32_t* overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tie_lds[];
+    int64_t* li = reinterpret_cast<int64_t*>(tie_lds);                 // [stride]
+    uint32_t* lk = reinterpret_cast<uint32_t*>(li + stride);           // [stride] sort keys of the scores (NaN == NaN, -0 == +0)
+    const int row = blockIdx.x;
+    const int have = buf_len[row];
+    const int L = min(have, stride);
+    const float* ts = tmp_s + (size_t)row * stride;
+    const int64_t* ti = tmp_i + (size_t)row * stride;
+    for (int p = threadIdx.x; p < L; p += blockDim.x) { lk[p] = desc_key_f32(ts[p]); li[p] = ti[p]; }
+    __syncthreads();
+    float* os = out_s + (size_t)row * k;
+    int64_t* oi = out_i + (size_t)row * k;
+    bool bad = false;
+    for (int p = threadIdx.x; p < max(L, k); p += blockDim.x) {
+        if (p >= L) { if (p < k) { os[p] = -INFINITY; oi[p] = -1; } continue; }      // short list: (-inf, -1) padding
+        const uint32_t key = lk[p];
+        int a = p, b = p + 1;
+        while (a > 0 && lk[a - 1] == key && p - a < TIE_RUN_MAX) --a;
+        if (a >= k) continue;                                                        // the run lies entirely behind the cut
+        while (b < L && lk[b] == key && b - p < TIE_RUN_MAX) ++b;
+        if ((a > 0 && lk[a - 1] == key) || (b < L && lk[b] == key) || (b == L && have > L)) { bad = true; continue; }
+        const int64_t id = li[p];
+        int rank = 0;
+        for (int j = a; j < b; ++j) rank += (li[j] < id) || (li[j] == id && j < p);
+        const int dst = a + rank;
+        if (dst < k) { os[dst] = ts[p]; oi[dst] = id; }
+    }
+    if (bad) atomicExch(overflow, 1);
+}
+
+extern "C" size_t fz_topk_fold_workspace_bytes(int rows, int k, int cap) {
+    if (rows <= 0 || k <= 0 || cap <= 0) return 0;
+    return fz_topk_update_workspace_bytes(rows, k, cap) + (size_t)rows * (k + TIE_MARGIN) * (4 + 8) + 256;
+}
 
 extern "C" int fz_topk_fold_f32(const float* run_scores, const int64_t* run_ids, int rows, int k, const float* cand_scores, const int64_t* cand_ids,
-                                int32_t* cand_len, int cap, float* new_scores, int64_t* new_ids, float* tau_out, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                int32_t* cand_len, int cap, int unordered, float* new_scores, int64_t* new_ids, float* tau_out, int32_t* overflow,
+                                void* workspace, size_t workspace_bytes, void* stream) {
     if (rows < 0 || k <= 0 || cap <= 0) return FZ_ERR_ARG;
     if ((long)k + cap > 35840) return FZ_ERR_UNSUPPORTED;
     if (rows == 0) return FZ_OK;
-    if (!run_scores || !run_ids || !cand_scores || !cand_ids || !cand_len || !new_scores || !new_ids) return FZ_ERR_ARG;
+    if (!run_scores || !run_ids || !cand_scores || !cand_ids || !cand_len || !new_scores || !new_ids || (unordered && !overflow)) return FZ_ERR_ARG;
     if (!workspace || workspace_bytes < fz_topk_fold_workspace_bytes(rows, k, cap)) return FZ_ERR_WORKSPACE;
     hipStream_t st = as_stream(stream);
     char* ws = reinterpret_cast<char*>(workspace);
     int64_t* buf_ids = reinterpret_cast<int64_t*>(ws); ws += (size_t)rows * (k + cap) * 8;
+    int64_t* tmp_ids = reinterpret_cast<int64_t*>(ws); ws += (size_t)rows * (k + TIE_MARGIN) * 8;
     float* buf_scores = reinterpret_cast<float*>(ws); ws += (size_t)rows * (k + cap) * 4;
+    float* tmp_scores = reinterpret_cast<float*>(ws); ws += (size_t)rows * (k + TIE_MARGIN) * 4;
     int32_t* buf_len = reinterpret_cast<int32_t*>(ws);
     topk_concat_kernel<<<rows, 256, 0, st>>>(run_scores, run_ids, k, cand_scores, cand_ids, cand_len, cap, buf_scores, buf_ids, buf_len);
     FZ_LAUNCH_CHECK();
+    const int lim = unordered ? k + TIE_MARGIN : k;
     SortArgs a{};
     a.keys = buf_scores; a.row_len = buf_len; a.n_total = k + cap; a.key_row_stride = k + cap; a.seg_len = k + cap;
     a.chunks = 1; a.chunk_len = k + cap;
-    a.sorted_keys = new_scores; a.out_ids = new_ids; a.idmap = buf_ids; a.out_row_stride = k; a.out_limit = k;
+    a.sorted_keys = unordered ? tmp_scores : new_scores; a.out_ids = unordered ? tmp_ids : new_ids; a.idmap = buf_ids;
+    a.out_row_stride = lim; a.out_limit = lim;
     if (int rc = launch_sort(a, 1, rows, k + cap, st)) return rc;
+    if (unordered) {
+        const size_t lds = (size_t)lim * (8 + 4);
+        if (lds > 60 * 1024) return FZ_ERR_UNSUPPORTED;
+        topk_tiefix_kernel<<<rows, 256, lds, st>>>(tmp_scores, tmp_ids, buf_len, k, lim, new_scores, new_ids, overflow);
+        FZ_LAUNCH_CHECK();
+    }
     topk_fold_done_kernel<<<(rows + 255) / 256, 256, 0, st>>>(new_scores, rows, k, tau_out, cand_len);
     FZ_LAUNCH_CHECK();
     return FZ_OK;

@@ -66,6 +66,7 @@ class ShardedDenseIndex:
 
     CHUNK = 8 * 28672   # documents per GEMM launch: 8 sort-kernel rows per query
     CAP = 7168          # candidate slots per row and chunk on the streaming path (k + CAP = one 8192-key sort row at k = 1024)
+    FUSED = True        # after the head, score and filter in one kernel (fz_dot_scores_filter_f32); False: GEMM, then the filter pass
     HEAD = 28672        # at most this many leading documents get the exact top-k (one sort-kernel row); 8 k of them (>= 8192) are enough
 
     def __init__(self, Dn_local: torch.Tensor, id_base: int, group=None):
@@ -86,6 +87,19 @@ class ShardedDenseIndex:
         head = min(self.HEAD, max(8192, -(-8 * k // 4096) * 4096))   # 8192 at k = 1000: a 0.09 ms sort instead of 0.35, one fold more
         streaming = streaming and k + self.CAP <= 35840 and k <= head // 8 and n > head
         best_s = best_i = stream = None
+        if streaming and self.FUSED and Qn.shape[1] % 4 == 0:
+            # the head's scores are materialised and ranked exactly; everything after it goes through the GEMM whose epilogue is the
+            # threshold filter: no score plane, no filter pass -- per shard 4.5 GB less written and 4.5 GB less read
+            S = ops.dot_scores(Qn, self.Dn[:head]); mark("shard_gemm")
+            bs, bi = ops.topk_rows(S, k, id_base=self.id_base)
+            stream = ops.TopkStream(bs, bi, seen=head, cap=self.CAP); mark("shard_topk_stream")
+            for c0 in range(head, n, self.CHUNK):
+                c1 = min(n, c0 + self.CHUNK)
+                stream.feed_gemm(Qn, self.Dn[c0:c1], self.id_base + c0, mark=mark)
+            best_s, best_i, overflow = stream.result(); mark("shard_topk_stream")
+            if int(overflow.item()) != 0:
+                return self.local_topk(Qn, k, streaming=False, mark=mark)
+            return best_s, best_i
         for c0 in range(0, max(n, 1), self.CHUNK):
             c1 = min(n, c0 + self.CHUNK)
             S = ops.dot_scores(Qn, self.Dn[c0:c1]); mark("shard_gemm")

@@ -624,7 +624,11 @@ class TopkStream:
         dev = run_scores.device
         self.rows, self.k, self.cap = rows, k, int(cap)
         self.best_s, self.best_i = run_scores.contiguous(), run_ids.contiguous()
-        self.tau = self.best_s[:, k - 1].contiguous()
+        # thresholds, padded to whole 128-query GEMM blocks with +inf (the fused GEMM reads its tile's 128 rows unconditionally)
+        self._tau_pad = torch.full((round_up(max(rows, 1), 128),), float("inf"), dtype=torch.float32, device=dev)
+        self.tau = self._tau_pad[:rows]
+        self.tau.copy_(self.best_s[:, k - 1])
+        self.unordered = False           # candidates appended by the fused GEMM arrive in no particular order
         self.cand_s = torch.empty((rows, cap), dtype=torch.float32, device=dev)
         self.cand_i = torch.empty((rows, cap), dtype=torch.int64, device=dev)
         self.cand_len = torch.zeros(rows, dtype=torch.int32, device=dev)
@@ -655,13 +659,36 @@ class TopkStream:
             if self.pending >= self._window():
                 self.fold()
 
+    def feed_gemm(self, Qn: torch.Tensor, Dn: torch.Tensor, id_base: int, mark=None):
+        """Score documents id_base .. id_base + len(Dn) - 1 against the queries and keep what beats the thresholds, in ONE kernel:
+        the GEMM's epilogue is the filter, the score plane is never written (fz_dot_scores_filter_f32).  Qn [rows, d], Dn [n, d]
+        L2-normalised float32, d % 4 == 0.  The documents are cut at the fold windows, one GEMM launch per piece."""
+        _dev(Qn, torch.float32, "TopkStream.feed_gemm(Qn)"); _dev(Dn, torch.float32, "TopkStream.feed_gemm(Dn)")
+        _need(Qn.shape[0] == self.rows and Qn.shape[1] == Dn.shape[1] and Qn.shape[1] % 4 == 0, "TopkStream.feed_gemm: [rows, d] x [n, d], d % 4 == 0")
+        Qn, Dn = Qn.contiguous(), Dn.contiguous()
+        lib = _lib.lib()
+        n, lo, d = Dn.shape[0], 0, Qn.shape[1]
+        self.unordered = True
+        while lo < n:
+            hi = min(n, lo + self._window() - self.pending)
+            piece = Dn[lo:hi]
+            check(lib.fz_dot_scores_filter_f32(_ptr(Qn), Qn.stride(0), _ptr(piece), Dn.stride(0), self.rows, hi - lo, d, int(id_base) + lo,
+                                               _ptr(self._tau_pad), _ptr(self.cand_s), _ptr(self.cand_i), _ptr(self.cand_len), self.cap,
+                                               _ptr(self.overflow), _stream(Qn)), "fz_dot_scores_filter_f32")
+            if mark: mark("shard_gemm_filter")
+            self.pending += hi - lo
+            lo = hi
+            if self.pending >= self._window():
+                self.fold()
+                if mark: mark("shard_topk_stream")
+
     def fold(self):
         if self.pending == 0:
             return
         ns, ni = torch.empty_like(self.best_s), torch.empty_like(self.best_i)
         check(_lib.lib().fz_topk_fold_f32(_ptr(self.best_s), _ptr(self.best_i), self.rows, self.k, _ptr(self.cand_s), _ptr(self.cand_i),
-                                          _ptr(self.cand_len), self.cap, _ptr(ns), _ptr(ni), _ptr(self.tau), _ptr(self._ws), self._wsb,
-                                          _stream(self.best_s)), "fz_topk_fold_f32")
+                                          _ptr(self.cand_len), self.cap, 1 if self.unordered else 0, _ptr(ns), _ptr(ni), _ptr(self.tau),
+                                          _ptr(self.overflow), _ptr(self._ws), self._wsb, _stream(self.best_s)), "fz_topk_fold_f32")
         self.best_s, self.best_i = ns, ni
         self.seen += self.pending
         self.pending = 0

@@ -66,6 +66,14 @@ int fz_normalize_rows_f32(const float* X, int rows, int d, int ldx, float* Y, in
  * util.dot_score, sentence_transformers.py:229).  Qn [Q][ldq], Dn [N][ldd], d = contraction. */
 int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int ldd, int Q, int N, int d, float* scores, int lds,
                       void* stream);
+/* The same GEMM with the streaming top-k's threshold filter as its epilogue: NO score plane is written; a score that beats its
+ * query's threshold tau[q] (or is NaN) is appended, with its document id id_base + corpus row, to the query's candidate list
+ * (cand_scores / cand_ids [Q][cap], cand_len [Q] int32, as for fz_topk_filter_append_f32) -- in arrival order, i.e. for
+ * fz_topk_fold_f32(unordered = 1).  tau_padded: [round_up(Q, 128)] floats, 16-byte aligned, +inf beyond Q.  Per 1.1 M-document shard
+ * the scores would otherwise cross HBM twice (4.5 GB written by the GEMM, read by the filter). */
+int fz_dot_scores_filter_f32(const float* Qn, int ldq, const float* Dn, int ldd, int Q, int N, int d, int64_t id_base,
+                             const float* tau_padded, float* cand_scores, int64_t* cand_ids, int32_t* cand_len, int cap,
+                             int32_t* overflow, void* stream);
 
 /* ---- K2: ColBERT late interaction, hybrid.py:108-137 (exact MaxSim) ------ */
 /* scores[q][j] = sum_{i<Lq} max_{t in doc j} <Qtok[q][i], Dtok[t]>.
@@ -195,13 +203,16 @@ int fz_topk_update_f32(const float* scores, int rows, int n, int ld, int64_t id_
  * list -- ascending id inside the chunk, chunks fed in ascending id order; fz_topk_fold_f32 merges [running k | candidates] into
  * the new running list (ties: running entries first, then ascending id), writes the new threshold tau_out[row] = k-th best
  * (nullable) and empties the candidate lists.  cand_scores / cand_ids [rows][cap], cand_len [rows] int32 (zero before the first
- * call); *overflow becomes 1 if a row's list would exceed cap (the caller then redoes the search exactly).  k + cap <= 35840. */
+ * call); *overflow becomes 1 if a row's list would exceed cap (the caller then redoes the search exactly).  k + cap <= 35840.
+ * unordered != 0: the candidates are in no particular order (fz_dot_scores_filter_f32 appends them as its waves finish); the fold
+ * then also puts every run of equal scores that reaches into the first k into ascending id order -- the same lists as from ordered
+ * candidates -- and sets *overflow if such a run is longer than it looks at (64 entries past k, 512 in all). */
 int fz_topk_filter_append_f32(const float* scores, int rows, int n, int ld, int64_t id_base, const float* tau, float* cand_scores,
                               int64_t* cand_ids, int32_t* cand_len, int cap, int32_t* overflow, void* stream);
 size_t fz_topk_fold_workspace_bytes(int rows, int k, int cap);
 int fz_topk_fold_f32(const float* run_scores, const int64_t* run_ids, int rows, int k, const float* cand_scores, const int64_t* cand_ids,
-                     int32_t* cand_len, int cap, float* new_scores, int64_t* new_ids, float* tau_out, void* workspace,
-                     size_t workspace_bytes, void* stream);
+                     int32_t* cand_len, int cap, int unordered, float* new_scores, int64_t* new_ids, float* tau_out, int32_t* overflow,
+                     void* workspace, size_t workspace_bytes, void* stream);
 /* merge G per-shard lists [G][rows][k] (as all-gathered over RCCL) into the global top-k [rows][k] */
 int fz_topk_merge(const float* in_scores, const int64_t* in_ids, int G, int rows, int k, float* out_scores, int64_t* out_ids,
                   void* stream);

@@ -264,6 +264,26 @@ def case_topk_stream(rng):
     return f"topk stream rows={rows} k={k} chunks={chunks}"
 
 
+def case_fused_search(rng):
+    """ShardedDenseIndex.local_topk, fused (filter in the GEMM epilogue) and not, against the oracle's top-k of the device's scores;
+    duplicated documents plant exact ties."""
+    from fusion_amd.distributed import ShardedDenseIndex
+    Q, N, d, k = int(rng.integers(1, 260)), int(rng.integers(9000, 90000)), int(rng.integers(1, 20) * 4), int(rng.integers(1, 1001))
+    g = torch.Generator(device="cuda").manual_seed(int(rng.integers(0, 1 << 30)))
+    Dn = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
+    Qn = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
+    for _ in range(int(rng.integers(0, 4))):
+        a, b, n = int(rng.integers(0, N)), int(rng.integers(0, N)), int(rng.integers(1, 40))
+        Dn[a:a + n] = Dn[b]
+    es, ei = oracle.topk_rows(ops.dot_scores(Qn, Dn).cpu().numpy(), k, id_base=77)
+    for fused in (True, False):
+        idx = ShardedDenseIndex(Dn, id_base=77)
+        idx.FUSED, idx.CHUNK = fused, int(rng.integers(8192, 60000))
+        s_, i_ = idx.local_topk(Qn, k)
+        np.testing.assert_array_equal(s_.cpu().numpy(), es); np.testing.assert_array_equal(i_.cpu().numpy(), ei)
+    return f"fused search Q={Q} N={N} d={d} k={k}"
+
+
 def case_segments(rng):
     lens = rng.integers(0, 70, int(rng.integers(1, 30)))
     d = int(rng.choice([rng.integers(1, 200) * 4, rng.integers(1, 3000)]))
@@ -373,7 +393,7 @@ def case_empty(rng):
 
 
 CASES = [case_encoder, case_lists, case_empty, case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
-         case_topk_stream, case_segments]
+         case_topk_stream, case_segments, case_fused_search]
 
 
 def main():

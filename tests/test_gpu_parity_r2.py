@@ -680,3 +680,49 @@ def test_row_stats_accepts_a_rank_tensor_with_its_own_row_stride(ops, oracle):
     for q in range(Q):
         v = p[q][r[q] >= 0].astype(np.float64)
         assert abs(float(mean[q]) - v.mean()) <= 1e-6 and abs(float(std[q]) - v.std(ddof=1)) <= 1e-6
+
+
+# ---- sharded search: the threshold filter as the GEMM's epilogue ---------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("Q,N,d,k", [(5, 120_000, 32, 1000), (130, 60_000, 64, 100), (3, 40_000, 36, 7)])
+def test_fused_gemm_filter_search_equals_the_two_pass_search_and_the_oracle(ops, oracle, Q, N, d, k):
+    """ShardedDenseIndex.local_topk with FUSED (scores never materialised after the head; candidates in arrival order; ties put in
+    id order by the fold) == the same search with the separate filter pass == the oracle's top-k of the full score matrix -- incl.
+    duplicated documents (exact score ties inside the head, across the head boundary, across folds, and more than 64 of them
+    where the k-th place is NOT at stake).  d = 36 takes the ragged-d GEMM instantiation, Q = 130 a partial query block."""
+    from fusion_amd.distributed import ShardedDenseIndex
+    g = torch.Generator(device="cuda").manual_seed(Q + N)
+    Dn = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
+    Qn = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
+    Dn[1000:1010] = Dn[7]
+    Dn[30_000:30_040] = Dn[7]
+    Dn[N - 70:N] = Dn[123]                       # 71 copies of one document far down most lists
+    S = ops.dot_scores(Qn, Dn).cpu().numpy()
+    es, ei = oracle.topk_rows(S, k, id_base=10**10)
+    for fused in (True, False):
+        idx = ShardedDenseIndex(Dn, id_base=10**10)
+        idx.FUSED = fused
+        idx.CHUNK = 50_000
+        s, i = idx.local_topk(Qn, k)
+        np.testing.assert_array_equal(s.cpu().numpy(), es)
+        np.testing.assert_array_equal(i.cpu().numpy(), ei)
+
+
+@pytest.mark.gpu
+def test_fused_gemm_filter_flags_a_tie_run_it_cannot_order(ops, oracle):
+    """More equal scores at the k-th place than the fold looks at (64 past k): the overflow flag, i.e. the exact path, and with
+    it still the oracle's answer."""
+    from fusion_amd.distributed import ShardedDenseIndex
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, d, k = 30_000, 32, 50
+    Dn = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
+    Qn = Dn[20_000:20_002].clone()               # the queries ARE documents: their copies score exactly 1.0
+    Dn[9_000:9_200] = Dn[20_000]                 # 200 copies behind the head: all tie at the top of query 0's list
+    idx = ShardedDenseIndex(Dn, id_base=0)
+    st = ops.TopkStream(*ops.topk_rows(ops.dot_scores(Qn, Dn[:8192]), k), seen=8192, cap=7168)
+    st.feed_gemm(Qn, Dn[8192:], 8192)
+    assert int(st.result()[2].item()) == 1
+    s, i = idx.local_topk(Qn, k)
+    es, ei = oracle.topk_rows(ops.dot_scores(Qn, Dn).cpu().numpy(), k)
+    np.testing.assert_array_equal(s.cpu().numpy(), es)
+    np.testing.assert_array_equal(i.cpu().numpy(), ei)
