@@ -258,62 +258,70 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
             const int h = lane >> 5;
             const int qw = crow + wr * 64 + 4 * h;                      // + mi*32 + (r&3) + 8*(r>>2)
             const int dw = ccol + wc * (BN / 2) + (lane & 31);          // + ni*32
-            auto beats = [&](int mi, int ni, int r, const float4& t4) __attribute__((always_inline)) -> bool {
-                const float tq = (r & 3) == 0 ? t4.x : (r & 3) == 1 ? t4.y : (r & 3) == 2 ? t4.z : t4.w;
-                // (rows past Q carry tau = +inf, but a NaN score beats even that: the row check stays)
-                return !(acc[mi][ni][r] <= tq) && dw + ni * 32 < g.N && qw + mi * 32 + (r & 3) + 8 * (r >> 2) < g.Q;
-            };
-            uint32_t counts = 0u;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(g.tau + qw + mi * 32 + 8 * rg);   // this lane half's thresholds, 4 rows
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const int r = rg * 4 + rr;
-                            const unsigned long long bal = __ballot(beats(mi, ni, r, t4));
-                            const uint32_t c = (uint32_t)__popc((uint32_t)bal) | ((uint32_t)__popc((uint32_t)(bal >> 32)) << 16);
-                            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(counts) : "s"(c), "i"((mi * NI + ni) * 16 + r));   // c is wave-uniform
-                        }
-                }
-            // lane s owns step s = (mi*NI + ni)*16 + r: queries qa (lanes 0-31 of the step) and qa + 4 (lanes 32-63)
-            int base_lo = 0, base_hi = 0;
-            if (lane < STEPS) {
-                const int r = lane & 15, mi = lane / (16 * NI);
-                const int qa = crow + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2);
-                const int c_lo = counts & 0xffff, c_hi = counts >> 16;
-                if (c_lo) base_lo = atomicAdd(&g.cand_len[qa], c_lo);
-                if (c_hi) base_hi = atomicAdd(&g.cand_len[qa + 4], c_hi);
-            }
             bool over = false;
+            // `edge` (compile time): the tile reaches past the last query or document and every score is bounds-checked; inside the
+            // matrix -- the usual tile -- a score costs ONE compare per pass (the two passes are ~3 % of the kernel)
+            auto passes = [&](auto edge) __attribute__((always_inline)) {
+                auto beats = [&](int mi, int ni, int r, const float4& t4) __attribute__((always_inline)) -> bool {
+                    const float tq = (r & 3) == 0 ? t4.x : (r & 3) == 1 ? t4.y : (r & 3) == 2 ? t4.z : t4.w;
+                    const bool b = !(acc[mi][ni][r] <= tq);
+                    if constexpr (decltype(edge)::value) return b && dw + ni * 32 < g.N && qw + mi * 32 + (r & 3) + 8 * (r >> 2) < g.Q;
+                    else return b;
+                };
+                uint32_t counts = 0u;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(g.tau + qw + mi * 32 + 8 * rg);   // (again: 32 registers are not to spare)
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(g.tau + qw + mi * 32 + 8 * rg);   // this lane half's thresholds, 4 rows
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
+                        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const int r = rg * 4 + rr, step = (mi * NI + ni) * 16 + r;
-                            const bool keep = beats(mi, ni, r, t4);
-                            const unsigned long long bal = __ballot(keep);
-                            if (bal == 0ull) continue;                     // wave-uniform
-                            const int b_lo = __builtin_amdgcn_readlane(base_lo, step), b_hi = __builtin_amdgcn_readlane(base_hi, step);
-                            const uint32_t mine = h ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-                            const int pos = (h ? b_hi : b_lo) + __popc(mine & ((1u << (lane & 31)) - 1u));
-                            if (keep) {
-                                const int q = qw + mi * 32 + (r & 3) + 8 * (r >> 2);
-                                if (pos < g.cap) {
-                                    g.cand_s[(size_t)q * g.cap + pos] = acc[mi][ni][r];
-                                    g.cand_i[(size_t)q * g.cap + pos] = g.id_base + dw + ni * 32;
-                                } else over = true;
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const int r = rg * 4 + rr;
+                                const unsigned long long bal = __ballot(beats(mi, ni, r, t4));
+                                const uint32_t c = (uint32_t)__popc((uint32_t)bal) | ((uint32_t)__popc((uint32_t)(bal >> 32)) << 16);
+                                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(counts) : "s"(c), "i"((mi * NI + ni) * 16 + r));   // c is wave-uniform
                             }
-                        }
+                    }
+                // lane s owns step s = (mi*NI + ni)*16 + r: queries qa (lanes 0-31 of the step) and qa + 4 (lanes 32-63)
+                int base_lo = 0, base_hi = 0;
+                if (lane < STEPS) {
+                    const int r = lane & 15, mi = lane / (16 * NI);
+                    const int qa = crow + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2);
+                    const int c_lo = counts & 0xffff, c_hi = counts >> 16;
+                    if (c_lo) base_lo = atomicAdd(&g.cand_len[qa], c_lo);
+                    if (c_hi) base_hi = atomicAdd(&g.cand_len[qa + 4], c_hi);
                 }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(g.tau + qw + mi * 32 + 8 * rg);   // (again: 32 registers are not to spare)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const int r = rg * 4 + rr, step = (mi * NI + ni) * 16 + r;
+                                const bool keep = beats(mi, ni, r, t4);
+                                const unsigned long long bal = __ballot(keep);
+                                if (bal == 0ull) continue;                     // wave-uniform
+                                const int b_lo = __builtin_amdgcn_readlane(base_lo, step), b_hi = __builtin_amdgcn_readlane(base_hi, step);
+                                const uint32_t mine = h ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                                const int pos = (h ? b_hi : b_lo) + __popc(mine & ((1u << (lane & 31)) - 1u));
+                                if (keep) {
+                                    const int q = qw + mi * 32 + (r & 3) + 8 * (r >> 2);
+                                    if (pos < g.cap) {
+                                        g.cand_s[(size_t)q * g.cap + pos] = acc[mi][ni][r];
+                                        g.cand_i[(size_t)q * g.cap + pos] = g.id_base + dw + ni * 32;
+                                    } else over = true;
+                                }
+                            }
+                    }
+            };
+            // (rows past Q carry tau = +inf, but a NaN score beats even that: the last query block keeps its row check)
+            if (ccol + BN <= g.N && crow + BM <= g.Q) passes(std::false_type{});   // workgroup-uniform
+            else passes(std::true_type{});
             if (over) atomicExch(g.overflow, 1);
         } else {
         const bool whole = crow + BM <= g.Q && ccol + BN <= g.N;
