@@ -114,7 +114,14 @@ def bench_topk(Q=1024, n=8 * 28672, k=1000):
     g = torch.Generator(device="cuda").manual_seed(3)
     S = ops.alloc_plane(Q, n, torch.float32, "cuda"); S.copy_(torch.rand((Q, n), generator=g, device="cuda"))
     ms = timeit(lambda: ops.topk_rows(S, k), n=5)
-    emit("topk_rows (chunk-sort-truncate)", ms, Q * n * 4, HBM, "GB/s", Q=Q, n=n, k=k)
+    emit("topk_rows (chunk-sort-truncate: the exact fall-back path)", ms, Q * n * 4, HBM, "GB/s", Q=Q, n=n, k=k)
+
+    def stream():   # what the sharded search does with materialised scores: exact head, threshold filter, folds
+        st = ops.TopkStream(*ops.topk_rows(S[:, :8192], k), seen=8192)
+        st.feed(S[:, 8192:], 8192)
+        return st.result()
+    ms = timeit(stream, n=5)
+    emit("TopkStream: topk_rows head + topk_filter + folds (same rows)", ms, Q * n * 4, HBM, "GB/s", Q=Q, n=n, k=k)
 
 
 def bench_mmarco(Q=1024, N=8841823 // 8, d=768, k=1000):
