@@ -614,7 +614,7 @@ class TopkStream:
     threshold (its k-th best when the list was last folded) are kept as candidates (fz_topk_filter_append_f32), and candidates
     are folded into the list (fz_topk_fold_f32: one row sort) only when their EXPECTED number -- k * (documents since the fold) /
     (documents before it), for scores in no particular order -- reaches half the candidate capacity.  The windows between folds
-    therefore grow geometrically: 3 folds for a 1.1 M-document shard at k = 1000, cap = 7168, however the scoring is chunked.
+    therefore grow geometrically: 4 folds for a 1.1 M-document shard at k = 1000, cap = 7168 after an 8192-document head, however the scoring is chunked.
     `overflow` (device int32) becomes 1 if a row ever had more than `cap` candidates: the caller redoes the search exactly."""
 
     def __init__(self, run_scores: torch.Tensor, run_ids: torch.Tensor, seen: int, cap: int = 7168):

@@ -198,7 +198,7 @@ size_t fz_topk_update_workspace_bytes(int rows, int k, int cap);
 int fz_topk_update_f32(const float* scores, int rows, int n, int ld, int64_t id_base, const float* run_scores,
                        const int64_t* run_ids, int k, int cap, float* new_scores, int64_t* new_ids, int32_t* overflow,
                        void* workspace, size_t workspace_bytes, void* stream);
-/* The same step in two halves, so that several chunks share ONE sort (the sharded search folds 3 times per 1.1 M-document shard
+/* The same step in two halves, so that several chunks share ONE sort (the sharded search folds 4 times per 1.1 M-document shard
  * instead of once per chunk): fz_topk_filter_append_f32 appends the chunk's scores above tau[row] (or NaN) to the row's candidate
  * list -- ascending id inside the chunk, chunks fed in ascending id order; fz_topk_fold_f32 merges [running k | candidates] into
  * the new running list (ties: running entries first, then ascending id), writes the new threshold tau_out[row] = k-th best
