@@ -19,7 +19,7 @@
 namespace fz {
 
 constexpr int TUNE_G = 8;        // gold documents per query handled per launch
-constexpr int TUNE_WCHUNK = 1792; // weight vectors per pass over the LDS counters (56 KB: two workgroups per CU)
+constexpr int TUNE_WCHUNK = 512;  // weight vectors per pass over the LDS counters and gold keys (16 + 32 KB: three workgroups per CU)
 constexpr int TUNE_COLS_F32 = 16, TUNE_COLS_F64 = 8;   // columns per thread (the float64 sweep keeps them as doubles: half as many)
 
 struct TuneArgs {
@@ -40,7 +40,8 @@ template <int S, bool WIDE>
 __global__ __launch_bounds__(256, 2) void gold_ranks_kernel(TuneArgs a) {
     typedef typename std::conditional<WIDE, double, float>::type F;
     constexpr int TUNE_COLS = WIDE ? TUNE_COLS_F64 : TUNE_COLS_F32;
-    extern __shared__ int lds_acc[];   // [TUNE_WCHUNK][TUNE_G] counts of the workgroup
+    extern __shared__ int lds_acc[];   // [wch][TUNE_G] counts of the workgroup, then [wch][TUNE_G] sort keys of the golds' fused scores
+    uint64_t* lds_kg = reinterpret_cast<uint64_t*>(lds_acc + (size_t)(a.W < TUNE_WCHUNK ? a.W : TUNE_WCHUNK) * TUNE_G);
     int w0 = 0, w1 = 0;
     __shared__ int lds_gold[TUNE_G + 1];
     __shared__ float lds_tg[S][TUNE_G];
@@ -140,16 +141,10 @@ __global__ __launch_bounds__(256, 2) void gold_ranks_kernel(TuneArgs a) {
             // "j precedes g": narrow -- ONE 64-bit unsigned compare of (key(fused), pos), lexicographic; wide -- the 64-bit key
             // compare, and only if some (column, gold) pair of the wave holds EQUAL keys (one scalar test per weight vector,
             // rare) a second pass for the position tie-break.  The count is exactly the rank the materialise-and-sort path gives.
-            uint64_t kg[NG];
+            uint64_t kg[NG];                                 // the golds' keys of this weight vector: computed once per workgroup (below), scalars here
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                float x[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) x[s] = lds_tg[s][g];
-                const F f = fuse(x, wv);
-                uint64_t k;
-                if constexpr (WIDE) k = key_of(f, sp);
-                else k = ((uint64_t)key_of(f, sp) << 32) | (uint32_t)lds_pg[g];
+                const uint64_t k = lds_kg[(size_t)(w - w0) * TUNE_G + g];
                 kg[g] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(k >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
             }
             int cnt[NG];
@@ -214,6 +209,26 @@ __global__ __launch_bounds__(256, 2) void gold_ranks_kernel(TuneArgs a) {
     for (w0 = 0; w0 < a.W; w0 += TUNE_WCHUNK) {
         w1 = min(a.W, w0 + TUNE_WCHUNK);
         for (int i = threadIdx.x; i < (w1 - w0) * TUNE_G; i += 256) lds_acc[i] = 0;
+        // the golds' fused scores and sort keys for every weight vector of the chunk, ONCE per workgroup (a thread per weight vector)
+        // instead of once per wave and weight vector inside the sweep; the full key form: it equals the fast one wherever that is valid
+        for (int w = w0 + threadIdx.x; w < w1; w += 256) {
+            F wv[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if constexpr (WIDE) wv[s] = a.weights64[(size_t)w * S + s];
+                else wv[s] = a.weights[(size_t)w * S + s];
+            }
+            for (int g = 0; g < ng; ++g) {
+                float x[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) x[s] = lds_tg[s][g];
+                const F f = fuse(x, wv);
+                uint64_t k;
+                if constexpr (WIDE) k = desc_key_f64(f);
+                else k = ((uint64_t)desc_key_f32(f) << 32) | (uint32_t)lds_pg[g];
+                lds_kg[(size_t)(w - w0) * TUNE_G + g] = k;
+            }
+        }
         __syncthreads();
         if (special) dispatch(std::true_type{});
         else dispatch(std::false_type{});
@@ -353,7 +368,7 @@ extern "C" int fz_gold_ranks_f32(const float* const* T_h, const int32_t* pos, co
     a.pos = pos; a.weights = weights; a.gold = gold; a.out = out_ranks; a.S = S; a.W = W; a.Q = Q; a.N = N; a.ld = ld;
     dim3 grid((unsigned)((N + 256 * TUNE_COLS_F32 - 1) / (256 * TUNE_COLS_F32)), (unsigned)Q);
     hipStream_t st = as_stream(stream);
-    const size_t lds_bytes = (size_t)(W < TUNE_WCHUNK ? W : TUNE_WCHUNK) * TUNE_G * sizeof(int);
+    const size_t lds_bytes = (size_t)(W < TUNE_WCHUNK ? W : TUNE_WCHUNK) * TUNE_G * (sizeof(int) + sizeof(uint64_t));
     switch (S) {
         case 1: gold_ranks_kernel<1, false><<<grid, 256, lds_bytes, st>>>(a); break;
         case 2: gold_ranks_kernel<2, false><<<grid, 256, lds_bytes, st>>>(a); break;
@@ -375,7 +390,7 @@ extern "C" int fz_gold_ranks_f64w(const float* const* T_h, const int32_t* pos, c
     a.pos = pos; a.weights64 = weights; a.gold = gold; a.out = out_ranks; a.S = S; a.W = W; a.Q = Q; a.N = N; a.ld = ld;
     dim3 grid((unsigned)((N + 256 * TUNE_COLS_F64 - 1) / (256 * TUNE_COLS_F64)), (unsigned)Q);
     hipStream_t st = as_stream(stream);
-    const size_t lds_bytes = (size_t)(W < TUNE_WCHUNK ? W : TUNE_WCHUNK) * TUNE_G * sizeof(int);
+    const size_t lds_bytes = (size_t)(W < TUNE_WCHUNK ? W : TUNE_WCHUNK) * TUNE_G * (sizeof(int) + sizeof(uint64_t));
     switch (S) {
         case 1: gold_ranks_kernel<1, true><<<grid, 256, lds_bytes, st>>>(a); break;
         case 2: gold_ranks_kernel<2, true><<<grid, 256, lds_bytes, st>>>(a); break;
