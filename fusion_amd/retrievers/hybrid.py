@@ -304,7 +304,7 @@ class Aggregator:
             rk = ops.gold_ranks(T, pos, weights, gold_dev)
             means = ops.tune_metrics(rk, gold_dev, pos, torch.from_numpy(n_gold.astype(np.int32)).to(dev), torch.from_numpy(idcg).to(dev),
                                      torch.from_numpy(table).to(dev), dict(recall=RECALL_KS, map=MAP_KS, mrr=MRR_KS, ndcg=NDCG_KS)).cpu().numpy()
-            return [{n: float(means[w, i]) for i, n in enumerate(mnames)} for w in range(W)]
+            return [dict(zip(mnames, row)) for row in means.tolist()]   # Python floats, as run_evaluation returns
         ranks = np.full((W, Q, max(Gmax, 1)), np.iinfo(np.int64).max, dtype=np.int64)
         pos_host = None
         for g0 in range(0, Gmax, G):
