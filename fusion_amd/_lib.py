@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfusion_hip.so")
+# FUSION_AMD_LIB: another build of the same library (the host-sanitized one of `make -C fusion_amd/csrc hostasan`); same ABI check applies
+LIB_PATH = os.environ.get("FUSION_AMD_LIB") or os.path.join(_HERE, "libfusion_hip.so")
 ABI_VERSION = 8
 
 FZ_OK, FZ_ERR_ARG, FZ_ERR_UNSUPPORTED, FZ_ERR_HIP, FZ_ERR_WORKSPACE = 0, -1, -2, -3, -4

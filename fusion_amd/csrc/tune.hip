@@ -40,7 +40,7 @@ template <int S, bool WIDE>
 __global__ __launch_bounds__(256, 2) void gold_ranks_kernel(TuneArgs a) {
     typedef typename std::conditional<WIDE, double, float>::type F;
     constexpr int TUNE_COLS = WIDE ? TUNE_COLS_F64 : TUNE_COLS_F32;
-    extern __shared__ int lds_acc[];   // [wch][TUNE_G] counts of the workgroup, then [wch][TUNE_G] sort keys of the golds' fused scores
+    extern __shared__ __attribute__((aligned(16))) int lds_acc[];   // (16-byte aligned: the uint64 keys behind the counters are read as 8-byte words) [wch][TUNE_G] counts of the workgroup, then [wch][TUNE_G] sort keys of the golds' fused scores
     uint64_t* lds_kg = reinterpret_cast<uint64_t*>(lds_acc + (size_t)(a.W < TUNE_WCHUNK ? a.W : TUNE_WCHUNK) * TUNE_G);
     int w0 = 0, w1 = 0;
     __shared__ int lds_gold[TUNE_G + 1];

@@ -71,6 +71,7 @@ class ShardedDenseIndex:
 
     def __init__(self, Dn_local: torch.Tensor, id_base: int, group=None):
         self.Dn, self.id_base, self.group = Dn_local, int(id_base), group
+        self.last_overflow = 0   # 1 after a local_topk whose streaming pass overflowed a candidate buffer (it was then redone exactly)
 
     def local_topk(self, Qn: torch.Tensor, k: int, streaming: bool = True, mark=None):
         """Chunked score -> top-k over this shard.  The first HEAD documents get an exact top-k (one sort-kernel row per query);
@@ -98,7 +99,10 @@ class ShardedDenseIndex:
                 stream.feed_gemm(Qn, self.Dn[c0:c1], self.id_base + c0, mark=mark)
             best_s, best_i, overflow = stream.result(); mark("shard_topk_stream")
             if int(overflow.item()) != 0:
-                return self.local_topk(Qn, k, streaming=False, mark=mark)
+                out = self.local_topk(Qn, k, streaming=False, mark=mark)
+                self.last_overflow = 1
+                return out
+            self.last_overflow = 0
             return best_s, best_i
         for c0 in range(0, max(n, 1), self.CHUNK):
             c1 = min(n, c0 + self.CHUNK)
@@ -115,10 +119,13 @@ class ShardedDenseIndex:
             else:   # exact path: per-chunk top-k, then merge two id-ascending lists (chunks arrive in id order)
                 s, i = ops.topk_rows(S, k, id_base=self.id_base + c0)
                 best_s, best_i = ops.topk_merge(torch.stack([best_s, s]), torch.stack([best_i, i])); mark("shard_topk_exact")
+        self.last_overflow = 0
         if stream is not None:
             best_s, best_i, overflow = stream.result(); mark("shard_topk_stream")
             if int(overflow.item()) != 0:
-                return self.local_topk(Qn, k, streaming=False, mark=mark)
+                out = self.local_topk(Qn, k, streaming=False, mark=mark)
+                self.last_overflow = 1
+                return out
         return best_s, best_i
 
     def search(self, Qn: torch.Tensor, k: int = 1000, mark=None):

@@ -37,9 +37,11 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libfusion_oracle.so")
-        if not os.path.exists(so):
-            build()
+        so = os.environ.get("FUSION_ORACLE_SO")   # e.g. build_asan/libfusion_oracle_asan.so (make -C oracle asan; tests/test_sanitizers_cpu.py)
+        if not so:
+            so = os.path.join(_HERE, "libfusion_oracle.so")
+            if not os.path.exists(so):
+                build()
         _LIB = C.CDLL(so)
     return _LIB
 

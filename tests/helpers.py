@@ -39,3 +39,16 @@ def load_lists(z):
     lists = {s: [[{"corpus_id": int(ids[si, q, r]), "score": float(sc[si, q, r])} for r in range(ln[si, q])] for q in range(Q)]
              for si, s in enumerate(systems)}
     return systems, lists, Q
+
+
+def integration_snippet(root):
+    """The reference-side ctypes binding printed in INTEGRATION.md section 2 (the fenced python block that defines rrf()), with the
+    library name replaced by this tree's libfusion_hip.so."""
+    import os
+    import re
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, re.S)
+    code = [b for b in blocks if "def rrf(" in b]
+    assert len(code) == 1, "INTEGRATION.md must hold exactly one binding snippet that defines rrf()"
+    from fusion_amd import _lib
+    return code[0].replace('"libfusion_hip.so"', repr(_lib.LIB_PATH))

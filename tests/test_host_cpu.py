@@ -39,6 +39,85 @@ def test_abi_argument_validation_without_gpu():
     assert L.fz_topk_workspace_bytes(4, 100000, 1000) > 0 and L.fz_topk_workspace_bytes(4, 1000, 10) <= 256
 
 
+def test_workspace_planning_is_consistent():
+    """Host-side planning code of the C ABI over a grid of shapes (also run under ASan / UBSan, tests/test_sanitizers_cpu.py): workspace
+    sizes are finite, monotone in the batch, and every entry point rejects null / negative / inconsistent arguments before any HIP call."""
+    from fusion_amd import _lib
+    L = _lib.lib()
+    ERR = _lib.FZ_ERR_ARG
+    for bits in (32, 64):
+        prev = 0
+        for rows in (1, 7, 195, 1024, 6980):
+            for n in (1, 64, 27942, 35840, 35841, 120000, 1105228):
+                b = L.fz_sort_workspace_bytes(bits, rows, n)
+                assert 0 <= b < (1 << 40)
+                if bits == 32 and n <= L.fz_sort_max_n():
+                    assert b == 0
+            b = L.fz_sort_workspace_bytes(bits, rows, 120000)
+            assert b >= prev
+            prev = b
+    kmax = L.fz_topk_max_k()
+    for rows in (1, 195, 1024):
+        for n in (10, 8192, 229376, 1105228):
+            for k in (1, 10, 1000, kmax):
+                assert 0 <= L.fz_topk_workspace_bytes(rows, n, k) < (1 << 40)
+        for k, cap in ((10, 64), (1000, 7168), (1024, 7168)):
+            assert 0 <= L.fz_topk_update_workspace_bytes(rows, k, cap) < (1 << 40)
+            assert 0 <= L.fz_topk_fold_workspace_bytes(rows, k, cap) < (1 << 40)
+        for world in (1, 2, 8):
+            assert L.fz_topk_allgather_workspace_bytes(world, rows, 1000) >= world * rows * 1000 * 12
+        assert 0 <= L.fz_insertion_order_workspace_bytes(rows, 27942) < (1 << 40)
+    assert L.fz_sort_max_n_f64() == 28672 and L.fz_tune_max_gold() == 8
+    # argument errors, one per family (no HIP call is reached: works without a GPU)
+    assert L.fz_normalize_rows_f32(None, 4, 8, 8, None, 8, None) == ERR
+    assert L.fz_normalize_rows_f32(None, -1, 8, 8, None, 8, None) == ERR
+    assert L.fz_dot_scores_f32(None, 4, None, 4, -1, 1, 4, None, 1, None) == ERR
+    assert L.fz_maxsim_f16(None, None, None, 0, 512, 1, 64, 1, 128, None, 1, None) == ERR
+    assert L.fz_sort_rows_desc_placed(None, 32, None, None, 1, 1, 1, None, None, None, None, 0, None) == ERR
+    assert L.fz_fuse_rank_f64(None, None, 0, 1, 1, 1, 0, None, None) == ERR
+    assert L.fz_fuse_rank_f64(None, None, 99, 1, 1, 1, 0, None, None) == ERR
+    assert L.fz_row_stats_f32(None, None, 1, 1, 1, 1, None, None, None) == ERR
+    assert L.fz_fuse_nsf_f32(None, None, None, 1, 1, 1, 1, 1, None, None, None, 0, None, None) == ERR
+    assert L.fz_fuse_nsf_stats_f32(None, None, None, 1, 1, 1, 1, 1, None, None, None, None, None, 0, None, None) == ERR
+    assert L.fz_fuse_none_f64(None, None, None, 1, 1, 1, 1, None, None) == ERR
+    assert L.fz_fuse_wsum_f64(None, None, None, None, None, 1, 1, 1, 1, None, None) == ERR
+    assert L.fz_insertion_order(None, None, 1, 1, 1, 1, None, None, None, 0, None) == ERR
+    assert L.fz_topk_rows_f32(None, 1, 10, 10, 5, 0, None, None, None, 0, None) == ERR
+    assert L.fz_topk_rows_f32(None, 1, 10, 10, kmax + 1, 0, None, None, None, 0, None) in (ERR, _lib.FZ_ERR_UNSUPPORTED)
+    assert L.fz_topk_merge(None, None, 2, 1, 10, None, None, None) == ERR
+    assert L.fz_topk_allgather(None, None, 1, 10, None, 2, None, None, None, 0, None) == ERR
+    assert L.fz_bm25_scores_f64(None, None, None, None, None, None, 1.0, 2.5, 0.2, None, None, 1, 1, None, 1, None) == ERR
+    assert L.fz_gold_ranks_f32(None, None, None, None, 2, 1, 1, 1, 1, None, None) == ERR
+    assert L.fz_tune_metrics_f64(None, None, None, 1, None, None, None, 1, None, 1, 0, 0, 0, 1, 1, None, None) == ERR
+    assert L.fz_attn_varlen_f32(None, 1, None, 1, 12, 64, 0.125, None, 1, None) == ERR
+    assert L.fz_add_layernorm_f32(None, 1, None, 1, None, None, 1e-5, 1, 768, None, 1, None) == ERR
+    assert L.fz_gelu_f32(None, None, 4, None) == ERR
+    assert L.fz_segment_mean_f32(None, 1, None, 1, 768, None, 1, None) == ERR
+
+
+def test_integration_md_binding_matches_the_abi():
+    """INTEGRATION.md's reference-side binding is executable documentation: its argtypes must be the binding table's
+    (fusion_amd/_lib.py == include/fusion_hip.h) and every call in it must pass exactly that many arguments -- round 2's
+    snippet had rotted to a 13-argument fz_sort_rows_desc."""
+    import ast
+    from fusion_amd import _lib
+    from helpers import integration_snippet
+    code = integration_snippet(ROOT)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)             # module level: loads the library, checks the ABI version, sets argtypes
+    L = ns["L"]
+    bound = [n for n in _lib.EXPORTS if getattr(getattr(L, n), "argtypes", None) is not None]
+    assert {"fz_sort_rows_desc", "fz_sort_rows_desc_placed", "fz_fuse_rank_f64", "fz_sort_workspace_bytes"} <= set(bound)
+    for n in bound:
+        assert list(getattr(L, n).argtypes) == list(_lib._PROTOS[n][1]), n
+    calls = [c for c in ast.walk(ast.parse(code)) if isinstance(c, ast.Call) and isinstance(c.func, ast.Attribute)
+             and isinstance(c.func.value, ast.Name) and c.func.value.id == "L" and c.func.attr.startswith("fz_")]
+    assert len(calls) >= 5
+    for c in calls:
+        assert len(c.args) == len(_lib._PROTOS[c.func.attr][1]) and not c.keywords, (c.func.attr, len(c.args))
+    assert f"fz_abi_version() == {_lib.ABI_VERSION}" in code
+
+
 def test_no_cpu_fallback():
     from fusion_amd import ops
     with pytest.raises(TypeError, match="no CPU path"):
