@@ -41,7 +41,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32, dense
 MFMA_F16_PEAK_TF = 2500.0      # v_mfma_f32_32x32x16_f16, dense
 METRIC = "queries/sec end-to-end (encode+score+fuse), LLeQA test; recall@500 parity"
-TRAFFIC_PROFILES = ("r02_hbm_traffic.json", "r01_hbm_traffic.json")
+TRAFFIC_PROFILES = ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
+# the stages of the step that ARE the path's kernels (scoring, ranking, fusion behind the C ABI).  The bench line's
+# `roofline` names the one of THESE that takes the most time per step; the encoder's kernels (HIP and vendor) stay in `roofline_all`.
+PATH_STAGES = ("dpr_score", "dpr_rank", "bm25_score", "bm25_rank", "fuse_rrf", "final_order")
 
 
 def parse():
@@ -179,6 +182,7 @@ def build_lleqa(args, dev, rank):
     st["encode_mode"] = args.encode_mode
     st["overlap"] = args.overlap_bm25
     st["host"] = dict(idf=idf, toff=toff, pd=pd, tf=tf, lens=lens, qoff=qoff, qterms=qterms)
+    st["bm25_postings"] = int(df[qterms].sum())     # postings the batch's query terms touch (terms repeat: bm25.py:152 does not de-duplicate)
     return st
 
 
@@ -251,6 +255,8 @@ def algorithmic_work(st):
     w.update({
         "dpr_score": dict(kernel="dot_scores_kernel (+ normalize_rows)", bound="mfma_f32", work=2.0 * Q * N * d),
         "dpr_rank": dict(kernel="sort_rows_kernel (f32 keys)", bound="hbm", work=e * (4 + 4 + 4)),
+        # BM25: every touched posting read once (doc id + tf, 8 B) + the fp64 score plane written once
+        "bm25_score": dict(kernel="bm25_kernel", bound="hbm", work=st.get("bm25_postings", 0) * 8 + e * 8),
         "bm25_rank": dict(kernel="sort_rows_kernel (f64 keys)", bound="hbm", work=e * (8 + 4 + 4)),
         "fuse_rrf": dict(kernel="fuse_rank_kernel", bound="hbm", work=e * (2 * 4 + 8)),
         "final_order": dict(kernel="sort_rows_kernel (f64 keys, placed)", bound="hbm", work=e * (8 + 4 + 4 + 8)),
@@ -265,7 +271,7 @@ def profiled_traffic(stage, st):
     if (st["Q"], st["N"], st["d"]) != (1024, 27942, 768):
         return None, None
     pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1,", "bm25_rank": "sort_rows_kernel<1024, 28, 2, false",
-            "final_order": "sort_rows_kernel<1024, 28, 2, false", "fuse_rrf": "fuse_rank_kernel", "encode_attn": "attn_varlen_kernel",
+            "final_order": "sort_rows_kernel<1024, 28, 2, false", "fuse_rrf": "fuse_rank_kernel", "bm25_score": "bm25_kernel", "encode_attn": "attn_varlen_kernel",
             "encode_gelu": "gelu_kernel", "encode_ln": "add_layernorm_kernel"}
     for name in TRAFFIC_PROFILES:
         try:
@@ -353,7 +359,7 @@ def rand_plane(ops, Q, N, g, scale=1.0, shift=0.0):
 def measure_configs(dev, N=27942):
     from fusion_amd import ops
     from fusion_amd.planes import RankedSystem
-    from fusion_amd.retrievers.hybrid import Aggregator, weight_grid
+    from fusion_amd.retrievers.hybrid import Aggregator, _rank_scores, weight_grid
     out = []
     g = torch.Generator(device=dev).manual_seed(11)
 
@@ -402,18 +408,9 @@ def measure_configs(dev, N=27942):
     names = ["bm25", "dpr", "splade", "colbert"]
     for Q in (1024, 195):
         planes = [rand_plane(ops, Q, N, g, s + 1.0, float(s)) for s in range(4)]
-        systems = {}
-        for i, (n, p) in enumerate(zip(names, planes)):
-            zst = (torch.empty(Q, dtype=torch.float32, device=dev), torch.empty(Q, dtype=torch.float32, device=dev))
-            od, sk, rk = ops.sort_rows_desc(p, want_rank=True, stats_out=zst)   # mean / std fall out of the ranking sort (hybrid._rank_scores)
-            if n == "colbert":   # PLAID-style short lists: the last 40 % of every ranking is absent
-                k = int(0.6 * N)
-                rk = ops.as_plane(torch.where(rk < k, rk, torch.full_like(rk, -1))); od = od.clone(); od[:, k:] = -1   # planes, as _rank_scores hands them on
-                systems[n] = RankedSystem(scores=p, order=od, rank=rk, lens=torch.full((Q,), k, dtype=torch.int32, device=dev),
-                                          ids=np.arange(N), full=False, score_sorted=True)
-            else:
-                systems[n] = RankedSystem(scores=p, order=od, rank=rk, lens=torch.full((Q,), N, dtype=torch.int32, device=dev),
-                                          ids=np.arange(N), full=True, score_sorted=True, zstats=zst)
+        # ranked the way Ranker hands systems on (hybrid._rank_scores): rank / order planes, and mean | std | min | max of every list as
+        # by-products of the ranking sort; ColBERT as PLAID-style short lists (the last 40 % of every ranking absent)
+        systems = {n: _rank_scores(p, np.arange(N), int(0.6 * N) if n == "colbert" else None) for n, p in zip(names, planes)}
         ranks = [None if s.full else s.rank for s in systems.values()]   # what Aggregator.fuse_device passes: validity of the partial list only
         w = [0.25] * 4
         fused = ops.alloc_plane(Q, N, torch.float32, dev)
@@ -425,15 +422,11 @@ def measure_configs(dev, N=27942):
         vbits = [s.valid_bits() for s in systems.values()]     # the partial list's validity as a bitmap, built once per system
         lens4 = torch.stack([s.lens for s in systems.values()]).contiguous()
         for norm in ("min-max", "z-score", "percentile-rank"):
-            # called the way Aggregator.fuse_device calls it: min-max of score-sorted lists takes the statistics from the list ends
-            kw = dict(orders=orders, lens=lens4) if norm == "min-max" else {}
-            kw["valid_bits"] = vbits
-
+            # called the way Aggregator.fuse_device calls it: every system brings the statistics its ranking sort produced (the short ColBERT
+            # lists: over their listed prefix), the partial list's validity is a bitmap -- the fusion is ONE flat pass, nothing else is launched
             def call():
-                if norm == "z-score":   # as fuse_device: the full systems' statistics come from their ranking, the partial list's from one reduction
-                    st = [s.zstats if s.full else ops.row_stats(s.scores, s.rank, "z-score") for s in systems.values()]
-                    return ops.fuse_nsf(planes, ranks, w, norm, out=fused, stats=(torch.cat([a for a, _ in st]), torch.cat([b for _, b in st])), **kw)
-                return ops.fuse_nsf(planes, ranks, w, norm, distr if norm == "percentile-rank" else None, out=fused, **kw)
+                st = [s.stats(norm) for s in systems.values()] if norm != "percentile-rank" else None
+                return ops.fuse_nsf(planes, ranks, w, norm, distr if norm == "percentile-rank" else None, out=fused, stats=st, valid_bits=vbits)
             ms = timeit_ms(call, n=10)
             out.append(dict(config=f"4: nsf {norm} fusion, S=4, colbert 40% absent", shape=dict(Q=Q, N=N, S=4),
                             **roof("fuse_nsf kernels", ms, work, "hbm")))
@@ -466,6 +459,123 @@ def measure_configs(dev, N=27942):
                     **roof("dot_scores_kernel<filter epilogue> + topk kernels", ms, 2.0 * Q * Nl * 768, "mfma_f32")))
     return out
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 4 as a PIPELINE (hybrid.py:344-358,431-455): four systems end to end, per stage, and the corpus-side encode
+# ---------------------------------------------------------------------------------------------------------------------
+def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
+    """BASELINE.json configs[3] end to end on one GPU: BM25 + DPR + SPLADE + ColBERT (each: query encode where it has an encoder, score,
+    full ranking), the 4-way nsf min-max fusion with equal weights (hybrid.py:448) and the final order -- HIP events per stage, queries/s
+    for the whole chain.  The corpus side (document embeddings / SPLADE vectors / ColBERT token matrix / BM25 index) is static and built
+    once, untimed; what encoding it costs is reported separately (corpus_encode: tokens/s per encoder on a 1/8 LLeQA-shaped sample)."""
+    from fusion_amd import encoders, ops
+    from fusion_amd.planes import RankedSystem
+    from fusion_amd.retrievers.hybrid import Aggregator, _rank_scores
+    out = []
+    g = torch.Generator(device=dev).manual_seed(31)
+    rng = np.random.default_rng(31)
+    ids_np = np.arange(N)
+    enc = {k: encoders.random_init(k, device=dev, size="base", seed=i) for i, k in enumerate(("dpr", "splade", "colbert"))}
+    cfg = enc["dpr"].backbone.config
+    V, Vp = cfg.vocab_size, -(-cfg.vocab_size // 4) * 4
+    # ---- corpus side, static --------------------------------------------------------------------------------------
+    Dn = ops.normalize_rows(torch.randn((N, 768), generator=g, device=dev))
+    Ds = torch.zeros((N, Vp), device=dev)
+    for c0 in range(0, N, 4096):
+        c1 = min(N, c0 + 4096)
+        Ds[c0:c1, :V] = torch.log1p(torch.relu(torch.randn((c1 - c0, V), generator=g, device=dev) - 1.0))
+    Ds = ops.normalize_rows(Ds)
+    dl = np.clip(rng.normal(300, 120, N), 16, 512).astype(np.int64)
+    off = np.zeros(N + 1, dtype=np.int64); off[1:] = np.cumsum(dl)
+    Dtok = torch.nn.functional.normalize(torch.randn((int(off[-1]), 128), generator=g, device=dev), dim=-1).half()
+    Doff = torch.from_numpy(off).to(dev)
+    Vb, blens, tok, doc, pz = synth_bm25_index(N, np.random.default_rng(99))
+    uniq, tf = np.unique(tok.astype(np.int64) * N + doc, return_counts=True)
+    pt, pd = uniq // N, uniq % N
+    df = np.bincount(pt, minlength=Vb)
+    toff = np.zeros(Vb + 1, dtype=np.int64); np.cumsum(df, out=toff[1:])
+    bm = dict(toff=torch.from_numpy(toff).to(dev), pdoc=torch.from_numpy(pd.astype(np.int32)).to(dev), ptf=torch.from_numpy(tf.astype(np.int32)).to(dev),
+              idf=torch.from_numpy(np.log10((N - df + 0.5) / (df + 0.5))).to(dev), doc_len=torch.from_numpy(blens.astype(np.int32)).to(dev), avgdl=float(blens.mean()))
+    bm["doc_norm"] = ops.bm25_doc_norms(bm["doc_len"], bm["avgdl"], 2.5, 0.2)
+
+    for Q in queries:
+        qids, _, qlen = synth_query_tokens(rng, Q, V, cfg.pad_token_id)
+        qids_d = torch.from_numpy(qids).to(dev)
+        cq = np.where(np.arange(64)[None, :] < qlen[:, None], qids, encoders.MASK_TOKEN_ID)     # ColBERT: padded with the mask token, all attended
+        cq_d = torch.from_numpy(cq).to(dev)
+        qn = rng.integers(4, 16, Q)
+        qterms = torch.from_numpy(rng.choice(Vb, size=int(qn.sum()), p=pz).astype(np.int32)).to(dev)
+        qoff_h = np.zeros(Q + 1, dtype=np.int64); np.cumsum(qn, out=qoff_h[1:])
+        qoff = torch.from_numpy(qoff_h).to(dev)
+        names = ["bm25", "dpr", "splade", "colbert"]
+        w = {n: 1 / 4 for n in names}                                                           # hybrid.py:448
+
+        def step(mark):
+            mark("start")
+            B = ops.bm25_scores(bm["toff"], bm["pdoc"], bm["ptf"], bm["idf"], bm["doc_len"], bm["avgdl"], 2.5, 0.2, qoff, qterms, Q, N, doc_norm=bm["doc_norm"])
+            mark("bm25_score")
+            st4 = torch.empty((4, Q), dtype=torch.float32, device=dev)
+            o_b, sk_b, r_b = ops.sort_rows_desc(B, want_rank=True, stats_out=st4)
+            sys_b = RankedSystem(scores=ops.f64_to_f32(B), order=o_b, rank=r_b, lens=torch.full((Q,), N, dtype=torch.int32, device=dev), ids=ids_np,
+                                 sorted_scores=sk_b, full=True, scores64=B, score_sorted=True, stats4=st4)
+            mark("bm25_rank")
+            e = enc["dpr"].encode_ids_packed(qids_d, qlen); mark("dpr_encode")
+            S_d = ops.dot_scores(ops.normalize_rows(e), Dn); mark("dpr_score")
+            sys_d = _rank_scores(S_d, ids_np, None); mark("dpr_rank")
+            v = enc["splade"].encode_ids_packed(qids_d, qlen); mark("splade_encode")
+            S_s = ops.dot_scores(ops.normalize_rows(v), Ds); mark("splade_score")
+            sys_s = _rank_scores(S_s, ids_np, None); mark("splade_rank")
+            Qtok = enc["colbert"].encode_query_ids(cq_d); mark("colbert_encode")
+            S_c = ops.maxsim(Qtok, Dtok, Doff, max_doc_len=512); mark("colbert_maxsim")
+            sys_c = _rank_scores(S_c, ids_np, None); mark("colbert_rank")
+            fused = Aggregator.fuse_device(dict(bm25=sys_b, dpr=sys_d, splade=sys_s, colbert=sys_c), "nsf", "min-max", w, {})
+            mark("fuse_and_order")
+            return fused
+        for _ in range(2):
+            step(lambda n: None)
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step(lambda n: None)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / reps
+        ev = Events()
+        step(ev.mark)
+        torch.cuda.synchronize()
+        stages, _ = ev.durations_ms()
+        sumL = int(off[-1])
+        out.append(dict(config="4: BM25+DPR+SPLADE+ColBERT pipeline END TO END (query encode x3, score x4, full ranking x4, nsf min-max fusion, final order)",
+                        shape=dict(Q=Q, N=N, S=4), ms=wall * 1e3, queries_per_s=Q / wall, stages_ms=stages,
+                        dominant_stage=max(stages, key=stages.get),
+                        stage_rooflines={"dpr_score": roof("dot_scores_kernel", stages["dpr_score"], 2.0 * Q * N * 768, "mfma_f32")["frac"],
+                                         "splade_score": roof("dot_scores_kernel", stages["splade_score"], 2.0 * Q * N * V, "mfma_f32")["frac"],
+                                         "colbert_maxsim": roof("maxsim_kernel", stages["colbert_maxsim"], 2.0 * Q * 64 * sumL * 128, "mfma_f16")["frac"]}))
+    del Ds, Dtok, Dn
+
+    # ---- corpus-side encode (hybrid.py:101; the reference's dominant cost, re-paid by each of run_hybrid.sh's processes) -----------
+    n = N // 8
+    lens = np.clip(rng.normal(300, 120, n), 16, 512).astype(np.int64)
+    ids = torch.from_numpy(rng.integers(7, V - 1, (n, 512))).to(dev)
+    T = int(lens.sum())
+    h, ff, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    body = 2.0 * T * L * (4 * h * h + 2 * h * ff)                                # the four Linears of every layer
+    attn = 4.0 * L * h * float((lens.astype(np.float64) ** 2).sum())             # q k^T and p v over each sequence
+    heads = {"dpr": 0.0, "splade": 2.0 * T * (h * h + h * V), "colbert": 2.0 * T * h * 128}
+    runs = {"dpr": lambda: enc["dpr"].encode_ids_corpus(ids, lens), "splade": lambda: enc["splade"].encode_ids_packed(ids, lens),
+            "colbert": lambda: enc["colbert"].encode_doc_ids(ids, lens)}
+    for k in ("dpr", "splade", "colbert"):
+        runs[k]()                                                                # first pass: TunableOp settles the sub-batch shapes
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        runs[k]()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        fl = body + attn + heads[k]
+        out.append(dict(config=f"corpus encode, {k} (CamemBERT-base-shaped fp32, padding-free forward), 1/8 of the LLeQA-shaped corpus",
+                        shape=dict(docs=n, tokens=T, mean_len=float(lens.mean())), ms=dt * 1e3, tokens_per_s=T / dt, docs_per_s=n / dt,
+                        full_corpus_s_estimate=dt * 8, flops=fl, bound="mfma", achieved=fl / dt / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                        frac=fl / dt / (MFMA_F32_PEAK_TF * 1e12)))
+    return out
 
 # ---------------------------------------------------------------------------------------------------------------------
 # N > 1: the corpus-sharded mMARCO config (north_star's multi-GPU configuration)
@@ -726,9 +836,12 @@ def main():
         work = algorithmic_work(st)
         all_roof = {k: roof(work[k]["kernel"], per_launch[k], work[k]["work"], work[k]["bound"], ms_per_step=stages[k],
                             launches_per_step=cnt[k] // args.steps, hand_written=work[k].get("hand", True)) for k in work if k in per_launch}
-        hand = {k: v for k, v in all_roof.items() if v["hand_written"]}
-        dom = max(hand, key=lambda k: hand[k]["ms_per_step"])                          # dominant = most time per step among OUR kernels
+        hand = {k: v for k, v in all_roof.items() if k in PATH_STAGES}                  # the path's own kernels
+        dom = max(hand, key=lambda k: hand[k]["ms_per_step"])                          # dominant = most time per step among them
         traffic, src = profiled_traffic(dom, st)
+        for k in all_roof:                                                             # every stage carries its profiled traffic too
+            t_k, s_k = profiled_traffic(k, st)
+            all_roof[k]["traffic"], all_roof[k]["traffic_source"] = t_k, s_k
         rl = dict(hand[dom], stage=dom, traffic=traffic,
                   traffic_source=(src + " (rocprofv3 PMC pass of this command at this shape; profile-derived, not measured in this run)") if src else None)
         res = {
@@ -764,9 +877,32 @@ def main():
             del st, out
             torch.cuda.empty_cache()
             res["configs_measured"] = measure_configs(dev, N)
+            torch.cuda.empty_cache()
+            res["configs_measured"] += measure_pipeline4(dev, N)
+        res["north_star_targets"] = north_star_targets(res)
         print(json.dumps(res))
     if dist:
         dist.destroy_process_group()
+
+
+def north_star_targets(res):
+    """The two numeric targets BASELINE.json's north_star states, read off THIS run: >= 90 % of the HBM peak on the normalisation +
+    fusion pass and >= 70 % MFMA utilisation on DPR scoring at query batch 1024 (fp32 MFMA: the 1e-4 score contract rules out f16)."""
+    d = res["roofline_all"].get("dpr_score")
+    out = {"dpr_mfma_frac": None if d is None else {"value": d["frac"], "target": 0.70, "met": d["frac"] >= 0.70, "kernel": d["kernel"],
+                                                      "where": "dpr_score stage of the timed step (Q = queries_per_gpu)", "peak_TFLOPs": MFMA_F32_PEAK_TF}}
+    fuse = {}
+    r = res["roofline_all"].get("fuse_rrf")
+    if r is not None:
+        fuse["rrf S=2, in the timed step"] = r["frac"]
+    for c in res.get("configs_measured", []):
+        if c.get("config", "").startswith("4: nsf") and c.get("shape", {}).get("Q") == 1024:
+            fuse[c["config"][3:]] = c["frac"]
+    best = max(fuse.values()) if fuse else None
+    out["fuse_hbm_frac"] = {"value": best, "target": 0.90, "met": bool(best is not None and best >= 0.90), "all": fuse, "peak_GBs": HBM_PEAK_GBS,
+                            "note": "fractions of the 8.0 TB/s spec; MI355X_MICROARCH.md measures 6.29 TB/s for a float4 copy on this part (0.79 of spec), "
+                                    "so 0.90 of spec is above what the memory system delivers -- the fractions are reported against spec all the same"}
+    return out
 
 
 def oracle_sort(plane):

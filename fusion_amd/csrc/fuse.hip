@@ -225,6 +225,8 @@ struct NsfArgs {
     const float* distr[FZ_MAX_SYSTEMS];
     int P[FZ_MAX_SYSTEMS];
     float w[FZ_MAX_SYSTEMS];
+    const float* sa[FZ_MAX_SYSTEMS];         // per-system row statistics [Q] (min | mean) and (max | unbiased std) for the flat passes: each system
+    const float* sb[FZ_MAX_SYSTEMS];         //   brings its own (a by-product of the sort that ranked it), nothing is concatenated per fusion call
     int S, N, ld, Q;
 };
 
@@ -518,8 +520,7 @@ __global__ __launch_bounds__(T) void fuse_nsf_row_kernel(NsfArgs a, float* __res
 
 // general-N path: statistics from a separate pass (stat arrays [S][Q]), then elementwise.
 template <int NORM>
-__global__ __launch_bounds__(256) void fuse_nsf_elem_kernel(NsfArgs a, const float* __restrict__ stat_a,
-                                                            const float* __restrict__ stat_b, int Q, float* __restrict__ fused) {
+__global__ __launch_bounds__(256) void fuse_nsf_elem_kernel(NsfArgs a, int Q, float* __restrict__ fused) {
     const int q = blockIdx.y;
     const size_t rowoff = (size_t)q * a.ld;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < a.N; j += gridDim.x * blockDim.x) {
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256) void fuse_nsf_elem_kernel(NsfArgs a, const flo
         bool present = false;
         for (int s = 0; s < a.S; ++s) {
             if (a.vbits[s] ? !((a.vbits[s][(size_t)q * a.ldb + (j >> 5)] >> (j & 31)) & 1u) : (a.ranks[s] && a.ranks[s][rowoff + j] < 0)) continue;
-            float t = transform<NORM>(a.planes[s][rowoff + j], stat_a[s * Q + q], stat_b[s * Q + q], a.distr[s], a.P[s]);
+            float t = transform<NORM>(a.planes[s][rowoff + j], a.sa[s] ? a.sa[s][q] : 0.f, a.sb[s] ? a.sb[s][q] : 0.f, a.distr[s], a.P[s]);
             float prod = t * a.w[s];
             acc = acc + prod;
             present = true;
@@ -540,8 +541,7 @@ __global__ __launch_bounds__(256) void fuse_nsf_elem_kernel(NsfArgs a, const flo
 // hand the whole fusion is ONE flat streaming pass -- and for min-max on RANKED systems they are: min and max of a list sorted
 // by score are its last and first entries (minmax_from_order_kernel), no reduction over the row at all.
 template <int NORM>
-__global__ __launch_bounds__(256) void fuse_nsf_elem4_kernel(NsfArgs a, const float* __restrict__ stat_a,
-                                                             const float* __restrict__ stat_b, int Q, float* __restrict__ fused) {
+__global__ __launch_bounds__(256) void fuse_nsf_elem4_kernel(NsfArgs a, int Q, float* __restrict__ fused) {
     const int q = blockIdx.y;
     const size_t rowoff = (size_t)q * a.ld;
     const int j0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void fuse_nsf_elem4_kernel(NsfArgs a, const fl
         const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.planes[s] + rowoff + j0));   // streamed once
         const float v[4] = {f.x, f.y, f.z, f.w};
         const uint32_t nib = valid_nibble(a, s, q, rowoff, j0);
-        const float sa = stat_a ? stat_a[s * Q + q] : 0.f, sb = stat_b ? stat_b[s * Q + q] : 0.f, w = a.w[s];
+        const float sa = a.sa[s] ? a.sa[s][q] : 0.f, sb = a.sb[s] ? a.sb[s][q] : 0.f, w = a.w[s];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (((nib >> c) & 1u) && j0 + c < a.N) {
@@ -1102,17 +1102,17 @@ extern "C" int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* cons
 }
 
 // general-N two-pass variant (statistics supplied by the caller, e.g. from fz_row_stats_f32)
-extern "C" int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S,
-                                     int Q, int N, int ld, int norm, const float* const* distr_h, const int32_t* P_h,
-                                     const float* stat_a, const float* stat_b, const uint32_t* const* valid_bits_h, int ldb,
-                                     float* fused, void* stream) {
+static int fuse_nsf_with_stats(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S,
+                               int Q, int N, int ld, int norm, const float* const* distr_h, const int32_t* P_h,
+                               const float* const* stat_a_h, const float* const* stat_b_h, const uint32_t* const* valid_bits_h, int ldb,
+                               float* fused, void* stream) {
     if (!planes_h || !w_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
     if (norm < FZ_NORM_MINMAX || norm > FZ_NORM_NCE) return FZ_ERR_ARG;
     if (Q == 0 || N == 0) return FZ_OK;                 // empty tensors carry null pointers
     if (!fused) return FZ_ERR_ARG;
     const bool needs_stats = (norm == FZ_NORM_MINMAX || norm == FZ_NORM_ZSCORE);
     const bool needs_distr = (norm == FZ_NORM_PERCENTILE || norm == FZ_NORM_NCE);
-    if (needs_stats && (!stat_a || !stat_b)) return FZ_ERR_ARG;
+    if (needs_stats && (!stat_a_h || !stat_b_h)) return FZ_ERR_ARG;
     if (needs_distr && (!distr_h || !P_h)) return FZ_ERR_ARG;
     if (Q == 0 || N == 0) return FZ_OK;
     NsfArgs a{};
@@ -1125,6 +1125,10 @@ extern "C" int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t
         a.distr[s] = needs_distr ? distr_h[s] : nullptr;
         a.P[s] = needs_distr ? P_h[s] : 0;
         a.w[s] = (float)w_h[s];
+        if (needs_stats) {
+            if (!stat_a_h[s] || !stat_b_h[s]) return FZ_ERR_ARG;
+            a.sa[s] = stat_a_h[s]; a.sb[s] = stat_b_h[s];
+        }
     }
     a.ldb = ldb;
     if (valid_bits_h && ldb * 32 < N) return FZ_ERR_ARG;
@@ -1134,23 +1138,62 @@ extern "C" int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t
     if (vec) {
         dim3 grid((unsigned)((N + 1023) / 1024), (unsigned)Q);
         switch (norm) {
-            case FZ_NORM_MINMAX: fuse_nsf_elem4_kernel<FZ_NORM_MINMAX><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
-            case FZ_NORM_ZSCORE: fuse_nsf_elem4_kernel<FZ_NORM_ZSCORE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
-            case FZ_NORM_ARCTAN: fuse_nsf_elem4_kernel<FZ_NORM_ARCTAN><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
-            case FZ_NORM_PERCENTILE: fuse_nsf_elem4_kernel<FZ_NORM_PERCENTILE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
-            case FZ_NORM_NCE: fuse_nsf_elem4_kernel<FZ_NORM_NCE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
+            case FZ_NORM_MINMAX: fuse_nsf_elem4_kernel<FZ_NORM_MINMAX><<<grid, 256, 0, st>>>(a, Q, fused); break;
+            case FZ_NORM_ZSCORE: fuse_nsf_elem4_kernel<FZ_NORM_ZSCORE><<<grid, 256, 0, st>>>(a, Q, fused); break;
+            case FZ_NORM_ARCTAN: fuse_nsf_elem4_kernel<FZ_NORM_ARCTAN><<<grid, 256, 0, st>>>(a, Q, fused); break;
+            case FZ_NORM_PERCENTILE: fuse_nsf_elem4_kernel<FZ_NORM_PERCENTILE><<<grid, 256, 0, st>>>(a, Q, fused); break;
+            case FZ_NORM_NCE: fuse_nsf_elem4_kernel<FZ_NORM_NCE><<<grid, 256, 0, st>>>(a, Q, fused); break;
         }
         FZ_LAUNCH_CHECK();
         return FZ_OK;
     }
     dim3 grid((unsigned)((N + 255) / 256 < 64 ? (N + 255) / 256 : 64), (unsigned)Q);
     switch (norm) {
-        case FZ_NORM_MINMAX: fuse_nsf_elem_kernel<FZ_NORM_MINMAX><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
-        case FZ_NORM_ZSCORE: fuse_nsf_elem_kernel<FZ_NORM_ZSCORE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
-        case FZ_NORM_ARCTAN: fuse_nsf_elem_kernel<FZ_NORM_ARCTAN><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
-        case FZ_NORM_PERCENTILE: fuse_nsf_elem_kernel<FZ_NORM_PERCENTILE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
-        case FZ_NORM_NCE: fuse_nsf_elem_kernel<FZ_NORM_NCE><<<grid, 256, 0, st>>>(a, stat_a, stat_b, Q, fused); break;
+        case FZ_NORM_MINMAX: fuse_nsf_elem_kernel<FZ_NORM_MINMAX><<<grid, 256, 0, st>>>(a, Q, fused); break;
+        case FZ_NORM_ZSCORE: fuse_nsf_elem_kernel<FZ_NORM_ZSCORE><<<grid, 256, 0, st>>>(a, Q, fused); break;
+        case FZ_NORM_ARCTAN: fuse_nsf_elem_kernel<FZ_NORM_ARCTAN><<<grid, 256, 0, st>>>(a, Q, fused); break;
+        case FZ_NORM_PERCENTILE: fuse_nsf_elem_kernel<FZ_NORM_PERCENTILE><<<grid, 256, 0, st>>>(a, Q, fused); break;
+        case FZ_NORM_NCE: fuse_nsf_elem_kernel<FZ_NORM_NCE><<<grid, 256, 0, st>>>(a, Q, fused); break;
     }
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+extern "C" int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S,
+                                     int Q, int N, int ld, int norm, const float* const* distr_h, const int32_t* P_h,
+                                     const float* stat_a, const float* stat_b, const uint32_t* const* valid_bits_h, int ldb,
+                                     float* fused, void* stream) {
+    const float* pa[FZ_MAX_SYSTEMS] = {};
+    const float* pb[FZ_MAX_SYSTEMS] = {};
+    if (S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0) return FZ_ERR_ARG;
+    for (int s = 0; s < S; ++s) { pa[s] = stat_a ? stat_a + (size_t)s * Q : nullptr; pb[s] = stat_b ? stat_b + (size_t)s * Q : nullptr; }
+    return fuse_nsf_with_stats(planes_h, ranks_h, w_h, S, Q, N, ld, norm, distr_h, P_h, stat_a ? pa : nullptr, stat_b ? pb : nullptr, valid_bits_h,
+                               ldb, fused, stream);
+}
+
+// the same with one statistics pointer PER SYSTEM (host arrays of S device pointers, [Q] floats each): every ranked system keeps the
+// statistics its ranking sort produced (fz_sort_rows_desc(row_stats)), so a fusion call concatenates nothing and reduces nothing
+extern "C" int fz_fuse_nsf_pstats_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S,
+                                      int Q, int N, int ld, int norm, const float* const* distr_h, const int32_t* P_h,
+                                      const float* const* stat_a_h, const float* const* stat_b_h, const uint32_t* const* valid_bits_h, int ldb,
+                                      float* fused, void* stream) {
+    if (S <= 0 || S > FZ_MAX_SYSTEMS) return FZ_ERR_ARG;
+    return fuse_nsf_with_stats(planes_h, ranks_h, w_h, S, Q, N, ld, norm, distr_h, P_h, stat_a_h, stat_b_h, valid_bits_h, ldb, fused, stream);
+}
+
+// Aggregator.aggregate_scores adds nothing for a document a system does not list (hybrid.py:301-304): plane[q][j] = 0 where rank[q][j] < 0.
+// The single-system planes of fz_fuse_nsf_f32 (weight 1) hold -inf there; the weight sweep (fz_gold_ranks_*) wants 0.
+__global__ __launch_bounds__(256) void zero_unlisted_kernel(float* __restrict__ plane, const int32_t* __restrict__ rank, int N, int ld) {
+    const size_t rowoff = (size_t)blockIdx.y * ld;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x)
+        if (rank[rowoff + j] < 0) plane[rowoff + j] = 0.f;
+}
+extern "C" int fz_zero_unlisted_f32(float* plane, const int32_t* rank, int Q, int N, int ld, void* stream) {
+    if (Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (Q == 0 || N == 0) return FZ_OK;
+    if (!plane || !rank) return FZ_ERR_ARG;
+    dim3 grid((unsigned)((N + 255) / 256 < 32 ? (N + 255) / 256 : 32), (unsigned)Q);
+    zero_unlisted_kernel<<<grid, 256, 0, as_stream(stream)>>>(plane, rank, N, ld);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

@@ -45,8 +45,10 @@ struct SortArgs {
     int64_t id_base;             // else out_ids = id_base + col
     int64_t* out_ids;            // nullable, [rows][out_row_stride] like order
     int32_t* row_flags;          // fp64 keys: [rows*chunks] 1 = the fast form left the row to the generic one
-    float* row_mean;             // nullable [rows]: mean and unbiased standard deviation of the row's float32 values, a by-product
-    float* row_std;              //   of having the row in registers (the z-score statistics of hybrid.py:261-262); plain rows only
+    float* row_stats;            // nullable [4][stats_rows]: mean | unbiased std | min | max of the list's float32 values (the statistics of
+    int stats_rows;              //   hybrid.py:254-262), a by-product of having the row in registers; chunks == 1 only
+    const int32_t* stats_len;    // nullable [rows]: the statistics cover the first stats_len[row] entries of the SORTED list (a ranking
+                                 //   truncated to its top-k: PLAID-style short lists, return_topk); fp32 keys only
 };
 
 // GEN (fp64 only): the generic eight-pass form, run as a second launch for the rows the fast form flags (see below).
@@ -79,7 +81,20 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     m_row = m_row < 0 ? 0 : (m_row > a.n_total ? a.n_total : m_row);
     int m = m_row - c0;
     m = m < 0 ? 0 : (m > a.chunk_len ? a.chunk_len : m);
-    if (m == 0) return;  // block-uniform: empty (pseudo-)row
+    // statistics by-product (block-uniform): over the whole list from the load phase, or -- stats_len -- over the first slen entries
+    // of the sorted list from the registers of the output phase
+    const bool st_on = a.row_stats && a.chunks == 1;
+    int slen = (st_on && a.stats_len) ? a.stats_len[row] : m;
+    slen = slen < 0 ? 0 : (slen > m ? m : slen);
+    const bool st_prefix = st_on && slen < m;
+    const bool st_load = !GEN && st_on && !st_prefix;
+    if (m == 0) {        // block-uniform: empty (pseudo-)row
+        if (st_on && threadIdx.x == 0) {
+            a.row_stats[row] = NAN; a.row_stats[a.stats_rows + row] = NAN;     // torch.mean / torch.std of an empty tensor
+            a.row_stats[2 * a.stats_rows + row] = 0.f; a.row_stats[3 * a.stats_rows + row] = 0.f;
+        }
+        return;
+    }
 
     // uniform row bases + 32-bit per-lane indices (saddr+voffset addressing; no 64-bit per-item addresses)
     const size_t krow = (size_t)row * a.key_row_stride;
@@ -179,8 +194,8 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         }
         __syncthreads();
     } else {
-        double s1 = 0.0, s2 = 0.0, sn = 0.0, x0 = 0.0;   // row statistics (only when a.row_mean)
-        if (!GEN && a.row_mean) {
+        double s1 = 0.0, s2 = 0.0, sn = 0.0, x0 = 0.0;   // row statistics (only when a.row_stats, whole-list form)
+        if (st_load) {
             float f0;
             if (KW == 1) f0 = kf[elem(init_row ? 0 : c0)];
             else { const uint2 v0 = kd[elem(init_row ? 0 : c0)]; f0 = (float)__hiloint2double((int)v0.y, (int)v0.x); }
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
                                             : (uint32_t)(key64(make_uint2(lo_t[i - i0], hi_t[KW == 2 ? i - i0 : 0])) >> (GEN ? 0 : 32));
                 ks[i] = ok ? kw : SENT;
                 orw |= ok ? kw : 0u; andw &= ok ? kw : 0xffffffffu;
-                if (!GEN && a.row_mean) {   // the value as the normalisations see it: float32 (BM25's float64 scores rounded, hybrid.py:261)
+                if (st_load) {   // the value as the normalisations see it: float32 (BM25's float64 scores rounded, hybrid.py:261)
                     const float xf = KW == 1 ? __uint_as_float(lo_t[i - i0]) : (float)__hiloint2double((int)hi_t[KW == 2 ? i - i0 : 0], (int)lo_t[i - i0]);
                     const double dd = ok ? (double)xf - x0 : 0.0;
                     s1 += dd; s2 = fma(dd, dd, s2); sn += ok ? 1.0 : 0.0;
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();   // misc[8..9] initialised
-        if (!GEN && a.row_mean && a.chunks == 1) {   // block-uniform
+        if (st_load) {   // block-uniform
             // z-score statistics of the row (torch.mean / torch.std of the float32 scores, hybrid.py:261-262): one pass, shifted by
             // the row's first value, fp64 throughout; wave sums by shuffles, the NW partial triples through the (still unused)
             // counter area, folded in wave order by every thread identically
@@ -234,8 +249,8 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
                 for (int i = 0; i < NW; ++i) { S1 += red[i]; S2 += red[NW + i]; n += red[2 * NW + i]; }
                 const double mean = n > 0.0 ? x0 + S1 / n : (double)NAN;
                 const double var = n > 1.0 ? (S2 - S1 * S1 / n) / (n - 1.0) : (double)NAN;
-                a.row_mean[row] = (float)mean;
-                a.row_std[row] = (float)sqrt(var < 0.0 ? 0.0 : var);
+                a.row_stats[row] = (float)mean;
+                a.row_stats[a.stats_rows + row] = (float)sqrt(var < 0.0 ? 0.0 : var);
             }
             __syncthreads();
         }
@@ -588,6 +603,63 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             __syncthreads();                                   // the slot numbers in exch[] have been read
             permute_to_meta_hi();
         }
+    }
+
+    // ---- statistics by-product (block-uniform).  min / max of a list sorted by score are its two ends (a NaN sorts first and makes both
+    // NaN, as torch.min / torch.max do): the columns of entries 0 and slen - 1 go through LDS, thread 0 reads their values back (L2 hits).
+    // A ranking cut to its first slen entries also takes its mean / unbiased std here: the sorted words go to LDS by rank and are summed by
+    // a rolled, strided loop (two live doubles) -- the same sums unrolled over the 28 register-resident keys spilled the sort's hot loops.
+    if (st_on) {
+        SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int p = (slot0 + i * 64);
+            const uint32_t col = (meta[i] & 0xffffu) + ((!init_row && !irow) ? (uint32_t)c0 : 0u);
+            if (p == 0) misc[17] = col;
+            if (p == slen - 1) misc[18] = col;
+        }
+        double x0 = 0.0;
+        const bool pre = KW == 1 && st_prefix;
+        if (pre) {
+            SLOT_FRESH();
+#pragma unroll
+            for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = ks[i];
+            __syncthreads();
+            const float f0 = desc_key_f32_inv(exch[0]);
+            x0 = (f0 == f0 && fabsf(f0) != INFINITY) ? (double)f0 : 0.0;
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll 1
+            for (int p = threadIdx.x; p < slen; p += T) {
+                const double dd = (double)desc_key_f32_inv(exch[p]) - x0;
+                s1 += dd; s2 = fma(dd, dd, s2);
+            }
+            s1 = wave_reduce_sum(s1); s2 = wave_reduce_sum(s2);
+            double* red = reinterpret_cast<double*>(cnt);
+            if (lane == 0) { red[w] = s1; red[NW + w] = s2; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            auto val = [&](int col) -> float {
+                if (KW == 1) return kf[elem(col)];
+                const uint2 v = kd[elem(col)];
+                return (float)__hiloint2double((int)v.y, (int)v.x);
+            };
+            float lo = 0.f, hi = 0.f;
+            if (slen > 0) { hi = val((int)misc[17]); lo = val((int)misc[18]); if (hi != hi) lo = hi; }
+            a.row_stats[2 * a.stats_rows + row] = lo;
+            a.row_stats[3 * a.stats_rows + row] = hi;
+            if (pre) {
+                const double* red = reinterpret_cast<const double*>(cnt);
+                double S1 = 0.0, S2 = 0.0;
+                for (int i = 0; i < NW; ++i) { S1 += red[i]; S2 += red[NW + i]; }
+                const double n = (double)slen;
+                const double mean = n > 0.0 ? x0 + S1 / n : (double)NAN;
+                const double var = n > 1.0 ? (S2 - S1 * S1 / n) / (n - 1.0) : (double)NAN;
+                a.row_stats[row] = (float)mean;
+                a.row_stats[a.stats_rows + row] = (float)sqrt(var < 0.0 ? 0.0 : var);
+            }
+        }
+        __syncthreads();   // exch[] and the counter area are free again
     }
 
     // ---- output (coalesced: consecutive lanes = consecutive ranks) -------------------------
@@ -999,14 +1071,15 @@ extern "C" size_t fz_sort_workspace_bytes(int key_bits, int rows, int n) {
 }
 
 extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows,
-                                 int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, float* row_mean, float* row_std,
+                                 int n, int ld, int32_t* order, void* sorted_keys, int32_t* rank, float* row_stats, const int32_t* stats_len,
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if ((key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
     if (rows == 0 || n == 0) return FZ_OK;      // nothing to do (empty tensors carry null pointers)
     if (!keys) return FZ_ERR_ARG;
-    if ((row_mean != nullptr) != (row_std != nullptr)) return FZ_ERR_ARG;
+    if (stats_len && !row_stats) return FZ_ERR_ARG;
+    if (stats_len && key_bits != 32) return FZ_ERR_UNSUPPORTED;   // prefix statistics come from the sorted fp32 keys in registers (fz_row_stats_f32 otherwise)
     if (n > (key_bits == 32 ? 35840 : 28672)) {   // longer than one workgroup's registers: chunk-sort + cross-chunk ranking
-        if (row_mean) return FZ_ERR_UNSUPPORTED;  // the statistics by-product exists for single-workgroup rows only (fz_row_stats_f32 otherwise)
+        if (row_stats) return FZ_ERR_UNSUPPORTED; // the statistics by-product exists for single-workgroup rows only (fz_row_stats_f32 otherwise)
         return sort_long_rows(keys, key_bits, init_order, nullptr, row_len, rows, n, ld, order, sorted_keys, rank, workspace, workspace_bytes,
                               as_stream(stream));
     }
@@ -1014,7 +1087,7 @@ extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* 
     a.keys = keys; a.init_order = init_order; a.row_len = row_len;
     a.n_total = n; a.key_row_stride = ld; a.seg_len = n; a.seg_stride = 0;
     a.chunks = 1; a.chunk_len = n;
-    a.order = order; a.sorted_keys = sorted_keys; a.rank = rank; a.row_mean = row_mean; a.row_std = row_std;
+    a.order = order; a.sorted_keys = sorted_keys; a.rank = rank; a.row_stats = row_stats; a.stats_rows = rows; a.stats_len = stats_len;
     a.out_row_stride = ld; a.out_chunk_stride = 0; a.out_limit = n;
     if (key_bits == 64) { if (!workspace || workspace_bytes < fz_sort_workspace_bytes(64, rows, n)) return FZ_ERR_WORKSPACE; a.row_flags = (int32_t*)workspace; }
     return launch_sort(a, key_bits / 32, rows, n, as_stream(stream));

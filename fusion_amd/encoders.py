@@ -101,6 +101,21 @@ def _token_batches(base, sentences, max_len, batch_size, tokenize=None):
         s += step
 
 
+def _id_batches(lengths, max_tokens: int):
+    """Sub-batches of already tokenised sequences for the padding-free forward: longest first (as SentenceTransformer.encode sorts),
+    cut where the running TOKEN count would pass `max_tokens`.  Yields index arrays into `lengths`."""
+    import numpy as np
+    lengths = np.asarray(lengths, dtype=np.int64)
+    order = np.argsort(-lengths, kind="stable")
+    csum = np.cumsum(lengths[order])
+    s = 0
+    while s < len(order):
+        e = int(np.searchsorted(csum, (csum[s - 1] if s else 0) + max_tokens, side="right"))
+        e = max(e, s + 1)
+        yield order[s:e]
+        s = e
+
+
 class FusedBertForward:
     """Lean fp32 forward of a BERT/RoBERTa-style encoder for a whole query batch (same weights, same maths as the HF
     module; checked against it in tests).  What it does differently from calling the HF module per length bucket:
@@ -301,6 +316,15 @@ class DenseEncoder(_Base):
         return self._packed(input_ids, lengths, mark=mark)   # raises for head_dim != 64
 
     @torch.no_grad()
+    def encode_ids_corpus(self, input_ids: torch.Tensor, lengths) -> torch.Tensor:
+        """encode_ids_packed for more sequences than one forward should hold: sub-batches of at most `packed_tokens` token rows."""
+        out = torch.empty((input_ids.shape[0], self.dim), dtype=torch.float32, device=self._device)
+        for idx in _id_batches(lengths, self.packed_tokens):
+            sel = torch.from_numpy(idx).to(self._device)
+            out[sel] = self.encode_ids_packed(input_ids.index_select(0, sel), lengths[idx])
+        return out
+
+    @torch.no_grad()
     def encode_ids_bucketed(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, lengths, n_buckets: int = 8) -> torch.Tensor:
         """Same result as encode_ids, without paying for padding: sequences are sorted by length (as
         SentenceTransformer.encode does, hybrid.py:101-102) and run in `n_buckets` sub-batches, each trimmed to its own
@@ -347,17 +371,40 @@ class SpladeEncoder(_Base):
         logits = self.mlm(input_ids=input_ids, attention_mask=attention_mask).logits
         return torch.amax(torch.log1p(torch.relu(logits * attention_mask.unsqueeze(-1))), dim=1)
 
+    HEAD_TOKENS = 16384     # token rows per MLM-head pass: the [T, vocab] logits are 16384 x 32005 fp32 = 2.1 GB
+
+    @torch.no_grad()
+    def _pool_packed(self, x: torch.Tensor, cu_d: torch.Tensor, mark=None) -> torch.Tensor:
+        """MLM head + SPLADE-max pooling over packed hidden rows x [T, hidden] of the sequences cu_d [n+1] -> [n, vocab]."""
+        from . import ops
+        out = ops.segment_splade_max(self.mlm.lm_head(x), cu_d)
+        if mark: mark("splade_head_pool")
+        return out
+
+    @torch.no_grad()
+    def encode_ids_packed(self, input_ids: torch.Tensor, lengths, mark=None) -> torch.Tensor:
+        """Already tokenised sequences [n, Lmax] (+ HOST token counts) -> SPLADE vectors [n, vocab] fp32, padding-free; sub-batches of
+        at most HEAD_TOKENS token rows."""
+        fwd = self._packed_forward(getattr(self.mlm, self.mlm.base_model_prefix))
+        if fwd is None:
+            raise RuntimeError("SpladeEncoder.encode_ids_packed needs the padding-free forward (GPU, 64-wide heads)")
+        out = torch.empty((input_ids.shape[0], self.dim), dtype=torch.float32, device=self._device)
+        for idx in _id_batches(lengths, self.HEAD_TOKENS):
+            sel = torch.from_numpy(idx).to(self._device)
+            x, cu_d = fwd.hidden(input_ids.index_select(0, sel), lengths[idx], mark)
+            out[sel] = self._pool_packed(x, cu_d, mark)
+        return out
+
     @torch.no_grad()
     def encode(self, sentences, batch_size: int = 64, query_mode: bool = True, **_) -> torch.Tensor:
         out = torch.empty((len(sentences), self.dim), dtype=torch.float32, device=self._device)
         max_len = self.max_query_length if query_mode else self.max_doc_length
         fwd = self._packed_forward(getattr(self.mlm, self.mlm.base_model_prefix))
         if fwd is not None:
-            from . import ops
-            self.packed_tokens = min(self.packed_tokens, 16384)     # the [T, vocab] logits: 16384 x 32005 fp32 = 2.1 GB
+            self.packed_tokens = min(self.packed_tokens, self.HEAD_TOKENS)
             for idx, ids, lens in _token_batches(self, sentences, max_len, batch_size):
                 x, cu_d = fwd.hidden(ids.to(self._device, non_blocking=True), lens)
-                out[torch.tensor(idx, device=self._device)] = ops.segment_splade_max(self.mlm.lm_head(x), cu_d)
+                out[torch.tensor(idx, device=self._device)] = self._pool_packed(x, cu_d)
             return out
         for idx, ids, mask in self._batches(sentences, batch_size, max_len):
             out[torch.tensor(idx, device=self._device)] = self.encode_ids(ids, mask).float()
@@ -426,6 +473,41 @@ class ColbertEncoder(_Base):
                 att = torch.ones_like(ids) if self.attend_to_mask_tokens else mask.to(self._device)
                 out[s0: s0 + len(part)] = self._tokens(ids, att).half()
         return out
+
+    @torch.no_grad()
+    def encode_query_ids(self, ids: torch.Tensor, mark=None) -> torch.Tensor:
+        """Already tokenised queries [Q, query_maxlen] (mask-token padded, all attended) -> [Q, query_maxlen, dim] fp16."""
+        import numpy as np
+        from . import ops
+        fwd = self._packed_forward(self.backbone)
+        if fwd is None:
+            raise RuntimeError("ColbertEncoder.encode_query_ids needs the padding-free forward (GPU, 64-wide heads)")
+        Q, Lq = ids.shape
+        x, _ = fwd.hidden(ids, np.full(Q, Lq), mark)
+        out = ops.normalize_rows(self.linear(x)).view(Q, Lq, self.dim).half()
+        if mark: mark("colbert_project")
+        return out
+
+    @torch.no_grad()
+    def encode_doc_ids(self, input_ids: torch.Tensor, lengths):
+        """Already tokenised documents [n, Lmax] (+ HOST token counts) -> (Dtok [sumL, dim] fp16 packed in input order, Doff [n+1] int64);
+        no punctuation skiplist on this path (ids only: synthetic corpora)."""
+        import numpy as np
+        from . import ops
+        fwd = self._packed_forward(self.backbone)
+        if fwd is None:
+            raise RuntimeError("ColbertEncoder.encode_doc_ids needs the padding-free forward (GPU, 64-wide heads)")
+        lengths = np.minimum(np.asarray(lengths, dtype=np.int64), input_ids.shape[1])
+        off = np.zeros(len(lengths) + 1, dtype=np.int64)
+        np.cumsum(lengths, out=off[1:])
+        tok = torch.empty((int(off[-1]), self.dim), dtype=torch.float16, device=self._device)
+        for idx in _id_batches(lengths, self.packed_tokens):
+            sel = torch.from_numpy(idx).to(self._device)
+            x, _ = fwd.hidden(input_ids.index_select(0, sel), lengths[idx])
+            v = ops.normalize_rows(self.linear(x)).half()
+            rows = np.concatenate([np.arange(off[i], off[i + 1]) for i in idx]) if len(idx) else np.zeros(0, dtype=np.int64)
+            tok[torch.from_numpy(rows).to(self._device)] = v
+        return tok, torch.from_numpy(off).to(self._device)
 
     @torch.no_grad()
     def encode_docs(self, docs: list[str], batch_size: int = 64):

@@ -198,14 +198,15 @@ def sort_max_n(dtype=torch.float32) -> int:
 
 def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, row_len: torch.Tensor | None = None,
                    want_order=True, want_keys=True, want_rank=False, init_rank: torch.Tensor | None = None,
-                   stats_out: tuple[torch.Tensor, torch.Tensor] | None = None):
+                   stats_out: torch.Tensor | None = None, stats_len: torch.Tensor | None = None):
     """Stable descending row sort (Python sorted(reverse=True): bm25.py:104, hybrid.py:306).
     Incoming sequence: identity (default), `init_order` (column at each sequence position) or `init_rank`
     (sequence position of each column: a rank plane; read coalesced, the fast form).
     Returns (order|None, sorted_keys|None, rank|None); order/sorted_keys entries beyond row_len are -1 / -inf,
     rank entries of elements outside the sequence are -1.
-    stats_out = (mean, std): two fp32 tensors of `rows` entries that receive each row's mean and unbiased standard deviation
-    (of the float32 values) as a by-product of the sort -- identity sequence only."""
+    stats_out: a contiguous fp32 tensor [4, rows] that receives mean | unbiased std | min | max of each list's float32 values as a
+    by-product of the sort (identity / init_order sequences, rows that fit one workgroup); stats_len [rows] int32 restricts the
+    statistics to the first stats_len[row] entries of the sorted list (a ranking cut to its top-k; fp32 keys only)."""
     _dev(keys, None, "sort_rows_desc(keys)")
     if keys.dtype not in (torch.float32, torch.float64):
         raise TypeError("keys must be float32 or float64")
@@ -241,6 +242,7 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
     wsb = int(lib.fz_sort_workspace_bytes(bits, rows, n))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
     if init_rank is not None:
+        _need(stats_out is None and stats_len is None, "sort_rows_desc: no statistics by-product for a placed sequence")
         _dev(init_rank, torch.int32, "init_rank")
         _need(tuple(init_rank.shape) == (rows, n), f"init_rank: expected shape {(rows, n)}, got {tuple(init_rank.shape)}")
         if _ld(init_rank) != ld and rows > 1:
@@ -250,15 +252,15 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
         check(lib.fz_sort_rows_desc_placed(_ptr(keys), bits, _ptr(init_rank), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk),
                                            _ptr(rank), _ptr(ws), wsb, _stream(keys)), "fz_sort_rows_desc_placed")
     else:
-        mean = std = None
         if stats_out is not None:
-            mean, std = stats_out
-            _need(init_order is None, "sort_rows_desc(stats_out): identity sequence only")
-            for x in (mean, std):
-                _dev(x, torch.float32, "sort_rows_desc(stats_out)")
-                _need(x.numel() == rows and x.is_contiguous(), f"sort_rows_desc(stats_out): need contiguous tensors of {rows} entries")
+            _dev(stats_out, torch.float32, "sort_rows_desc(stats_out)")
+            _need(tuple(stats_out.shape) == (4, rows) and stats_out.is_contiguous(), f"sort_rows_desc(stats_out): need a contiguous [4, {rows}] tensor")
+        if stats_len is not None:
+            _need(stats_out is not None, "sort_rows_desc(stats_len) needs stats_out")
+            _dev(stats_len, torch.int32, "sort_rows_desc(stats_len)")
+            _need(stats_len.numel() == rows and stats_len.is_contiguous(), f"sort_rows_desc(stats_len): need {rows} contiguous lengths")
         check(lib.fz_sort_rows_desc(_ptr(keys), bits, _ptr(init_order), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk),
-                                    _ptr(rank), _ptr(mean), _ptr(std), _ptr(ws), wsb, _stream(keys)), "fz_sort_rows_desc")
+                                    _ptr(rank), _ptr(stats_out), _ptr(stats_len), _ptr(ws), wsb, _stream(keys)), "fz_sort_rows_desc")
     return order, sk, rank
 
 
@@ -322,13 +324,14 @@ def minmax_from_order(scores: torch.Tensor, order: torch.Tensor, lens: torch.Ten
 def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None, weights, norm: str,
              distr: list[torch.Tensor] | None = None, out: torch.Tensor | None = None,
              orders: list[torch.Tensor] | None = None, lens: torch.Tensor | None = None,
-             stats: tuple[torch.Tensor, torch.Tensor] | None = None,
+             stats=None,
              valid_bits: list[torch.Tensor | None] | None = None) -> torch.Tensor:
     """normalise -> weight -> sum in one HBM pass (hybrid.py:212-214,254-280,291,301-304).
     orders (+ lens [S, Q]): the systems' order planes, when they are ranked -- min-max then takes every list's minimum and
     maximum from its two ends and the fusion is one flat streaming pass (same bits as the reducing kernel).
-    stats = (a, b): the row statistics [S*Q] fp32 each (min / max, or mean / unbiased std), when the caller has them -- e.g. from
-    the sort that ranked the systems (sort_rows_desc(stats_out=...)): the fusion is then one flat streaming pass.
+    stats: the row statistics (min / max, or mean / unbiased std), when the caller has them -- the fusion is then one flat streaming
+    pass.  Either (a, b) = two contiguous [S*Q] fp32 tensors, or a list of S pairs (a_s, b_s) of [Q] fp32 tensors, one per system:
+    each ranked system keeps the statistics its ranking sort produced (sort_rows_desc(stats_out=...)), nothing is concatenated.
     valid_bits[s] (optional): the validity of system s as a bitmap (rank_to_bitmap), read instead of its rank plane."""
     for p in planes:
         _dev(p, torch.float32, "fuse_nsf(planes)")
@@ -369,6 +372,16 @@ def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None
         dptr = _ptr_array(distr)
         P = (C.c_int32 * S)(*[int(d.numel()) for d in distr])
     lib = _lib.lib()
+    if stats is not None and norm in ("min-max", "z-score") and Q > 0 and N > 0 and isinstance(stats, list):
+        _need(len(stats) == S, f"fuse_nsf(stats): {S} planes but {len(stats)} statistics pairs")
+        for pr in stats:
+            for x in pr:
+                _dev(x, torch.float32, "fuse_nsf(stats)")
+                _need(x.numel() == Q and x.is_contiguous(), f"fuse_nsf(stats): per-system statistics must be contiguous tensors of {Q} entries")
+        check(lib.fz_fuse_nsf_pstats_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm],
+                                         dptr, P, _ptr_array([a_ for a_, _ in stats]), _ptr_array([b_ for _, b_ in stats]), vb, ldb, _ptr(fused),
+                                         _stream(planes[0])), "fz_fuse_nsf_pstats_f32")
+        return fused
     if stats is not None and norm in ("min-max", "z-score") and Q > 0 and N > 0:
         sa, sb = stats
         for x in (sa, sb):
@@ -430,6 +443,16 @@ def rank_to_bitmap(rank: torch.Tensor) -> torch.Tensor:
     bits = torch.zeros((max(Q, 1), ldb), dtype=torch.int32, device=rank.device)[:Q]
     check(_lib.lib().fz_rank_to_bitmap(_ptr(rank), Q, N, _ld(rank), _ptr(bits), ldb, _stream(rank)), "fz_rank_to_bitmap")
     return bits
+
+
+def zero_unlisted_(plane: torch.Tensor, rank: torch.Tensor) -> torch.Tensor:
+    """plane[q, j] = 0 where rank[q, j] < 0, in place: a system adds nothing for a document it does not list (hybrid.py:301-304)."""
+    _dev(plane, torch.float32, "zero_unlisted_(plane)"); _dev(rank, torch.int32, "zero_unlisted_(rank)")
+    _same_shape([plane, rank], "zero_unlisted_")
+    Q, N = plane.shape
+    _need(Q <= 1 or _ld(plane) == _ld(rank), "zero_unlisted_: plane and rank must share the row stride")
+    check(_lib.lib().fz_zero_unlisted_f32(_ptr(plane), _ptr(rank), Q, N, _ld(plane), _stream(plane)), "fz_zero_unlisted_f32")
+    return plane
 
 
 def fuse_none(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None, weights) -> torch.Tensor:

@@ -27,7 +27,29 @@ class RankedSystem:
     scores64: torch.Tensor | None = None   # [Q, N] float64 plane when the raw scores are not float32 values (BM25's Python
                                            # floats, host lists): the 'none' passthrough keeps them unrounded (hybrid.py:280)
     score_sorted: bool = False    # every list is in descending order of its float32 scores (rankers: yes; host lists: checked)
-    zstats: tuple | None = None   # (mean [Q], unbiased std [Q]) fp32 of the FULL rows, a by-product of the ranking sort (z-score)
+    stats4: torch.Tensor | None = None   # [4, Q] fp32: mean | unbiased std | min | max of every list's float32 scores (over the LISTED
+                                         # documents), a by-product of the ranking sort; min-max / z-score fusion reads it in place
+
+    @property
+    def zstats(self):
+        """(mean [Q], unbiased std [Q]) when the ranking sort produced them, else None."""
+        return None if self.stats4 is None else (self.stats4[0], self.stats4[1])
+
+    def stats(self, norm: str):
+        """(a, b) = (min, max) for 'min-max', (mean, unbiased std) for 'z-score': [Q] fp32 each, over the listed documents of every
+        query (hybrid.py:254-262).  From the ranking sort when it produced them; otherwise computed ONCE per system -- the two ends of
+        a score-sorted list, or one reduction (fz_row_stats_f32) -- and kept: a system's statistics do not depend on the fusion weights,
+        so Aggregator.fuse, the float64 fusion of the tuning grid and Aggregator.tune all normalise with the same bits."""
+        if self.stats4 is not None:
+            return (self.stats4[2], self.stats4[3]) if norm == "min-max" else (self.stats4[0], self.stats4[1])
+        key = "stats_" + norm
+        if self.meta.get(key) is None:
+            from . import ops
+            if norm == "min-max" and self.score_sorted:
+                self.meta[key] = ops.minmax_from_order(self.scores, self.order, self.lens)
+            else:
+                self.meta[key] = ops.row_stats(self.scores, None if self.full else self.rank, norm)
+        return self.meta[key]
 
     def valid_bits(self) -> torch.Tensor | None:
         """Validity of a partial system as a bitmap (1 bit per document instead of the 4-byte rank), built once and kept."""

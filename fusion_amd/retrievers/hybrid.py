@@ -54,19 +54,19 @@ def _device():
 def _rank_scores(scores: torch.Tensor, ids: np.ndarray, return_topk: int | None) -> RankedSystem:
     """Full ranking of a [Q, N] score plane: what util.semantic_search(top_k=N) + sorted() produce (hybrid.py:103)."""
     Q, N = scores.shape
-    zstats = None
-    if N <= ops.sort_max_n(scores.dtype):   # single-workgroup rows: the sort has the row in registers, mean / std come for free
-        zstats = (torch.empty(Q, dtype=torch.float32, device=scores.device), torch.empty(Q, dtype=torch.float32, device=scores.device))
-    order, sk, rank = ops.sort_rows_desc(scores, want_rank=True, stats_out=zstats)
     k = N if return_topk is None else min(return_topk, N)
     lens = torch.full((Q,), k, dtype=torch.int32, device=scores.device)
     full = k == N
-    if not full:  # lists truncated to top-k: docs beyond rank k are absent from the list
-        rank = torch.where(rank < k, rank, torch.full_like(rank, -1))
-        order = order.clone()
+    # single-workgroup rows: the sort has the row in registers, so the list's mean / std / min / max -- over its k listed documents --
+    # come for free (a truncated float64 ranking takes one reduction later instead: RankedSystem.stats)
+    stats4 = None
+    if N <= ops.sort_max_n(scores.dtype) and Q > 0 and (full or scores.dtype == torch.float32):
+        stats4 = torch.empty((4, Q), dtype=torch.float32, device=scores.device)
+    order, sk, rank = ops.sort_rows_desc(scores, want_rank=True, stats_out=stats4, stats_len=None if full or stats4 is None else lens)
+    if not full:  # lists truncated to top-k: docs beyond rank k are absent from the list (in place: the planes keep their padded rows)
+        rank.masked_fill_(rank >= k, -1)
         order[:, k:] = -1
-    return RankedSystem(scores=scores, order=order, rank=rank, lens=lens, ids=ids, sorted_scores=sk, full=full, score_sorted=True,
-                        zstats=zstats if full else None)   # a truncated list's statistics are over its k entries only
+    return RankedSystem(scores=scores, order=order, rank=rank, lens=lens, ids=ids, sorted_scores=sk, full=full, score_sorted=True, stats4=stats4)
 
 
 class Ranker:
@@ -86,9 +86,10 @@ class Ranker:
         rs = retriever.search_device(queries, ids=ids)
         if return_topk is not None and return_topk < rs.N:
             k = return_topk
-            rs.rank = torch.where(rs.rank < k, rs.rank, torch.full_like(rs.rank, -1))
-            rs.order = rs.order.clone(); rs.order[:, k:] = -1
+            rs.rank.masked_fill_(rs.rank >= k, -1)          # in place: the planes keep their padded, 16-byte aligned rows
+            rs.order[:, k:] = -1
             rs.lens = torch.full_like(rs.lens, k); rs.full = False
+            rs.stats4 = None   # the sort's statistics covered all N documents; the cut list's are taken over its k entries (RankedSystem.stats)
         return rs if as_device else rs.to_lists()
 
     @staticmethod
@@ -169,6 +170,17 @@ class Ranker:
 class Aggregator:
     """Normalise + fuse ranked lists (hybrid.py:166-307)."""
 
+    # NumPy scalar promotion of `np.float32 score * w` (hybrid.py:291).  False (default): NumPy >= 2 -- a Python-float weight is a weak
+    # scalar, product and running sum stay float32; only np.float64 weights (the tuning grid, hybrid.py:405-409) give float64.  That is
+    # the arithmetic of the reference run under this image's NumPy 2.2, on whose outputs tests/golden is pinned.  True: NumPy 1.x value-
+    # based promotion, the reference's own pinned environment (torch 2.1.2 / pandas 2.1.4 era): EVERY nsf product and sum is float64.
+    # Scores differ by ~1e-8 relative; near-tied documents can swap.  Also switched on by FUSION_AMD_NUMPY1_PROMOTION=1.
+    NUMPY1_PROMOTION = os.environ.get("FUSION_AMD_NUMPY1_PROMOTION", "0") == "1"
+
+    @classmethod
+    def _wide(cls, w) -> bool:
+        return cls.NUMPY1_PROMOTION or ops.is_wide_weight(w)
+
     @classmethod
     def fuse(cls, ranked_lists: dict, method: str, normalization: str = None, linear_weights: dict[str, float] = None,
              percentile_distributions: dict[str, np.ndarray] = None, return_topk: int = 1000, *, as_device: bool = False):
@@ -202,30 +214,17 @@ class Aggregator:
             if percentile_distributions is None:            # the reference calls .get() on it for every system (hybrid.py:213)
                 raise AttributeError("'NoneType' object has no attribute 'get'")
             w = [linear_weights[n] for n in names]          # KeyError when a system has no weight (hybrid.py:214)
-            wide = [ops.is_wide_weight(x) for x in w]       # np.float64 weights (the tuning grid): NumPy promotes to float64
+            wide = [cls._wide(x) for x in w]                # np.float64 weights (the tuning grid): NumPy promotes to float64
             if normalization in ("min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent"):
                 distr = None
                 if normalization in ("percentile-rank", "normal-curve-equivalent"):
                     distr = [cls._table(percentile_distributions.get(n), dev) for n in names]
+                st = [s.stats(normalization) for s in S] if normalization in ("min-max", "z-score") else None   # kept per system
                 if any(wide):   # transform every system in float32 (weight 1: fl32(t * 1) == t), then weight + sum as NumPy does
-                    T = [ops.fuse_nsf([s.scores], None if s.full else [s.rank], [1.0], normalization, None if distr is None else [distr[i]]) for i, s in enumerate(S)]
+                    T = cls._normalised_planes(S, normalization, distr, st)
                     fused = ops.fuse_wsum(T, ranks, w, narrow=[not x for x in wide])
-                elif normalization == "z-score" and all_full and all(s.zstats is not None for s in S):
-                    # ranked systems bring their row statistics along (by-product of the ranking sort): one flat pass
-                    fused = ops.fuse_nsf([s.scores for s in S], None, w, normalization,
-                                         stats=(torch.cat([s.zstats[0] for s in S]), torch.cat([s.zstats[1] for s in S])))
-                elif normalization == "z-score" and all(s.zstats is not None for s in S if s.full):
-                    # some lists are partial: their statistics (over the listed documents only) take one small reduction each, the
-                    # full systems bring theirs, and the fusion is the same flat pass with the validity read as bitmaps
-                    st = [s.zstats if s.full else ops.row_stats(s.scores, s.rank, "z-score") for s in S]
-                    fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization,
-                                         stats=(torch.cat([a for a, _ in st]), torch.cat([b for _, b in st])), valid_bits=vbits)
-                elif normalization == "min-max" and all(s.score_sorted for s in S):
-                    # score-sorted lists: min / max are the two ends of every list, no row reduction
-                    fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, orders=[s.order for s in S],
-                                         lens=torch.stack([s.lens for s in S]).contiguous(), valid_bits=vbits)
-                else:           # the statistics are taken over the VALUES, whatever the list order (hybrid.py:255-262)
-                    fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, distr, valid_bits=vbits)
+                else:           # one flat pass: statistics in hand, validity of the partial lists as bitmaps
+                    fused = ops.fuse_nsf([s.scores for s in S], ranks, w, normalization, distr, stats=st, valid_bits=vbits)
             else:                                           # 'none' / unknown string: raw Python floats, float64 (hybrid.py:280)
                 fused = ops.fuse_wsum([s.scores if s.scores64 is None else s.scores64 for s in S], ranks, w)
         else:                                               # unknown method: raw scores are summed (hybrid.py:203-218)
@@ -256,7 +255,7 @@ class Aggregator:
         S = [systems[n] for n in names]
         # NumPy promotion (hybrid.py:291,304): the reference's grid (np.arange, :405-409) holds np.float64 weights -> float64
         # products and sums; a grid of Python floats fuses in float32.  A grid that mixes the two kinds goes the generic way.
-        kinds = {ops.is_wide_weight(x) for w in weight_combinations for x in w.values()}
+        kinds = {cls._wide(x) for w in weight_combinations for x in w.values()}
         if (normalization not in ("min-max", "z-score", "arctan", "percentile-rank", "normal-curve-equivalent") or len(S) > 4
                 or len(kinds) > 1):
             return cls._tune_by_fusing(systems, normalization, weight_combinations, labels, percentile_distributions)
@@ -264,16 +263,11 @@ class Aggregator:
         Q, N = S[0].Q, S[0].N
         dev = S[0].scores.device
         all_full = all(s.full for s in S)
-        T = []
-        for n, s in zip(names, S):
-            distr = None
-            if normalization in ("percentile-rank", "normal-curve-equivalent"):
-                distr = [cls._table(percentile_distributions.get(n), dev)]
-            t = ops.fuse_nsf([s.scores], None if s.full else [s.rank], [1.0], normalization, distr)   # fl32(t*1) + 0 = t, exactly
-            if not s.full:
-                t = torch.where(s.rank >= 0, t, torch.zeros_like(t))   # a system adds nothing for docs it does not list
-                t = ops.as_plane(t)
-            T.append(t)
+        distr = None
+        if normalization in ("percentile-rank", "normal-curve-equivalent"):
+            distr = [cls._table(percentile_distributions.get(n), dev) for n in names]
+        st = [s.stats(normalization) for s in S] if normalization in ("min-max", "z-score") else None
+        T = cls._normalised_planes(S, normalization, distr, st, zero_unlisted=True)   # the very planes fuse_device's float64 path sums
         if all_full:
             pos = S[0].rank
         else:
@@ -320,6 +314,20 @@ class Aggregator:
             ranks[:, :, g0:g0 + G] = blk[:, :, : ranks.shape[2] - g0]
         list_len = (pos_host >= 0).sum(1) if pos_host is not None else np.zeros(Q, dtype=np.int64)
         return metrics_from_gold_ranks(ranks, n_gold, list_len)
+
+    @staticmethod
+    def _normalised_planes(S, normalization, distr, st, zero_unlisted=False):
+        """Every system's transformed scores as its own float32 plane (fusion kernel with weight 1: fl32(t * 1) + 0 == t), with the SAME
+        per-system statistics the one-pass fusion uses.  zero_unlisted: 0 instead of -inf where a system does not list a document (what
+        the sweep kernel multiplies by the weights; a system adds nothing for such a document, hybrid.py:301-304)."""
+        T = []
+        for i, s in enumerate(S):
+            t = ops.fuse_nsf([s.scores], None if s.full else [s.rank], [1.0], normalization, None if distr is None else [distr[i]],
+                             stats=None if st is None else [st[i]], valid_bits=None if s.full else [s.valid_bits()])
+            if zero_unlisted and not s.full:
+                ops.zero_unlisted_(t, ops.harmonise([t, s.rank])[1])
+            T.append(t)
+        return T
 
     @classmethod
     def _tune_by_fusing(cls, systems, normalization, weight_combinations, labels, percentile_distributions):

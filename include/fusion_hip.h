@@ -95,18 +95,23 @@ int fz_maxsim_f16(const void* Qtok, const void* Dtok, const int64_t* Doff, int64
  *   rank[row][payload]  = r  (inverse permutation; other entries untouched: pre-fill with -1)
  * Any n.  Rows of up to fz_sort_max_n() (fp32 keys) / fz_sort_max_n_f64() (fp64 keys) elements live in the registers of one
  * workgroup (the fast path: LLeQA's 27,942 articles fit both); longer rows are chunk-sorted and ranked across chunks
- * (exact and stable as well, O(n * chunks * log n); row_mean / row_std are not produced there). */
+ * (exact and stable as well, O(n * chunks * log n); row_stats are not produced there). */
 int fz_sort_max_n(void);
 int fz_sort_max_n_f64(void);
 /* workspace: fz_sort_workspace_bytes(key_bits, rows, n) bytes of device memory (0 for fp32 rows that fit one workgroup).
  * fp64 keys are sorted by their high word (4 radix passes) and repaired in place where equal high words hide a low-word
  * inversion; a row with such a run longer than 17 keys is flagged in the workspace and redone by a generic 8-pass launch. */
 size_t fz_sort_workspace_bytes(int key_bits, int rows, int n);
-/* row_mean / row_std (both or neither, [rows] fp32, nullable): the mean and the UNBIASED standard deviation of each row's
- * values as float32 (fp64 keys rounded first) -- torch.mean / torch.std of hybrid.py:261-262, a by-product of having the
- * row in registers: with them z-score fusion of ranked systems is one flat pass (fz_fuse_nsf_stats_f32). */
+/* row_stats (nullable, [4][rows] fp32): mean | UNBIASED standard deviation | min | max of each list's values as float32 (fp64 keys
+ * rounded first) -- torch.mean / torch.std / torch.min / torch.max of hybrid.py:254-262, a by-product of having the row in
+ * registers (min and max of a sorted list are its two ends; a NaN sorts first and makes both NaN): with them min-max and z-score
+ * fusion of ranked systems is one flat pass that reduces nothing (fz_fuse_nsf_pstats_f32 takes row_stats + k*rows directly).  An
+ * empty list gives NaN, NaN, 0, 0.
+ * stats_len (nullable, [rows] int32, needs row_stats; fp32 keys only, FZ_ERR_UNSUPPORTED otherwise): the statistics cover only the
+ * first stats_len[row] entries of the SORTED list -- a ranking cut to its top-k (PLAID-style short ColBERT lists, hybrid.py:137;
+ * return_topk) normalises over the listed documents only. */
 int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order, const int32_t* row_len, int rows, int n,
-                      int ld, int32_t* order, void* sorted_keys, int32_t* rank, float* row_mean, float* row_std,
+                      int ld, int32_t* order, void* sorted_keys, int32_t* rank, float* row_stats, const int32_t* stats_len,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same sort, incoming sequence given the other way round: init_rank[row][j] = position of column j in the incoming
@@ -132,7 +137,8 @@ int fz_row_stats_f32(const float* scores, const int32_t* rank, int rows, int N, 
                      float* stat_b, void* stream);
 /* fused[q][j] = sum_s fl32( t_s(score_s[q][j]) * fl32(w_s) ), fp32, unfused, in system order
  * (NumPy-2 semantics of hybrid.py:291,304), t_s = the normalisation with that row's statistics;
- * docs absent from every system: -inf.  One pass over HBM: each plane is read once.
+ * docs absent from every system: -inf (so with S = 1 the output is -inf, NOT 0, wherever the system does not list the document:
+ * fz_zero_unlisted_f32 turns such a plane into the input fz_gold_ranks_* expects).  One pass over HBM: each plane is read once.
  * planes_h / ranks_h / distr_h: HOST arrays of S device pointers (ranks_h nullable, entries
  * nullable = all docs present; distr_h needed only for PERCENTILE/NCE: ascending fp32 tables of
  * P_h[s] entries, hybrid.py:272).  w_h: HOST fp64 weights (rounded to fp32 inside).
@@ -150,6 +156,15 @@ int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* const* ranks_h,
 int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
                           int ld, int norm, const float* const* distr_h, const int32_t* P_h, const float* stat_a,
                           const float* stat_b, const uint32_t* const* valid_bits_h, int ldb, float* fused, void* stream);
+/* The same flat pass with ONE statistics pointer PER SYSTEM: stat_a_h / stat_b_h are HOST arrays of S device pointers, each [Q] fp32
+ * (min | mean and max | unbiased std of that system's lists) -- e.g. straight into the row_stats block its ranking sort wrote
+ * (fz_sort_rows_desc): a fusion call then gathers, concatenates and reduces nothing. */
+int fz_fuse_nsf_pstats_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
+                           int ld, int norm, const float* const* distr_h, const int32_t* P_h, const float* const* stat_a_h,
+                           const float* const* stat_b_h, const uint32_t* const* valid_bits_h, int ldb, float* fused, void* stream);
+/* plane[q][j] = 0 where rank[q][j] < 0.  A system adds nothing for a document it does not list (hybrid.py:301-304); the
+ * single-system planes of fz_fuse_nsf_f32 hold -inf there (see below), the weight sweep wants 0. */
+int fz_zero_unlisted_f32(float* plane, const int32_t* rank, int Q, int N, int ld, void* stream);
 /* min / max of RANKED lists without a reduction: a list sorted by score has its maximum first and its minimum last.
  * mn[row] = scores[row][order[row][len-1]], mx[row] = scores[row][order[row][0]], len = lens[row] (NULL = N); an empty list gives
  * 0, 0; a NaN at the head makes both NaN (torch.min / torch.max propagate it, hybrid.py:254-258).  With these,
@@ -241,7 +256,9 @@ int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* 
  * out_ranks[w][q][g] = #{docs that precede gold g in the list Aggregator.fuse(method='nsf') would return with
  * weights[w]} (fused score desc, ties by first-insertion position).  Every metric of run_evaluation is a
  * function of these ranks.  T_h: HOST array of S device planes [Q][ld] holding the NORMALISED scores
- * (fz_fuse_nsf_f32 of one system with weight 1; entries of docs the system does not list = 0); pos [Q][ld] =
+ * (fz_fuse_nsf_f32 of one system with weight 1, then -- for a system with a partial list -- fz_zero_unlisted_f32: entries of docs
+ * the system does not list MUST be 0, the kernel multiplies them by the weights like any other; fz_fuse_nsf_f32 leaves -inf
+ * there); pos [Q][ld] =
  * first-insertion position (-1 = in no list); weights [W][S] fp32; gold [Q][fz_tune_max_gold()] corpus positions
  * (-1 = padding); out_ranks must be zeroed by the caller.  S <= 4. */
 int fz_tune_max_gold(void);

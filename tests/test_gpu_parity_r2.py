@@ -311,10 +311,10 @@ def test_sort_row_stats_feed_zscore_fusion(ops, oracle, Q, N):
     a = _rank_scores(dev(p32), ids, None)
     from fusion_amd.planes import RankedSystem
     sc64 = ops.alloc_plane(Q, N, torch.float64, "cuda"); sc64.copy_(torch.from_numpy(p64))
-    zs = (torch.empty(Q, device="cuda"), torch.empty(Q, device="cuda"))
+    zs = torch.empty((4, Q), device="cuda")
     od, sk, rk = ops.sort_rows_desc(sc64, want_rank=True, stats_out=zs)
     b = RankedSystem(scores=ops.f64_to_f32(sc64), order=od, rank=rk, lens=torch.full((Q,), N, dtype=torch.int32, device="cuda"), ids=ids,
-                     sorted_scores=sk, full=True, scores64=sc64, score_sorted=True, zstats=zs)
+                     sorted_scores=sk, full=True, scores64=sc64, score_sorted=True, stats4=zs)
     for rs, plane_np in ((a, p32), (b, p64.astype(np.float32))):
         e_mean, e_std = oracle.row_stats(plane_np, None, "z-score")
         g_mean, g_std = rs.zstats[0].cpu().numpy(), rs.zstats[1].cpu().numpy()
@@ -324,6 +324,8 @@ def test_sort_row_stats_feed_zscore_fusion(ops, oracle, Q, N):
             assert np.array_equal(g_std == 0, e_std == 0)
         else:
             assert np.all(np.isnan(g_std)) and np.all(np.isnan(e_std))             # torch.std of one element
+        np.testing.assert_array_equal(rs.stats4[2].cpu().numpy(), plane_np.min(axis=1))     # min | max: the two ends of the sorted list
+        np.testing.assert_array_equal(rs.stats4[3].cpu().numpy(), plane_np.max(axis=1))
     w = {"x": 0.4, "y": 0.6}
     fused = Aggregator.fuse_device({"x": a, "y": b}, "nsf", "z-score", w, {})
     exp = oracle.fuse_nsf([p32, p64.astype(np.float32)], None, [0.4, 0.6], "z-score")

@@ -1,0 +1,203 @@
+"""Round-3 GPU parity: statistics by-products of the ranking sort (mean | std | min | max, also over the listed prefix of a truncated
+ranking), the per-system-statistics flat fusion, fz_zero_unlisted_f32 and the weight sweep driven through the C ABI with a partial
+list, the NumPy-1 promotion switch.  Everything goes through the C ABI; the oracle is the checker."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from helpers import load_lists
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from fusion_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def plane_of(ops, a):
+    p = ops.alloc_plane(a.shape[0], a.shape[1], torch.from_numpy(a[:0]).dtype, "cuda")
+    p.copy_(torch.from_numpy(a))
+    return p
+
+
+# ---- the sort's statistics by-product --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Q,N,k", [(3, 1, 1), (4, 2, 1), (5, 300, 37), (7, 5000, 4999), (3, 27942, 16765), (3, 35840, 1000)])
+def test_sort_prefix_statistics_equal_row_stats_over_the_listed_documents(ops, oracle, Q, N, k):
+    """fz_sort_rows_desc(row_stats, stats_len): mean | unbiased std | min | max over the first k entries of the sorted list == the
+    oracle's statistics over exactly those documents (hybrid.py:254-262 on a list cut to its top-k)."""
+    rng = np.random.default_rng(N + k)
+    x = rng.normal(1.0, 2.0, (Q, N)).astype(np.float32)
+    if N >= 300:
+        x[1, :] = -0.75                                              # constant list: std 0, min == max
+        x[2, : N // 2] = x[2, N // 2: 2 * (N // 2)]                  # ties across the cut
+    lens = torch.full((Q,), k, dtype=torch.int32, device="cuda")
+    st = torch.full((4, Q), 7.0, device="cuda")
+    od, sk, rk = ops.sort_rows_desc(plane_of(ops, x), want_rank=True, stats_out=st, stats_len=lens)
+    rk = rk.cpu().numpy()
+    listed = np.where(rk < k, rk, -1).astype(np.int32)
+    e_mean, e_std = oracle.row_stats(x, listed, "z-score")
+    e_min, e_max = oracle.row_stats(x, listed, "min-max")
+    g = st.cpu().numpy()
+    np.testing.assert_array_equal(g[2], e_min)
+    np.testing.assert_array_equal(g[3], e_max)
+    if k > 1:
+        assert np.max(np.abs(g[0] - e_mean) / np.maximum(1.0, np.abs(e_mean))) <= 2e-7
+        assert np.max(np.abs(g[1] - e_std) / np.maximum(1e-30, np.abs(e_std)), initial=0.0, where=e_std > 0) <= 2e-7
+        assert np.array_equal(g[1] == 0, e_std == 0)
+    else:
+        assert np.all(np.isnan(g[1])) and np.allclose(g[0], e_mean, rtol=2e-7)   # torch.std of one element
+    # the whole-list form of the same call
+    st2 = torch.empty((4, Q), device="cuda")
+    ops.sort_rows_desc(plane_of(ops, x), stats_out=st2)
+    np.testing.assert_array_equal(st2[2].cpu().numpy(), x.min(axis=1))
+    np.testing.assert_array_equal(st2[3].cpu().numpy(), x.max(axis=1))
+
+
+def test_sort_statistics_propagate_nan_and_reject_what_they_cannot_do(ops):
+    from fusion_amd._lib import FusionHipError
+    x = np.arange(12, dtype=np.float32).reshape(2, 6)
+    x[1, 3] = np.nan
+    st = torch.empty((4, 2), device="cuda")
+    ops.sort_rows_desc(plane_of(ops, x), stats_out=st)
+    g = st.cpu().numpy()
+    assert g[2, 0] == 0.0 and g[3, 0] == 5.0 and np.isnan(g[:, 1]).all()         # torch.min / max / mean / std propagate a NaN
+    with pytest.raises(FusionHipError):                                          # prefix statistics exist for fp32 keys only
+        ops.sort_rows_desc(plane_of(ops, x.astype(np.float64)), stats_out=st, stats_len=torch.full((2,), 3, dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("norm", ["min-max", "z-score"])
+def test_truncated_ranking_fuses_like_the_oracle_on_the_cut_lists(ops, oracle, norm):
+    """Ranker-style systems, one of them cut to its top-k (statistics over the listed prefix from the ranking sort), fused in one flat
+    pass with per-system statistics == the oracle's fusion of the same planes with the cut expressed as a rank plane."""
+    from fusion_amd.retrievers.hybrid import Aggregator, _rank_scores
+    rng = np.random.default_rng(5)
+    Q, N, k = 6, 27942, 16765
+    a = rng.normal(0.0, 1.0, (Q, N)).astype(np.float32)
+    b = (20.0 + 4.0 * rng.normal(0.0, 1.0, (Q, N))).astype(np.float32)
+    ids = np.arange(N)
+    A, B = _rank_scores(plane_of(ops, a), ids, None), _rank_scores(plane_of(ops, b), ids, k)
+    assert A.stats4 is not None and B.stats4 is not None and not B.full
+    fused = Aggregator.fuse_device({"a": A, "b": B}, "nsf", norm, {"a": 0.3, "b": 0.7}, {})
+    rb = np.where(B.rank.cpu().numpy() >= 0, B.rank.cpu().numpy(), -1).astype(np.int32)
+    exp = oracle.fuse_nsf([a, b], [None, rb], [0.3, 0.7], norm)
+    got = np.full((Q, N), np.nan, dtype=np.float32)
+    o, s_, ln = fused.order.cpu().numpy(), fused.scores.cpu().numpy(), fused.lens.cpu().numpy()
+    assert np.all(ln == N)
+    for q in range(Q):
+        got[q, o[q]] = s_[q]
+    tol = 0.0 if norm == "min-max" else 2e-6
+    assert np.max(np.abs(got - exp)) <= tol
+    # the float64 fusion (np.float64 weights, the tuning grid's kind) normalises with the SAME statistics: identical float32 planes
+    T = Aggregator._normalised_planes([A, B], norm, None, [A.stats(norm), B.stats(norm)])
+    one = ops.fuse_nsf([A.scores, B.scores], [None, B.rank], [1.0, 0.0], norm, stats=[A.stats(norm), B.stats(norm)], valid_bits=[None, B.valid_bits()])
+    np.testing.assert_array_equal(T[0].cpu().numpy(), one.cpu().numpy())
+
+
+def test_tune_and_fuse_agree_bit_for_bit_on_ranked_systems(ops):
+    """Aggregator.tune must rank with the statistics Aggregator.fuse uses -- z-score on Ranker-made systems (statistics from
+    the ranking sort), float32 sweep (Python-float weights) against one fuse_device per weight vector: identical ranks (metrics equal up to the last ulp of the mean over queries)."""
+    from fusion_amd.retrievers.hybrid import Aggregator, _rank_scores
+    rng = np.random.default_rng(11)
+    Q, N = 9, 3000
+    base = rng.normal(0, 1, (Q, N))
+    planes = [(base + 0.3 * rng.normal(0, 1, (Q, N))).astype(np.float32) for _ in range(3)]
+    planes[1] = np.round(planes[1], 1)                                            # many near and exact ties
+    ids = np.arange(N) + 100
+    systems = {n: _rank_scores(plane_of(ops, p), ids, None if n != "c" else 1800) for n, p in zip("abc", planes)}
+    labels = [[int(ids[j]) for j in rng.choice(N, size=3, replace=False)] for _ in range(Q)]
+    grid = [dict(a=x, b=y, c=round(1.0 - x - y, 2)) for x in (0.0, 0.25, 0.5) for y in (0.0, 0.25, 0.5)]
+    for norm in ("z-score", "min-max"):
+        got = Aggregator.tune(systems, norm, grid, labels, {})
+        exp = Aggregator._tune_by_fusing(systems, norm, grid, labels, {})
+        for g, e in zip(got, exp):
+            assert list(g) == list(e) and all(abs(float(g[m]) - float(e[m])) <= 1e-14 for m in e), (norm, g, e)   # any swapped pair moves a metric by >= 1e-5
+
+
+# ---- the sweep through the C ABI alone, with a partial list (the -inf / 0 contract) ---------------------------------------------
+def test_c_abi_sweep_recipe_with_a_partial_list(ops, oracle):
+    """INTEGRATION.md section 5 as a non-Python host would run it: fz_fuse_nsf_f32 (S = 1, weight 1) leaves -inf where the system does not
+    list a document; fz_zero_unlisted_f32 makes it the 0 the sweep multiplies; fz_gold_ranks_f64w then gives the ranks of the oracle's
+    fused lists."""
+    from fusion_amd import _lib
+    L = _lib.lib()
+    z = np.load(os.path.join(GOLDEN, "tune_seed21_S3_Q4_N257_colbert_first.npz"), allow_pickle=False)
+    systems, lists, Q = load_lists(z)
+    labels = [[int(x) for x in str(s).split(",")] for s in z["labels"]]
+    _, ids, planes, ranks, orders, lens, _ = oracle.lists_to_planes(lists)
+    S, N = len(systems), planes[0].shape[1]
+    assert any((r < 0).any() for r in ranks)                                    # the fixture holds a partial ColBERT list
+    ld = ops.round_up(N, 64)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    dplanes, dranks, dorders, T = [], [], [], []
+    for s in range(S):
+        dplanes.append(plane_of(ops, planes[s])); dranks.append(plane_of(ops, ranks[s])); dorders.append(plane_of(ops, orders[s]))
+        t = ops.alloc_plane(Q, N, torch.float32, "cuda")
+        one = (C.c_void_p * 1)(dplanes[s].data_ptr()); oner = (C.c_void_p * 1)(dranks[s].data_ptr()); w1 = (C.c_double * 1)(1.0)
+        assert L.fz_fuse_nsf_f32(one, oner, w1, 1, Q, N, ld, 1, None, None, None, 0, P(t), st) == 0       # min-max
+        if (ranks[s] < 0).any():
+            assert torch.isinf(t[dranks[s] < 0]).all()                        # the documented -inf
+        assert L.fz_zero_unlisted_f32(P(t), P(dranks[s]), Q, N, ld, st) == 0
+        assert (t[dranks[s] < 0] == 0).all()
+        T.append(t)
+    dlens = dev(lens.astype(np.int32))
+    ins = torch.full((Q, ld), -1, dtype=torch.int32, device="cuda"); U = torch.zeros(Q, dtype=torch.int32, device="cuda")
+    assert L.fz_insertion_order((C.c_void_p * S)(*[o.data_ptr() for o in dorders]), P(dlens), S, Q, N, ld, P(ins), P(U), None, 0, st) == 0
+    pos = torch.full((Q, ld), -1, dtype=torch.int32, device="cuda")
+    Uh, insh = U.cpu().numpy(), ins.cpu().numpy()
+    for q in range(Q):
+        pos[q, torch.from_numpy(insh[q, : Uh[q]].astype(np.int64)).cuda()] = torch.arange(int(Uh[q]), dtype=torch.int32, device="cuda")
+    W = z["weights"][::9]
+    G = L.fz_tune_max_gold()
+    id2pos = {int(c): j for j, c in enumerate(ids)}
+    gold = np.full((Q, G), -1, dtype=np.int32)
+    for q, gl in enumerate(labels):
+        u = [id2pos.get(g, -1) for g in dict.fromkeys(gl)]
+        gold[q, : len(u)] = u
+    out = torch.zeros((len(W), Q, G), dtype=torch.int32, device="cuda")
+    assert L.fz_gold_ranks_f64w((C.c_void_p * S)(*[t.data_ptr() for t in T]), P(pos), P(dev(W.astype(np.float64))), P(dev(gold)), S, len(W), Q, N, ld,
+                                P(out), st) == 0
+    out = out.cpu().numpy()
+    for wi, wv in enumerate(W):
+        fl = oracle.fuse_lists(lists, "nsf", "min-max", {s: np.float64(x) for s, x in zip(systems, wv)}, {})
+        for q in range(Q):
+            rank_of = {x["corpus_id"]: r for r, x in enumerate(fl[q])}
+            for g in range(G):
+                if gold[q, g] >= 0 and ids[gold[q, g]] in rank_of:
+                    assert out[wi, q, g] == rank_of[ids[gold[q, g]]], (wi, q, g)
+
+
+# ---- NumPy-1 promotion switch -----------------------------------------------------------------------------------------------
+def test_numpy1_promotion_switch_fuses_python_float_weights_in_float64(oracle):
+    """The reference pins NumPy 1.x, where np.float32 * python_float is float64: with Aggregator.NUMPY1_PROMOTION the equal-weights fusion
+    (weights 1/S, Python floats, hybrid.py:448) takes the float64 path -- the very path the np.float64 grid takes, pinned by the tune
+    fixtures -- instead of NumPy 2's float32."""
+    from fusion_amd.retrievers.hybrid import Aggregator
+    z = np.load(os.path.join(GOLDEN, "tune_seed21_S3_Q4_N257_colbert_first.npz"), allow_pickle=False)
+    systems, lists, Q = load_lists(z)
+    w_py = {s: 1 / len(systems) for s in systems}
+    w_np = {s: np.float64(1 / len(systems)) for s in systems}
+    for norm in ("min-max", "z-score", "percentile-rank"):
+        distr = {s: z[f"distr_{s}"] for s in systems}
+        narrow = Aggregator.fuse(lists, "nsf", norm, w_py, distr)
+        assert isinstance(narrow[0][0]["score"], np.float32)
+        Aggregator.NUMPY1_PROMOTION = True
+        try:
+            legacy = Aggregator.fuse(lists, "nsf", norm, w_py, distr)
+        finally:
+            Aggregator.NUMPY1_PROMOTION = False
+        wide = Aggregator.fuse(lists, "nsf", norm, w_np, distr)
+        assert legacy == wide and isinstance(legacy[0][0]["score"], float)
+        exp = oracle.fuse_lists(lists, "nsf", norm, w_np, distr)
+        assert [[x["corpus_id"] for x in l] for l in legacy] == [[x["corpus_id"] for x in l] for l in exp]
