@@ -98,6 +98,11 @@ class Events:
         return tot, cnt
 
 
+def log(msg):
+    """Progress on stderr (stdout carries the one JSON line): a long run must not look hung."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def timeit_ms(f, n=10, warm=2):
     """Average duration of f() over n back-to-back calls, HIP events on the current stream."""
     for _ in range(warm):
@@ -376,6 +381,7 @@ def measure_configs(dev, N=27942):
         out.append(dict(config="2: DPR full ranking", shape=dict(Q=Q, N=N), **roof("sort_rows_kernel (f32 keys)", ms, Q * N * 12, "hbm")))
     del Dn, Qn
 
+    log("configs: DPR done")
     # -- config 3: ColBERT MaxSim, Q = 195, L_q = 64, L_d ~ clip(N(300,120),16,512), dim 128, fp16 unit-norm tokens ---
     rng = np.random.default_rng(0)
     lens = np.clip(rng.normal(300, 120, N), 16, 512).astype(np.int64)
@@ -391,6 +397,7 @@ def measure_configs(dev, N=27942):
                         **roof("maxsim_kernel", ms, 2.0 * Q * 64 * sumL * 128, "mfma_f16")))
     del Dtok, Qtok
 
+    log("configs: MaxSim done")
     # -- config 3b: SPLADE-shaped dense scoring, V = 32,005 (the reference scores SPLADE vectors densely, hybrid.py:101-103)
     V, Vp, Q = 32005, 32008, 1024
     Ds = torch.zeros((N, Vp), device=dev)
@@ -404,6 +411,7 @@ def measure_configs(dev, N=27942):
     out.append(dict(config="3b: SPLADE dense cos-sim scoring", shape=dict(Q=Q, N=N, V=V), **roof("dot_scores_kernel", ms, 2.0 * Q * N * V, "mfma_f32")))
     del Ds, Qs
 
+    log("configs: SPLADE scoring done")
     # -- config 4: 4-way nsf fusion, colbert plane 40 % invalid; min-max / z-score / percentile-rank; Q in {1024, 195} --
     names = ["bm25", "dpr", "splade", "colbert"]
     for Q in (1024, 195):
@@ -445,6 +453,7 @@ def measure_configs(dev, N=27942):
                                 ms=dt * 1e3, ms_per_weight_vector=dt * 1e3 / len(grid), note="wall clock incl. host-side metrics"))
         del planes, systems, ranks, fused
 
+    log("configs: fusion + sweep done")
     # -- config 5 at one GPU: one 1/8 shard of mMARCO (what each GPU does at G = 8), no collective ---------------------
     from fusion_amd.distributed import ShardedDenseIndex
     Nl, Q, k = 8841823 // 8, 1024, 1000
@@ -473,6 +482,11 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
     from fusion_amd.planes import RankedSystem
     from fusion_amd.retrievers.hybrid import Aggregator, _rank_scores
     out = []
+    # recorded hipBLASLt solutions stay in use (fusion_amd/tuned/gemm_gfx950.csv), but shapes that are not in the file are NOT tuned on
+    # first use here: the SPLADE vocabulary head and the corpus encode's sub-batches bring dozens of new GEMM shapes, minutes of tuning
+    tuning_was_on = torch.cuda.tunable.is_enabled() and torch.cuda.tunable.tuning_is_enabled()
+    if tuning_was_on:
+        torch.cuda.tunable.tuning_enable(False)
     g = torch.Generator(device=dev).manual_seed(31)
     rng = np.random.default_rng(31)
     ids_np = np.arange(N)
@@ -499,6 +513,7 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
               idf=torch.from_numpy(np.log10((N - df + 0.5) / (df + 0.5))).to(dev), doc_len=torch.from_numpy(blens.astype(np.int32)).to(dev), avgdl=float(blens.mean()))
     bm["doc_norm"] = ops.bm25_doc_norms(bm["doc_len"], bm["avgdl"], 2.5, 0.2)
 
+    log("pipeline4: corpus side built")
     for Q in queries:
         qids, _, qlen = synth_query_tokens(rng, Q, V, cfg.pad_token_id)
         qids_d = torch.from_numpy(qids).to(dev)
@@ -534,7 +549,8 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
             return fused
         for _ in range(2):
             step(lambda n: None)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            log(f"pipeline4: warm-up step done (Q={Q})")
         reps = 3
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -566,6 +582,7 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
     runs = {"dpr": lambda: enc["dpr"].encode_ids_corpus(ids, lens), "splade": lambda: enc["splade"].encode_ids_packed(ids, lens),
             "colbert": lambda: enc["colbert"].encode_doc_ids(ids, lens)}
     for k in ("dpr", "splade", "colbert"):
+        log(f"corpus encode: {k}, {T} tokens")
         runs[k]()                                                                # first pass: TunableOp settles the sub-batch shapes
         torch.cuda.synchronize(); t0 = time.perf_counter()
         runs[k]()
@@ -575,6 +592,8 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
                         shape=dict(docs=n, tokens=T, mean_len=float(lens.mean())), ms=dt * 1e3, tokens_per_s=T / dt, docs_per_s=n / dt,
                         full_corpus_s_estimate=dt * 8, flops=fl, bound="mfma", achieved=fl / dt / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                         frac=fl / dt / (MFMA_F32_PEAK_TF * 1e12)))
+    if tuning_was_on:
+        torch.cuda.tunable.tuning_enable(True)
     return out
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -876,8 +895,10 @@ def main():
         if world == 1 and not args.no_configs and (Q, N) == (1024, 27942):
             del st, out
             torch.cuda.empty_cache()
+            log("headline + cpu baseline done; configs_measured ...")
             res["configs_measured"] = measure_configs(dev, N)
             torch.cuda.empty_cache()
+            log("configs 2-5 done; config-4 pipeline ...")
             res["configs_measured"] += measure_pipeline4(dev, N)
         res["north_star_targets"] = north_star_targets(res)
         print(json.dumps(res))
