@@ -24,14 +24,12 @@
 // A fragments refilled in place under the last MFMA chain (slower: 0.39), waves 4-7 staggered by s_sleep 4..24.
 #include <hip/hip_fp16.h>
 
-#include <type_traits>
-
 #include "common.h"
 
 namespace fz {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MS_DIM = 128;
 constexpr int MS_WAVES = 8;
@@ -56,40 +54,29 @@ struct MaxSimArgs {
     int64_t sumL;
 };
 
-// One workgroup = 8 waves x (up to) 8 column blocks of 16 query tokens; see the header.
 __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char tile[MS_RING][MS_TILE_BYTES];   // ring of 8 KiB tiles
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep what derives from it in SGPRs
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int qg = idx % a.QG;
     const int dr = (idx / a.QG) * 8 + x;
     if (dr >= a.DR) return;
 
-    // ---- this wave's queries.  A group covers 8 waves x qpw queries; the queries of a group that is not full (the last one) are
-    //      spread evenly over the waves (at Q = 195, Lq = 64: three waves with one query each instead of two waves with 2 + 1), so
-    //      that the group's tile stream is not paced by waves that carry a full load next to idle ones ----
-    const int qpw = MS_BLOCKS_PER_WAVE / a.QB;                 // queries a wave can hold (Lq = 32 / 64 / 128: 4 / 2 / 1)
-    const int q_first = qg * MS_WAVES * qpw;
-    const int nq_group = min(a.Q - q_first, MS_WAVES * qpw);
-    const int per_wave = (nq_group + MS_WAVES - 1) / MS_WAVES;  // <= qpw
-    const int q0 = q_first + w * per_wave;                      // this wave's first query
-    const int nq = max(0, min(per_wave, q_first + nq_group - q0));   // ... and how many it has (wave-uniform)
-    const int ncb = nq * a.QB * 2;                              // live column blocks (16 query tokens each) of this wave: 0 .. 8
-    const bool wave_has_queries = nq > 0;
-
-    // ---- B fragments: up to 8 column blocks x 4 k-steps of 32 dims, resident for the whole kernel (128 VGPRs) ----
-    // lane l holds B[k = 8 (l >> 4) + j][col = l & 15] = Qtok[token l & 15 of the block][dim 32 ks + 8 (l >> 4) + j]
-    constexpr int NCB = 2 * MS_BLOCKS_PER_WAVE;
-    f16x8 bq[NCB][4];
+    // ---- B fragments: this wave's 4 query blocks, all of K, resident for the whole kernel ----
+    // lane l holds B[k = 8*(l>>5) + j][col = l&31] = Qtok[token l&31 of the block][dim 16*ks + 8*(l>>5) + j]
+    const int blk0 = (qg * MS_WAVES + w) * MS_BLOCKS_PER_WAVE;   // global query-block index of this wave's first block
+    const int nblk_total = a.Q * a.QB;
+    const bool wave_has_queries = blk0 < nblk_total;   // wave-uniform
+    f16x8 bq[MS_BLOCKS_PER_WAVE][8];
 #pragma unroll
-    for (int b = 0; b < NCB; ++b) {
-        const bool okb = b < ncb;
-        const size_t tok = okb ? ((size_t)q0 * a.QB * 2 + b) * 16 + (lane & 15) : 0;   // a query's tokens are consecutive in [Q * Lq]
-        const _Float16* src = a.Qtok + tok * MS_DIM + 8 * (lane >> 4);
+    for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) {
+        const int blk = blk0 + b;
+        const bool okb = blk < nblk_total;
+        const size_t tok = okb ? (size_t)blk * 32 + (lane & 31) : 0;   // blocks are consecutive 32-token slices of [Q*Lq]
+        const _Float16* src = a.Qtok + tok * MS_DIM + 8 * (lane >> 5);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            f16x8 v = *reinterpret_cast<const f16x8*>(src + 32 * ks);
+        for (int ks = 0; ks < 8; ++ks) {
+            f16x8 v = *reinterpret_cast<const f16x8*>(src + 16 * ks);
             if (!okb) v = (f16x8)(_Float16)0;
             bq[b][ks] = v;
         }
@@ -97,6 +84,24 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
 
     const int d_begin = dr * a.docs_per_wg;
     const int d_end = (d_begin + a.docs_per_wg < a.N) ? d_begin + a.docs_per_wg : a.N;
+
+    // ---- tile walk: tiles are aligned to document starts -------------------------------
+    // vals[b]: per-block sums already reduced over the wave; lane 0 writes one score per query.
+    // An empty document scores 0 for every query (sum of an empty max := 0, as in the oracle).
+    auto write_scores = [&](int d, const float* vals) {
+        if (lane == 0) {
+            const int qpw = MS_BLOCKS_PER_WAVE / a.QB;   // queries per wave
+            for (int qi = 0; qi < qpw; ++qi) {
+                const int q = blk0 / a.QB + qi;
+                if (q < a.Q) {
+                    float s = 0.f;
+                    for (int b = 0; b < a.QB; ++b) s += vals[qi * a.QB + b];
+                    a.scores[(size_t)q * a.lds + d] = s;
+                }
+            }
+        }
+    };
+    const float zeros[MS_BLOCKS_PER_WAVE] = {0.f, 0.f, 0.f, 0.f};
 
     // ---- tile table of this document range, built ONCE into LDS ------------------------------------------
     // (walking Doff[] with scalar global loads per tile put ~0.5 us of load latency on the critical path of every
@@ -126,14 +131,12 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
     }
     __syncthreads();
     const int ntiles = s_ntiles;
-    // An empty document scores 0 for every query (sum of an empty max := 0, as in the oracle).
-    if (lane < nq)
-        for (int i = 0; i < MS_DOCS_PER_WG; ++i)
-            if (s_len[i] == 0) a.scores[(size_t)(q0 + lane) * a.lds + d_begin + i] = 0.f;
+    for (int i = 0; i < MS_DOCS_PER_WG; ++i)
+        if (s_len[i] == 0) write_scores(d_begin + i, zeros);   // empty documents
     if (ntiles == 0) return;   // block-uniform
 
     // ---- tile ring, filled by LDS-DMA.  Tile k lives in slot k % MS_RING; a tile is 32 rows x 256 B, row r's 16-B chunks
-    // XOR-swizzled by r & 15 (conflict-free ds_read_b128 of 16 rows x one chunk).  global_load_lds writes lane l of a wave to
+    // XOR-swizzled by r & 15 (conflict-free ds_read_b128 of 32 rows).  global_load_lds writes lane l of a wave to
     // (wave-uniform LDS base) + 16 l, so the swizzle is applied on the GLOBAL side: wave w fills rows 4w .. 4w+3, lane l sits
     // at chunk position l & 15 of row 4w + (l >> 4) and fetches the chunk whose swizzled position that is.  No staging
     // registers, no ds_write, and the loads of a whole group are in flight for a whole group of MFMA work:
@@ -160,17 +163,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
     __syncthreads();
     const uint32_t tile_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&tile[0][0]);
 
-    // A-fragment addresses: lane l reads rows (l & 15) and 16 + (l & 15), dims 32 ks + 8 (l >> 4) .. + 7 = chunk 4 ks + (l >> 4) of the
-    // row at its swizzled position (16 lanes = 16 rows x one chunk each = 16 distinct positions: conflict-free).  The four per-lane
-    // byte offsets are computed ONCE; the tile slot inside the group's half of the ring and the row block go into the instruction's
-    // immediate offset, and the ring half is toggled once per group: the tile loop spends no vector instruction on addressing.
-    uint32_t aaddr[4];
+    float run[MS_BLOCKS_PER_WAVE];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) aaddr[ks] = tile_lds + (lane & 15) * 256 + (((4 * ks + (lane >> 4)) ^ (lane & 15)) << 4);
-
-    float run[NCB];
-#pragma unroll
-    for (int b = 0; b < NCB; ++b) run[b] = -INFINITY;
+    for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) run[b] = -INFINITY;
 
     for (int k0 = 0; k0 < ntiles; k0 += MS_GROUP) {
       int metas[MS_GROUP];
@@ -185,124 +180,86 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
         for (int i = 0; i < MS_GROUP; ++i)
             if (k0 + MS_GROUP + i < ntiles) dma_tile(toks[i], ((k0 + MS_GROUP) & (MS_RING - 1)) + i);
       }
-      // one tile of the group; GI (compile time) = its slot in the group's half of the ring
-      auto tile_body = [&](auto GI) __attribute__((always_inline)) {
-        constexpr int gi = decltype(GI)::value;
+#pragma unroll
+      for (int gi = 0; gi < MS_GROUP; ++gi) {
+        const int k = k0 + gi;
+        if (k >= ntiles) break;
         const int meta = metas[gi];
         const int rows_valid = (meta >> 8) & 0xff;
         const bool last_tile_of_doc = (meta >> 16) & 1;
-        // a wave without queries (the tail of the last query group) has nothing to multiply: it only keeps feeding the ring and
-        // meeting the barriers
-        if (!wave_has_queries) return;
+        // a wave whose four query blocks all lie past the last query (the tail of the last query group: at Q = 195, six of its
+        // eight waves) has nothing to multiply: it only keeps feeding the ring and meeting the barriers
+        if (!wave_has_queries) continue;
 
-        f16x8 af[2][4];
+        // ---- A fragments from LDS: lane l -> row l&31, k = 16*ks + 8*(l>>5) .. +7 ------------
+        f16x8 af[8];
+        {
+            // the lane id is re-derived here (two v_mbcnt) rather than kept: at 256 registers one long-lived value more is a
+            // spill, and a spill's reload is a vmcnt(0) -- which would also wait for the DMAs in flight
+            uint32_t l;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            const uint32_t a_h = l >> 5, a_x = l & 15;
+            const uint32_t base = tile_lds + (l & 31) * 256 + (uint32_t)(((k0 & (MS_RING - 1)) + gi) * MS_TILE_BYTES);
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[rb][ks]) : "v"(aaddr[ks]), "n"(gi * MS_TILE_BYTES + rb * 4096));
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]));
-
-        // ---- 8 column blocks x (2 row blocks x 4 k-steps of v_mfma_f32_16x16x32_f16): the two row blocks' chains interleave (no
-        //      MFMA waits for the one before it); the 8-way max of a column block is 4 v_max3 ------------------------------------
-        auto chain = [&](int cb, f32x4& lo, f32x4& hi) __attribute__((always_inline)) {
-            lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][0], bq[cb][0], (f32x4)0.f, 0, 0, 0);
-            hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1][0], bq[cb][0], (f32x4)0.f, 0, 0, 0);
-#pragma unroll
-            for (int ks = 1; ks < 4; ++ks) {
-                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][ks], bq[cb][ks], lo, 0, 0, 0);
-                hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1][ks], bq[cb][ks], hi, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) {
+                const uint32_t addr = base + (((2 * ks + a_h) ^ a_x) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(af[ks]) : "v"(addr));
             }
-        };
-        auto fold = [&](f32x4 lo, f32x4 hi, int cb) __attribute__((always_inline)) {
-            if (rows_valid < 32) {   // wave-uniform: the last tile of a document.  Row of register r: 4 (lane >> 4) + r (+ 16)
-                const int r0 = 4 * (lane >> 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (r0 + r >= rows_valid) lo[r] = -INFINITY;
-                    if (16 + r0 + r >= rows_valid) hi[r] = -INFINITY;
-                }
-            }
-            float m = run[cb];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, lo[r]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, hi[r]);
-            run[cb] = m;
-        };
-        if (ncb == NCB) {   // wave-uniform: the full load (every wave of every full query group)
-            f32x4 aL, aH, bL, bH;
-            chain(0, aL, aH);
-            chain(1, bL, bH);
-            fold(aL, aH, 0);
-            chain(2, aL, aH);
-            fold(bL, bH, 1);
-            chain(3, bL, bH);
-            fold(aL, aH, 2);
-            chain(4, aL, aH);
-            fold(bL, bH, 3);
-            chain(5, bL, bH);
-            fold(aL, aH, 4);
-            chain(6, aL, aH);
-            fold(bL, bH, 5);
-            chain(7, bL, bH);
-            fold(aL, aH, 6);
-            fold(bL, bH, 7);
-        } else {            // a partly loaded wave of the last query group: its live column blocks only (pairs: ncb is even)
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb += 2) {
-                if (cb < ncb) {
-                    f32x4 aL, aH, bL, bH;
-                    chain(cb, aL, aH);
-                    chain(cb + 1, bL, bH);
-                    fold(aL, aH, cb);
-                    fold(bL, bH, cb + 1);
-                }
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]));
         }
-        // ---- end of a document: finish the max over the four 16-lane rows and sum over the query tokens, transposing as we go:
-        //      P(A, B) (permlane32 swap + max) leaves [A's rows (0|2), (1|3), B's (0|2), (1|3)], S(X, Y) (permlane16 swap + max) of two
-        //      such registers leaves one finished column block per 16-lane row -- 8 registers -> 2, then one 16-lane sum per register
-        //      and two more swap steps add the rows up.  28 VALU instead of 64 for the block-by-block form.
+        // ---- 4 query blocks x 8 k-steps, two accumulators in ping-pong: the 16-way max of block b runs on the
+        //      VALU while the MFMA chain of block b+1 occupies the matrix pipe ---------------------------------
+        auto chain = [&](int b) -> f32x16 {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bq[b][ks], acc, 0, 0, 0);
+            return acc;
+        };
+        auto fold = [&](f32x16 acc, int b) {
+            if (rows_valid < 32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {   // row of register r = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row >= rows_valid) acc[r] = -INFINITY;
+                }
+            }
+            float m = run[b];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[r]);
+            run[b] = m;
+        };
+        {
+            f32x16 accA = chain(0);
+            f32x16 accB = chain(1);
+            fold(accA, 0);
+            accA = chain(2);
+            fold(accB, 1);
+            accB = chain(3);
+            fold(accA, 2);
+            fold(accB, 3);
+        }
+        // ---- end of a document: finish max over the two lane halves, sum over query tokens
         if (last_tile_of_doc) {
-            auto P = [&](float A, float B) __attribute__((always_inline)) -> float { swap32(A, B); return fmaxf(A, B); };
-            auto S = [&](float X, float Y) __attribute__((always_inline)) -> float { swap16(X, Y); return fmaxf(X, Y); };
-            float t0 = row16_sum(S(P(run[0], run[2]), P(run[1], run[3])));     // rows: column blocks 0, 1, 2, 3 (sums over their 16 tokens)
-            float t1 = row16_sum(S(P(run[4], run[6]), P(run[5], run[7])));     // rows: column blocks 4, 5, 6, 7
+            float sums[MS_BLOCKS_PER_WAVE];
 #pragma unroll
-            for (int b = 0; b < NCB; ++b) run[b] = -INFINITY;
-            float o0 = t0, o1 = t1;
-            swap16(t0, o0); swap16(t1, o1);
-            t0 += o0; t1 += o1;                                                  // rows (0,1): blocks 0+1 | rows (2,3): blocks 2+3
-            const int d = d_begin + (meta & 0xff);
-            if (a.QB == 1) {        // Lq = 32: a query is two column blocks -- lanes 0 and 32 hold two queries per register
-                if ((lane & 31) == 0) {
-                    const int h = lane >> 5;
-                    if (h < nq) a.scores[(size_t)(q0 + h) * a.lds + d] = t0;
-                    if (2 + h < nq) a.scores[(size_t)(q0 + 2 + h) * a.lds + d] = t1;
-                }
-            } else {
-                o0 = t0; o1 = t1;
-                swap32(t0, o0); swap32(t1, o1);
-                t0 += o0; t1 += o1;                                              // all four rows: (b0 + b1) + (b2 + b3)
-                if (lane == 0) {
-                    if (a.QB == 2) {                                             // Lq = 64: one query per register
-                        a.scores[(size_t)q0 * a.lds + d] = t0;
-                        if (nq > 1) a.scores[(size_t)(q0 + 1) * a.lds + d] = t1;
-                    } else a.scores[(size_t)q0 * a.lds + d] = t0 + t1;           // Lq = 128: one query per wave
-                }
+            for (int b = 0; b < MS_BLOCKS_PER_WAVE; ++b) {
+                // all on the VALU (DPP + permlane swaps): the ds_bpermute form put six LDS round trips per block on the
+                // critical path of every document
+                float m = run[b], other = m;
+                swap32(m, other);                 // m = [lo, lo], other = [hi, hi]
+                m = fmaxf(m, other);              // both halves now hold the column max
+                m = row16_sum(m);                 // per 16 columns
+                other = m;
+                swap16(m, other);                 // rows (0,1) and (2,3) paired
+                sums[b] = m + other;              // sum over the 32 columns, in every lane
+                run[b] = -INFINITY;
             }
+            write_scores(d_begin + (meta & 0xff), sums);
         }
-      };
-      if (k0 + 0 < ntiles) { tile_body(std::integral_constant<int, 0>{});
-      if (k0 + 1 < ntiles) { tile_body(std::integral_constant<int, 1>{});
-      if (k0 + 2 < ntiles) { tile_body(std::integral_constant<int, 2>{});
-      if (k0 + 3 < ntiles) { tile_body(std::integral_constant<int, 3>{}); } } } }
-      // the next group lives in the other half of the ring
-      const uint32_t flip = (k0 & MS_GROUP) ? (uint32_t)(-MS_GROUP * MS_TILE_BYTES) : (uint32_t)(MS_GROUP * MS_TILE_BYTES);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) aaddr[ks] += flip;
+      }
       __syncthreads();   // group boundary: the next group's tiles have landed (vmcnt(0)) and everyone has left this group's
     }
 }

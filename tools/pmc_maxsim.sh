@@ -2,7 +2,8 @@
 # PMC passes over the MaxSim kernel at the LLeQA test shape (Q = 195, N = 27,942, sum L = 8.3 M).  Run on the GPU box from the repo root.
 set -e
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/pmc_maxsim
+TAG=${1:-}
+OUT=$PWD/gpurun_out/pmc_maxsim$TAG   # FUSION_AMD_LIB=<other build> tools/pmc_maxsim.sh _tag profiles that build instead
 rm -rf $OUT; mkdir -p $OUT
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES"
 P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM"
@@ -12,4 +13,4 @@ for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
   (cd /tmp && rocprofv3 --pmc $P --kernel-trace -d $OUT/pass$i -o p --output-format csv -- python3 $OLDPWD/tools/run_maxsim.py > $OUT/pass$i.log 2>&1) || { tail -5 $OUT/pass$i.log; }
 done
-python3 tools/pmc_summary.py gpurun_out/pmc_maxsim.json $OUT/pass1 $OUT/pass2 $OUT/pass3 --match maxsim
+python3 tools/pmc_summary.py gpurun_out/pmc_maxsim$TAG.json $OUT/pass1 $OUT/pass2 $OUT/pass3 --match maxsim
