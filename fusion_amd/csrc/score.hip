@@ -74,13 +74,20 @@ struct GemmArgs {
     int32_t* overflow;
     int cap;
     int64_t id_base;           // document id of corpus row 0
+    // SPLADE form (fz_splade_head_max_f32): A = packed hidden rows [T][d], B = vocabulary projection [V][d]; no logits plane
+    const float* bias;         // [N] decoder bias
+    const int32_t* cu_rows;    // [nseq + 1] first packed row of every sequence
+    int nseq;
+    float* pool; int ldp;      // [nseq][ldp] zero-initialised: pool[s][v] = max over the sequence's rows of log1p(relu(logit))
 };
+
+enum { EPI_STORE = 0, EPI_FILTER = 1, EPI_SPLADE = 2 };
 
 // One workgroup's share of the tiles: ids first, first + step, ... below `end`, all of one shape (128 x BN).  The k-tiles of
 // ALL those tiles form one stream through the software pipeline: the operand loads of a tile's first two k-tiles are issued
 // during the last two k-tiles of the tile before it, and its score stores drain under the next tile's MFMAs -- a workgroup
 // pays the pipeline fill once per launch, not once per tile.
-template <int BN, bool RAGGED /* d is not a whole number of k-tile pairs */, bool FILTER>
+template <int BN, bool RAGGED /* d is not a whole number of k-tile pairs */, int EPI>
 __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int first, const int end, const int step) {
     constexpr int NI = BN / 64;          // 32x32 MFMA tiles per wave along N (wave tile = 64 x BN/2)
     constexpr int BROWS = BN / 32;       // staging float4 per thread for the corpus tile
@@ -247,7 +254,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
         ktile(KT - 1, 1, 0, r1, r0, EDGE);
 
         // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-        if constexpr (FILTER) {
+        if constexpr (EPI == EPI_FILTER) {
             // Threshold filter in the epilogue: a score enters its query's candidate list iff it beats tau[q] (or is NaN) -- the
             // score plane is never written.  One accumulator register of the wave = 32 documents x 2 queries (lane halves), a "step".
             // Pass A counts per step and half by ballot and parks the counts in lane `step` of one register; then the lanes reserve
@@ -323,6 +330,51 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
             if (ccol + BN <= g.N && crow + BM <= g.Q) passes(std::false_type{});   // workgroup-uniform
             else passes(std::true_type{});
             if (over) atomicExch(g.overflow, 1);
+        } else if constexpr (EPI == EPI_SPLADE) {
+            // SPLADE-max pooling as the epilogue of the vocabulary projection (splade/splade.py:88-99: amax over the tokens of
+            // log1p(relu(logits))): the [T, V] logits are never written.  log1p o relu is monotone, so the max over a sequence's rows is
+            // taken on the raw dot products, the bias added and the transform applied ONCE per (sequence, column), and the result --
+            // a non-negative float, whose bit pattern orders like an unsigned integer -- goes into the zero-initialised pool[s][v] by
+            // atomicMax.  A wave's 64 rows are cut at the sequence boundaries (cu_rows: packed rows, sequences back to back); per piece:
+            // an in-lane max over the accumulator registers whose row lies in the piece, one permlane32 swap to join the lane halves,
+            // and one atomic per column from lanes 0-31.
+            const int R0 = crow + wr * 64;
+            const int Rend = min(R0 + 64, g.Q);
+            if (R0 < Rend) {      // wave-uniform
+                int lo_s = 0, hi_s = g.nseq;             // first sequence that ends after R0 (scalar binary search)
+                while (lo_s < hi_s) { const int mid = (lo_s + hi_s) >> 1; if (g.cu_rows[mid + 1] > R0) hi_s = mid; else lo_s = mid + 1; }
+                const int h4 = 4 * (lane >> 5);
+                for (int sq = lo_s; sq < g.nseq; ++sq) {
+                    const int a0 = g.cu_rows[sq], a1 = g.cu_rows[sq + 1];
+                    if (a0 >= Rend) break;
+                    const int lo = max(a0, R0) - R0, hi = min(a1, Rend) - R0;     // piece [lo, hi) of the wave's rows
+                    if (lo >= hi) continue;                                           // (an empty sequence)
+                    float m[NI];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) m[ni] = -INFINITY;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + h4;
+                            const bool in = row >= lo && row < hi;
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) m[ni] = fmaxf(m[ni], in ? acc[mi][ni][r] : -INFINITY);
+                        }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        float other = m[ni];
+                        swap32(m[ni], other);                 // m = [lo half, lo half], other = [hi half, hi half]
+                        const float best = fmaxf(m[ni], other);
+                        const int c = ccol + wc * (BN / 2) + ni * 32 + (lane & 31);
+                        if (lane < 32 && c < g.N) {
+                            const float logit = best + g.bias[c];
+                            const float v = log1pf(fmaxf(logit, 0.0f));
+                            if (v > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(g.pool + (size_t)sq * g.ldp + c), __float_as_uint(v));
+                        }
+                    }
+                }
+            }
         } else {
         const bool whole = crow + BM <= g.Q && ccol + BN <= g.N;
 #pragma unroll
@@ -352,13 +404,13 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
 // are consecutive ids on one XCD, run at about the same time, and the corpus tile is fetched from HBM once.  The first `g.full`
 // ids are 128x128 tiles; the rest is the LAST partial round cut into 128x64 halves, so that the tail occupies every CU for half a
 // tile time instead of half the CUs for a whole one (1792 equal tiles on 512 slots otherwise cost 4 rounds for 3.5 of work).
-template <bool RAGGED, bool FILTER>
+template <bool RAGGED, int EPI>
 __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    gemm_stream<128, RAGGED, FILTER>(g, lds, blockIdx.x, g.full, gridDim.x);
+    gemm_stream<128, RAGGED, EPI>(g, lds, blockIdx.x, g.full, gridDim.x);
     if ((int)blockIdx.x < g.halves) {
         __syncthreads();                     // the half tile restarts the pipeline in stage 0
-        gemm_stream<64, RAGGED, FILTER>(g, lds, g.full + blockIdx.x, g.full + blockIdx.x + 1, 1);
+        gemm_stream<64, RAGGED, EPI>(g, lds, g.full + blockIdx.x, g.full + blockIdx.x + 1, 1);
     }
 }
 
@@ -376,7 +428,7 @@ extern "C" int fz_normalize_rows_f32(const float* X, int rows, int d, int ldx, f
     return FZ_OK;
 }
 
-static int launch_gemm(GemmArgs& g, bool filter, hipStream_t st) {
+static int launch_gemm(GemmArgs& g, int epi, hipStream_t st) {
     g.QB = (g.Q + BM - 1) / BM;
     g.TN = (g.N + 127) / 128;
     const long B = 8L * g.QB * ((g.TN + 7) / 8);        // ids of whole tiles (incl. the XCD padding, which decodes to nothing)
@@ -395,17 +447,19 @@ static int launch_gemm(GemmArgs& g, bool filter, hipStream_t st) {
     constexpr size_t lds_db = 2 * (BM + 128) * LDT * sizeof(float);
     // per-lane offsets are signed 32-bit byte offsets inside one 128-row operand tile
     if (128.0 * g.lda * 4 >= 2147483648.0 || 128.0 * g.ldb * 4 >= 2147483648.0) return FZ_ERR_UNSUPPORTED;
-    static unsigned long long lds_set[4] = {0ull, 0ull, 0ull, 0ull};
+    static unsigned long long lds_set[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     const bool ragged = g.d % (2 * BK) != 0;
-#define FZ_GEMM_LAUNCH(RG, FL)                                                                                                   \
+#define FZ_GEMM_LAUNCH(RG, EP)                                                                                                   \
     {                                                                                                                            \
-        if (int rc = raise_lds_limit((const void*)dot_scores_kernel<RG, FL>, lds_db, lds_set[2 * RG + FL])) return rc;           \
-        dot_scores_kernel<RG, FL><<<(unsigned)nblk, 256, lds_db, st>>>(g);                                                       \
+        if (int rc = raise_lds_limit((const void*)dot_scores_kernel<RG, EP>, lds_db, lds_set[3 * RG + EP])) return rc;           \
+        dot_scores_kernel<RG, EP><<<(unsigned)nblk, 256, lds_db, st>>>(g);                                                       \
     }
-    if (ragged && filter) FZ_GEMM_LAUNCH(true, true)
-    else if (ragged) FZ_GEMM_LAUNCH(true, false)
-    else if (filter) FZ_GEMM_LAUNCH(false, true)
-    else FZ_GEMM_LAUNCH(false, false)
+    if (ragged && epi == EPI_FILTER) FZ_GEMM_LAUNCH(true, EPI_FILTER)
+    else if (ragged && epi == EPI_SPLADE) FZ_GEMM_LAUNCH(true, EPI_SPLADE)
+    else if (ragged) FZ_GEMM_LAUNCH(true, EPI_STORE)
+    else if (epi == EPI_FILTER) FZ_GEMM_LAUNCH(false, EPI_FILTER)
+    else if (epi == EPI_SPLADE) FZ_GEMM_LAUNCH(false, EPI_SPLADE)
+    else FZ_GEMM_LAUNCH(false, EPI_STORE)
 #undef FZ_GEMM_LAUNCH
     FZ_LAUNCH_CHECK();
     return FZ_OK;
@@ -421,7 +475,7 @@ extern "C" int fz_dot_scores_f32(const float* Qn, int ldq, const float* Dn, int 
     GemmArgs g{};
     g.A = Qn; g.lda = ldq; g.B = Dn; g.ldb = ldd; g.C = scores; g.ldc = lds;
     g.Q = Q; g.N = N; g.d = d;
-    return launch_gemm(g, false, as_stream(stream));
+    return launch_gemm(g, EPI_STORE, as_stream(stream));
 }
 
 extern "C" int fz_dot_scores_filter_f32(const float* Qn, int ldq, const float* Dn, int ldd, int Q, int N, int d, int64_t id_base,
@@ -435,5 +489,19 @@ extern "C" int fz_dot_scores_filter_f32(const float* Qn, int ldq, const float* D
     g.A = Qn; g.lda = ldq; g.B = Dn; g.ldb = ldd;
     g.Q = Q; g.N = N; g.d = d;
     g.tau = tau_padded; g.cand_s = cand_scores; g.cand_i = cand_ids; g.cand_len = cand_len; g.cap = cap; g.id_base = id_base; g.overflow = overflow;
-    return launch_gemm(g, true, as_stream(stream));
+    return launch_gemm(g, EPI_FILTER, as_stream(stream));
+}
+
+// SPLADE head: pool[s][v] = max over the rows t of sequence s of log1p(relu(<X[t], W[v]> + bias[v])), the logits never materialised.
+extern "C" int fz_splade_head_max_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const int32_t* cu_rows, int nseq, int T,
+                                      int V, int d, float* pool, int ldp, void* stream) {
+    if (T < 0 || V < 0 || nseq < 0 || d <= 0 || ldx < d || ldw < d || ldp < V) return FZ_ERR_ARG;
+    if (T == 0 || V == 0 || nseq == 0) return FZ_OK;
+    if (!X || !W || !bias || !cu_rows || !pool) return FZ_ERR_ARG;
+    if ((d % 4) || (ldx % 4) || (ldw % 4) || ((uintptr_t)X % 16) || ((uintptr_t)W % 16)) return FZ_ERR_UNSUPPORTED;
+    GemmArgs g{};
+    g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw;
+    g.Q = T; g.N = V; g.d = d;
+    g.bias = bias; g.cu_rows = cu_rows; g.nseq = nseq; g.pool = pool; g.ldp = ldp;
+    return launch_gemm(g, EPI_SPLADE, as_stream(stream));
 }

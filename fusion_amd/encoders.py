@@ -371,13 +371,31 @@ class SpladeEncoder(_Base):
         logits = self.mlm(input_ids=input_ids, attention_mask=attention_mask).logits
         return torch.amax(torch.log1p(torch.relu(logits * attention_mask.unsqueeze(-1))), dim=1)
 
-    HEAD_TOKENS = 16384     # token rows per MLM-head pass: the [T, vocab] logits are 16384 x 32005 fp32 = 2.1 GB
+    HEAD_TOKENS = 65536     # token rows per forward + head pass (the fused head writes no [T, vocab] logits: 16384 rows of them were 2.1 GB)
+    FUSED_HEAD = True       # False: decoder GEMM -> [T, vocab] logits -> fz_segment_splade_max_f32 (the reference's shape, splade.py:94)
 
     @torch.no_grad()
     def _pool_packed(self, x: torch.Tensor, cu_d: torch.Tensor, mark=None) -> torch.Tensor:
-        """MLM head + SPLADE-max pooling over packed hidden rows x [T, hidden] of the sequences cu_d [n+1] -> [n, vocab]."""
+        """MLM head + SPLADE-max pooling over packed hidden rows x [T, hidden] of the sequences cu_d [n+1] -> [n, vocab].
+        With a RoBERTa-style head (dense -> GELU -> LayerNorm -> decoder) the vocabulary projection runs as fz_splade_head_max_f32: the
+        pooling is the GEMM's epilogue and the [T, vocab] logits -- 4.2 GB per batch of 64 x 512 tokens in the reference, splade.py:94,
+        ~1 TB over the LLeQA corpus -- are never written."""
         from . import ops
-        out = ops.segment_splade_max(self.mlm.lm_head(x), cu_d)
+        head = self.mlm.lm_head
+        fused = self.FUSED_HEAD and all(hasattr(head, n) for n in ("dense", "layer_norm", "decoder")) and x.shape[0] > 0
+        if not fused:
+            out = None
+            for r0 in range(0, max(x.shape[0], 1), 16384):       # the logits plane in slices of 16384 rows (2.1 GB)
+                cu = (cu_d.clamp(r0, min(r0 + 16384, x.shape[0])) - r0).int()
+                part = ops.segment_splade_max(head(x[r0: r0 + 16384]), cu)
+                out = part if out is None else torch.maximum(out, part)
+            if mark: mark("splade_head_pool")
+            return out
+        h = torch.nn.functional.linear(x, head.dense.weight, head.dense.bias)
+        h = ops.gelu_(h) if h.numel() % 4 == 0 and h.is_contiguous() else torch.nn.functional.gelu(h)
+        h = ops.add_layernorm(h, None, head.layer_norm.weight, head.layer_norm.bias, head.layer_norm.eps)
+        bias = head.decoder.bias if head.decoder.bias is not None else torch.zeros(head.decoder.weight.shape[0], device=x.device)
+        out = ops.splade_head_max(h, head.decoder.weight, bias.contiguous(), cu_d)
         if mark: mark("splade_head_pool")
         return out
 

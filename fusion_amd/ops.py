@@ -876,6 +876,27 @@ def _segment_reduce(fn: str, x: torch.Tensor, cu_rows: torch.Tensor) -> torch.Te
     return out
 
 
+def splade_head_max(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, cu_rows: torch.Tensor) -> torch.Tensor:
+    """SPLADE vocabulary projection with the pooling as its epilogue (splade/splade.py:88-99): x [T, d] packed hidden rows, weight [V, d],
+    bias [V], cu_rows [B+1] int32 -> [B, V] fp32 = max over each sequence's rows of log1p(relu(x @ weight.T + bias)); the [T, V] logits
+    are never written (fz_splade_head_max_f32: the fp32-MFMA tile stream of dot_scores with a segment-max / atomicMax epilogue)."""
+    _dev(x, torch.float32, "splade_head_max(x)"); _dev(weight, torch.float32, "splade_head_max(weight)")
+    _dev(bias, torch.float32, "splade_head_max(bias)"); _dev(cu_rows, torch.int32, "splade_head_max(cu_rows)")
+    T, d = x.shape
+    V = weight.shape[0]
+    B = cu_rows.numel() - 1
+    _need(weight.dim() == 2 and weight.shape[1] == d and bias.numel() == V and bias.is_contiguous(), f"splade_head_max: weight [V, {d}] and bias [V] expected")
+    _need(cu_rows.is_contiguous() and B >= 0, "splade_head_max: cu_rows must hold B + 1 contiguous offsets")
+    x, weight = pad_dim(x), pad_dim(weight)
+    ldp = max(round_up(V, _PAD), _PAD)
+    pool = torch.zeros((max(B, 1), ldp), dtype=torch.float32, device=x.device)[:B, :V]     # zero = log1p(relu(.)) of an empty sequence
+    if T == 0 or B == 0:
+        return pool
+    check(_lib.lib().fz_splade_head_max_f32(_ptr(x), x.stride(0) if T > 1 else x.shape[1], _ptr(weight), weight.stride(0), _ptr(bias), _ptr(cu_rows), B, T, V,
+                                            x.shape[1], _ptr(pool), ldp, _stream(x)), "fz_splade_head_max_f32")
+    return pool
+
+
 def segment_mean(x: torch.Tensor, cu_rows: torch.Tensor) -> torch.Tensor:
     """Mean over each sequence's rows: x [T, d] fp32, cu_rows [B+1] int32 -> [B, d]."""
     return _segment_reduce("fz_segment_mean_f32", x, cu_rows)

@@ -309,6 +309,15 @@ int fz_segment_mean_f32(const float* x, int ldx, const int32_t* cu_rows, int B, 
  * rows [cu_rows[b], cu_rows[b+1]) of x)) -- the same value, log1p o relu being monotone; 0 for an empty sequence. */
 int fz_segment_splade_max_f32(const float* x, int ldx, const int32_t* cu_rows, int B, int d, float* out, int ldo, void* stream);
 
+/* The SPLADE head with the pooling as its epilogue (splade/splade.py:88-99 over the MLM decoder): pool[s][v] = max over the packed rows
+ * t in [cu_rows[s], cu_rows[s+1]) of log1p(relu(<X[t], W[v]> + bias[v])) -- the same value as fz_segment_splade_max_f32 over the decoder's
+ * logits, but the [T][V] logits (4.2 GB per 64 x 512-token batch, splade.py:94) are never written: the fp32-MFMA tile stream of
+ * fz_dot_scores_f32 with a segment-max / atomicMax epilogue.  X [T][ldx] packed hidden rows (after the head's dense + GELU + LayerNorm), W [V][ldw]
+ * the decoder weight, bias [V]; pool [nseq][ldp] MUST be zero on entry (0 = log1p(relu(x)) of every x <= 0 and of an empty sequence).
+ * d % 4 == 0, 16-byte aligned rows. */
+int fz_splade_head_max_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const int32_t* cu_rows, int nseq, int T, int V,
+                           int d, float* pool, int ldp, void* stream);
+
 /* ---- small utilities ------------------------------------------------------------------ */
 int fz_fill_i32(int32_t* p, size_t count, int32_t value, void* stream);
 int fz_f64_to_f32(const double* src, float* dst, size_t count, void* stream);

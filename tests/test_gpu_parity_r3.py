@@ -201,3 +201,72 @@ def test_numpy1_promotion_switch_fuses_python_float_weights_in_float64(oracle):
         assert legacy == wide and isinstance(legacy[0][0]["score"], float)
         exp = oracle.fuse_lists(lists, "nsf", norm, w_np, distr)
         assert [[x["corpus_id"] for x in l] for l in legacy] == [[x["corpus_id"] for x in l] for l in exp]
+
+
+# ---- SPLADE head with the pooling as the GEMM's epilogue (splade/splade.py:88-99) -----------------------------------------------------
+def test_splade_head_epilogue_matches_reference_pooling(ops):
+    """The reference's own pooled vectors (fixture from SPLADE.forward) through the fused kernel: with one-hot hidden rows the GEMM
+    reproduces the fixture's logits exactly (1 x logit + zeros), so what is checked is the epilogue -- segment cuts, lane-half join,
+    bias, log1p o relu, atomicMax -- against the reference's amax(log1p(relu(logits * mask)))."""
+    z = np.load(os.path.join(GOLDEN, "splade_pool_B5_L24_V509.npz"))
+    logits, lens = z["logits"], z["lens"]
+    rows = np.concatenate([logits[b, : lens[b]] for b in range(len(lens))])          # packed: attended tokens only  [T, V]
+    T, V = rows.shape
+    d = -(-T // 4) * 4
+    X = np.zeros((T, d), dtype=np.float32); X[np.arange(T), np.arange(T)] = 1.0
+    W = np.zeros((V, d), dtype=np.float32); W[:, :T] = rows.T
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device="cuda")
+    got = ops.splade_head_max(dev(X), dev(W), torch.zeros(V, device="cuda"), cu).cpu().numpy()
+    assert np.max(np.abs(got - z["max"])) <= 5e-7      # log1p: ocml vs torch's vectorised CPU implementation
+    assert got[1, 7] == 0.0 and np.all(got >= 0)
+    # the bias is added before the transform: shifting every logit of a column by b == giving the column the bias b
+    b = np.linspace(-1.0, 1.0, V).astype(np.float32)
+    shifted = ops.segment_splade_max(dev(rows + b[None, :]), cu).cpu().numpy()
+    got_b = ops.splade_head_max(dev(X), dev(W), dev(b), cu).cpu().numpy()
+    assert np.max(np.abs(got_b - shifted)) <= 5e-7
+
+
+@pytest.mark.parametrize("T,V,d,seed", [(700, 32005, 768, 0), (4100, 2000, 768, 1), (130, 509, 64, 2)])
+def test_splade_head_fused_equals_unfused_path(ops, T, V, d, seed):
+    """fz_splade_head_max_f32 == decoder GEMM -> [T, V] logits -> fz_segment_splade_max_f32 (the materialising path) on ragged sequences:
+    empty ones, one-token ones, sequences that cross the 64-row wave cuts and the 128-row tile cuts, a last partial tile; V = 32,005
+    takes the ragged-column tiles.  Both sides accumulate 768 fp32 products in different orders: |diff| <= 2e-6 on values of <= 3."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn((T, d), generator=g, device="cuda") * 0.5
+    W = torch.randn((V, d), generator=g, device="cuda") * 0.08
+    bias = torch.randn((V,), generator=g, device="cuda") * 0.3
+    rng = np.random.default_rng(seed)
+    cuts = np.sort(rng.choice(np.arange(1, T), size=min(T // 40 + 3, T - 1), replace=False))
+    cu_np = np.concatenate([[0, 0, 1], cuts[cuts > 1], [T, T]]).astype(np.int32)      # leading empty + one-token sequence, trailing empty
+    cu = torch.from_numpy(cu_np).cuda()
+    fused = ops.splade_head_max(x, W, bias, cu)
+    logits = torch.nn.functional.linear(x, W, bias)
+    unfused = ops.segment_splade_max(logits, cu)
+    assert fused.shape == unfused.shape == (len(cu_np) - 1, V)
+    assert float((fused - unfused).abs().max()) <= 2e-6
+    exact = torch.nn.functional.linear(x.double(), W.double(), bias.double())
+    ref = torch.stack([torch.log1p(torch.relu(exact[a:b].max(dim=0).values)) if b > a else torch.zeros(V, dtype=torch.float64, device="cuda")
+                       for a, b in zip(cu_np[:-1], cu_np[1:])])
+    assert float((fused.double() - ref).abs().max()) <= 5e-6     # 768 fp32 products per logit, logits up to ~15
+    assert float(fused[0].abs().max()) == 0.0 and float(fused[-1].abs().max()) == 0.0       # empty sequences pool to 0
+
+
+def test_splade_encoder_fused_head_equals_materialising_head():
+    """SpladeEncoder (random CamemBERT-shaped tiny model): encode_ids_packed with the fused head == with FUSED_HEAD = False == the plain HF
+    forward + amax(log1p(relu(logits * mask))) of splade.py:88-99."""
+    from fusion_amd import encoders
+    cfg = dict(encoders.TINY, hidden_size=128, num_attention_heads=2, intermediate_size=256)   # 64-wide heads: the padding-free forward
+    torch.manual_seed(3)
+    enc = encoders.SpladeEncoder(encoders._backbone(cfg, mlm=True), encoders.HashTokenizer(cfg["vocab_size"]), "cuda")
+    rng = np.random.default_rng(0)
+    n, L = 37, 40
+    lens = rng.integers(1, L + 1, n)
+    ids = rng.integers(7, 500, (n, L))
+    ids_d = torch.from_numpy(ids).cuda()
+    fused = enc.encode_ids_packed(ids_d, lens)
+    enc.FUSED_HEAD = False
+    unfused = enc.encode_ids_packed(ids_d, lens)
+    mask = torch.from_numpy((np.arange(L)[None, :] < lens[:, None]).astype(np.int64)).cuda()
+    plain = enc.encode_ids(torch.where(mask.bool(), ids_d, torch.ones_like(ids_d)), mask)
+    assert float((fused - unfused).abs().max()) <= 2e-6
+    assert float((fused - plain).abs().max()) <= 5e-6
