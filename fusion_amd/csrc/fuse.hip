@@ -940,7 +940,8 @@ struct InsArgs {
     int S, Q, N, ld;
 };
 
-__global__ __launch_bounds__(1024) void insertion_order_kernel(InsArgs a, int32_t* __restrict__ ins_order, int32_t* __restrict__ U) {
+__global__ __launch_bounds__(1024) void insertion_order_kernel(InsArgs a, int32_t* __restrict__ ins_order, int32_t* __restrict__ U,
+                                                              int32_t* __restrict__ pos /* nullable: the inverse, pre-filled with -1 */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int T = 1024, NW = T / 64;
     const int words = (a.N + 31) / 32;
@@ -976,7 +977,10 @@ __global__ __launch_bounds__(1024) void insertion_order_kernel(InsArgs a, int32_
             int woff = 0, tot = 0;
 #pragma unroll
             for (int i = 0; i < NW; ++i) { int c = wtot[i]; if (i < w) woff += c; tot += c; }
-            if (isnew) ins_order[rowoff + base + woff + below] = j;
+            if (isnew) {
+                ins_order[rowoff + base + woff + below] = j;
+                if (pos) pos[rowoff + j] = base + woff + below;
+            }
             base += tot;
         }
     }
@@ -1325,7 +1329,7 @@ extern "C" size_t fz_insertion_order_workspace_bytes(int Q, int N) {
 }
 
 extern "C" int fz_insertion_order(const int32_t* const* orders_h, const int32_t* lens, int S, int Q, int N, int ld,
-                                  int32_t* ins_order, int32_t* U, void* workspace, size_t workspace_bytes, void* stream) {
+                                  int32_t* ins_order, int32_t* U, int32_t* pos, void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
     if (!orders_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
     if (Q != 0 && (!lens || !ins_order || !U)) return FZ_ERR_ARG;   // empty tensors carry null pointers
@@ -1341,7 +1345,7 @@ extern "C" int fz_insertion_order(const int32_t* const* orders_h, const int32_t*
     if (lds > 48 * 1024) {
         FZ_HIP_TRY(hipFuncSetAttribute((const void*)insertion_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    insertion_order_kernel<<<Q, 1024, lds, as_stream(stream)>>>(a, ins_order, U);
+    insertion_order_kernel<<<Q, 1024, lds, as_stream(stream)>>>(a, ins_order, U, pos);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

@@ -17,6 +17,8 @@
 //                and read them back in striped order.
 // Passes whose digit is constant over the row are skipped.  LDS: up to 156 KiB of the CU's
 // 160 KiB, i.e. one 1024-thread workgroup per CU.
+#include <type_traits>
+
 #include "common.h"
 
 namespace fz {
@@ -1007,9 +1009,153 @@ static int launch_sort(const SortArgs& a, int kw, int prows, int n_chunk, hipStr
     return FZ_ERR_UNSUPPORTED;
 }
 
+
+// ---- top-k form of the fused-list ordering (hybrid.py:306 + main's predictions(1000), :537) -------------------------------------------
+// Aggregator.fuse sorts every fused row in full; what main() reads of it is the first 1000 entries.  For that use the row is SELECTED, not
+// sorted: one workgroup holds the row's float32 sort keys in registers, bisects the key range for a threshold that at least k and at most
+// cap keys do not exceed (one count + workgroup sum per step), and writes the documents at or above it -- the k best, every tie at the
+// k-th place and up to cap - k more -- with their fused scores and (negated) first-insertion positions.  Two small row sorts then put
+// those candidates into insertion order and, stably, into score order: the first k entries of the full sort, bit for bit.
+// float64 fused scores (rrf / bcf / 'none') are selected by their float32 rounding -- rounding is monotone, so the k-th largest rounded
+// value is the rounding of the k-th largest value and nothing of the top-k is lost; the candidates keep their float64 scores.
+struct SelectArgs {
+    const void* fused; int key_bits;   // [rows][ld] float32 (32) or float64 (64)
+    const int32_t* pos;                // nullable [rows][ld]: first-insertion position of the column, < 0 = in no list; NULL = the column itself
+    int n, ld, k, cap;
+    int32_t* cand_cols;                // [rows][cap]
+    void* cand_vals;                   // [rows][cap] same type as fused
+    float* cand_negpos;                // [rows][cap] -(float)position: descending sort = ascending insertion position
+    int32_t* cand_len;                 // [rows]
+    int32_t* overflow;                 // set when a row has more than cap candidates (the caller then sorts in full)
+};
+
+template <int T, int E, int KW>
+__global__ __launch_bounds__(T) void topk_select_kernel(SelectArgs a) {
+    constexpr int NW = T / 64;
+    __shared__ uint32_t red[2][NW];
+    const int row = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t base = (size_t)row * a.ld;
+    const float* __restrict__ vf = reinterpret_cast<const float*>(a.fused) + base;
+    const double* __restrict__ vd = reinterpret_cast<const double*>(a.fused) + base;
+    const int32_t* __restrict__ ps = a.pos ? a.pos + base : nullptr;
+    uint32_t key[E];
+    uint32_t nvalid = 0u;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int j = w * E * 64 + i * 64 + lane;
+        const bool in = j < a.n;
+        const int p = in ? (ps ? ps[j] : j) : -1;
+        const float v = KW == 1 ? vf[in ? j : 0] : (float)vd[in ? j : 0];
+        const bool ok = in && p >= 0;
+        key[i] = ok ? desc_key_f32(v) : 0xffffffffu;           // (no real key is all ones: that would be -NaN's pattern, mapped to 0)
+        nvalid += ok ? 1u : 0u;
+    }
+    // wave sums / minima / maxima on the VALU (DPP + permlane swaps: no LDS round trips), partials through parity-buffered LDS slots:
+    // one barrier per reduction
+    auto wave_u32 = [&](uint32_t v, auto op) __attribute__((always_inline)) -> uint32_t {
+        auto dpp = [&](uint32_t x, auto ctrl) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, 0xf, 0xf, true); };
+        v = op(v, dpp(v, std::integral_constant<int, 0xB1>{})); v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));
+        v = op(v, dpp(v, std::integral_constant<int, 0x141>{})); v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));
+        float x = __uint_as_float(v), o = x;
+        swap16(x, o); v = op(__float_as_uint(x), __float_as_uint(o));
+        x = __uint_as_float(v); o = x;
+        swap32(x, o);
+        return op(__float_as_uint(x), __float_as_uint(o));
+    };
+    auto add_ = [](uint32_t p, uint32_t q) { return p + q; };
+    auto min_ = [](uint32_t p, uint32_t q) { return p < q ? p : q; };
+    auto max_ = [](uint32_t p, uint32_t q) { return p > q ? p : q; };
+    int par = 0;
+    auto block_u32 = [&](uint32_t v, auto op, uint32_t ident) __attribute__((always_inline)) -> uint32_t {
+        v = wave_u32(v, op);
+        if (lane == 0) red[par][w] = v;
+        __syncthreads();
+        uint32_t t = ident;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) t = op(t, red[par][i]);
+        par ^= 1;
+        return t;
+    };
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+    for (int i = 0; i < E; ++i) if (key[i] != 0xffffffffu) { kmin = min_(kmin, key[i]); kmax = max_(kmax, key[i]); }
+    const uint32_t total = block_u32(nvalid, add_, 0u);
+    kmin = block_u32(kmin, min_, 0xffffffffu);
+    kmax = block_u32(kmax, max_, 0u);
+    const uint32_t need = (uint32_t)a.k < total ? (uint32_t)a.k : total;   // fewer listed documents than k: all of them
+    // A threshold key tau with need <= #{key <= tau} <= cap is all the two sorts behind this kernel need -- not the exact k-th smallest
+    // key -- so the bisection over the key range stops at the first midpoint whose count falls into that window (k = 1000 of 27,942,
+    // cap = 2 k: 8-12 counts instead of one per key bit).  If no midpoint does (a tie run longer than cap - k at the k-th place) it ends
+    // at the smallest key with at least `need` keys at or below it, the count exceeds cap and the overflow flag sends the caller to the
+    // full sort.
+    uint32_t tau = kmax;
+    if (total > (uint32_t)a.cap) {
+        uint32_t lo = kmin, hi = kmax;                         // invariant: count(<= hi) >= need
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < E; ++i) c += key[i] <= mid ? 1u : 0u;
+            c = block_u32(c, add_, 0u);
+            if (c < need) lo = mid + 1;
+            else { hi = mid; tau = mid; if (c <= (uint32_t)a.cap) break; }
+        }
+        if (lo >= hi) tau = hi;
+    }
+    // candidates: every listed document whose key does not exceed the threshold
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < E; ++i) mine += (need > 0 && key[i] <= tau && key[i] != 0xffffffffu) ? 1u : 0u;
+    uint32_t incl = wave_incl_scan_u32(mine, lane);
+    __syncthreads();                                           // (the last reduction's slots have been read)
+    if (lane == 63) red[0][w] = incl;
+    __syncthreads();
+    uint32_t off = incl - mine, all = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { if (i < w) off += red[0][i]; all += red[0][i]; }
+    if (threadIdx.x == 0) {
+        a.cand_len[row] = (int32_t)(all < (uint32_t)a.cap ? all : (uint32_t)a.cap);
+        if (all > (uint32_t)a.cap) atomicExch(a.overflow, 1);
+    }
+    const size_t cb = (size_t)row * a.cap;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        if (need > 0 && key[i] <= tau && key[i] != 0xffffffffu) {
+            if (off < (uint32_t)a.cap) {
+                const int j = w * E * 64 + i * 64 + lane;
+                a.cand_cols[cb + off] = j;
+                a.cand_negpos[cb + off] = -(float)(ps ? ps[j] : j);
+                if (KW == 1) reinterpret_cast<float*>(a.cand_vals)[cb + off] = vf[j];
+                else reinterpret_cast<double*>(a.cand_vals)[cb + off] = vd[j];
+            }
+            ++off;
+        }
+    }
+}
+
 }  // namespace fz
 
 using namespace fz;
+
+extern "C" int fz_select_topk_f(const void* fused, int key_bits, const int32_t* pos, int rows, int n, int ld, int k, int cap, int32_t* cand_cols,
+                                void* cand_vals, float* cand_negpos, int32_t* cand_len, int32_t* overflow, void* stream) {
+    if ((key_bits != 32 && key_bits != 64) || rows < 0 || n < 0 || ld < n || k <= 0 || cap < k) return FZ_ERR_ARG;
+    if (rows == 0) return FZ_OK;
+    if (!cand_len || !overflow) return FZ_ERR_ARG;
+    if (n == 0) { FZ_HIP_TRY(hipMemsetAsync(cand_len, 0, (size_t)rows * 4, as_stream(stream))); return FZ_OK; }
+    if (!fused || !cand_cols || !cand_vals || !cand_negpos) return FZ_ERR_ARG;
+    if (n > 1024 * 28) return FZ_ERR_UNSUPPORTED;   // one workgroup holds the row (and positions stay exact in float32)
+    SelectArgs a{fused, key_bits, pos, n, ld, k, cap, cand_cols, cand_vals, cand_negpos, cand_len, overflow};
+    hipStream_t st = as_stream(stream);
+#define FZ_SEL(TT, EE) { if (key_bits == 32) topk_select_kernel<TT, EE, 1><<<rows, TT, 0, st>>>(a); else topk_select_kernel<TT, EE, 2><<<rows, TT, 0, st>>>(a); }
+    if (n <= 256 * 4) FZ_SEL(256, 4)
+    else if (n <= 256 * 16) FZ_SEL(256, 16)
+    else if (n <= 1024 * 16) FZ_SEL(1024, 16)
+    else FZ_SEL(1024, 28)
+#undef FZ_SEL
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
 
 extern "C" int fz_sort_max_n(void) { return 35840; }   // single-workgroup rows (the fast path), fp32 keys; fp64 keys: 28672.  Longer rows: chunk-sort + merge
 extern "C" int fz_sort_max_n_f64(void) { return 28672; }

@@ -264,6 +264,45 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
     return order, sk, rank
 
 
+def select_topk(fused: torch.Tensor, pos: torch.Tensor | None, k: int, cap: int | None = None):
+    """First k entries of sort_rows_desc(fused, init_rank=pos) without sorting the rows (fz_select_topk_f + two small row sorts): the
+    fused lists main() actually reads (predictions(1000), hybrid.py:537).  fused [Q, N] float32 / float64 plane, pos [Q, N] int32 plane =
+    first-insertion position of every column (< 0: in no list; None: the column index).  Returns (cols [Q, k] int32 -- -1 past a row's
+    length --, scores [Q, k], lens [Q] int32), or None when a row has more than `cap` candidates (a long tie run at the k-th place) or
+    the row is longer than one workgroup holds: the caller then sorts in full."""
+    _dev(fused, None, "select_topk(fused)")
+    if fused.dtype not in (torch.float32, torch.float64):
+        raise TypeError("select_topk(fused): float32 or float64 expected")
+    fused = as_plane(fused)
+    Q, N = fused.shape
+    _need(k > 0, "select_topk: k must be positive")
+    if N > 28672 or Q == 0:
+        return None
+    if pos is not None:
+        _dev(pos, torch.int32, "select_topk(pos)")
+        _same_shape([fused, pos], "select_topk")
+        _need(Q <= 1 or _ld(pos) == _ld(fused), "select_topk: fused and pos must share the row stride")
+    cap = int(cap) if cap else round_up(k + 1024, 1024)
+    dev = fused.device
+    cols = alloc_plane(Q, cap, torch.int32, dev)
+    vals = alloc_plane(Q, cap, fused.dtype, dev)
+    negp = alloc_plane(Q, cap, torch.float32, dev)
+    clen = torch.empty(Q, dtype=torch.int32, device=dev)
+    over = torch.zeros(1, dtype=torch.int32, device=dev)
+    _need(_ld(cols) == _ld(vals) == _ld(negp), "select_topk: candidate planes must share the row stride")
+    rc = _lib.lib().fz_select_topk_f(_ptr(fused), 32 if fused.dtype == torch.float32 else 64, _ptr(pos), Q, N, _ld(fused), int(k), _ld(cols), _ptr(cols),
+                                     _ptr(vals), _ptr(negp), _ptr(clen), _ptr(over), _stream(fused))
+    check(rc, "fz_select_topk_f")
+    by_pos, _, _ = sort_rows_desc(negp, row_len=clen, want_keys=False)                 # candidate slots in first-insertion order
+    slots, sk, _ = sort_rows_desc(vals, init_order=by_pos, row_len=clen)              # ... then, stably, by fused score
+    if int(over.item()) != 0:
+        return None
+    kk = min(k, cap)
+    sel = slots[:, :kk]
+    out_cols = torch.where(sel >= 0, torch.gather(cols, 1, sel.clamp(min=0).long()), torch.full_like(sel, -1))
+    return out_cols, sk[:, :kk], torch.clamp(clen, max=kk)
+
+
 # ---------------------------------------------------------------------------------------
 # fusion
 # ---------------------------------------------------------------------------------------
@@ -514,8 +553,9 @@ def fuse_wsum(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | Non
     return fused
 
 
-def insertion_order(orders: list[torch.Tensor], lens: torch.Tensor, N: int):
-    """First-insertion order of the fused dict (hybrid.py:301-304). Returns (ins_order [Q,N] int32, U [Q] int32)."""
+def insertion_order(orders: list[torch.Tensor], lens: torch.Tensor, N: int, want_pos: bool = False):
+    """First-insertion order of the fused dict (hybrid.py:301-304). Returns (ins_order [Q,N] int32, U [Q] int32), with want_pos also the
+    inverse plane pos [Q,N] int32 (first-insertion position of every document, -1 = in no list)."""
     for o in orders:
         _dev(o, torch.int32, "insertion_order(orders)")
     _same_shape(orders, "insertion_order")
@@ -529,9 +569,10 @@ def insertion_order(orders: list[torch.Tensor], lens: torch.Tensor, N: int):
     dev = orders[0].device
     ins = torch.full((max(Q, 1), ld), -1, dtype=torch.int32, device=dev)[:Q, :N]
     U = torch.zeros(Q, dtype=torch.int32, device=dev)
-    check(_lib.lib().fz_insertion_order(_ptr_array(orders), _ptr(lens), len(orders), Q, N, ld, _ptr(ins), _ptr(U), None, 0,
+    pos = torch.full((max(Q, 1), ld), -1, dtype=torch.int32, device=dev)[:Q, :N] if want_pos else None
+    check(_lib.lib().fz_insertion_order(_ptr_array(orders), _ptr(lens), len(orders), Q, N, ld, _ptr(ins), _ptr(U), _ptr(pos), None, 0,
                                         _stream(orders[0])), "fz_insertion_order")
-    return ins, U
+    return (ins, U, pos) if want_pos else (ins, U)
 
 
 def gold_ranks(T: list[torch.Tensor], pos: torch.Tensor, weights: torch.Tensor, gold: torch.Tensor) -> torch.Tensor:

@@ -193,7 +193,11 @@ class Aggregator:
     # -- device pipeline -----------------------------------------------------------------
     @classmethod
     def fuse_device(cls, systems: dict[str, RankedSystem], method: str, normalization: str = None,
-                    linear_weights: dict[str, float] = None, percentile_distributions: dict[str, np.ndarray] = None) -> FusedResult:
+                    linear_weights: dict[str, float] = None, percentile_distributions: dict[str, np.ndarray] = None,
+                    topk: int | None = None) -> FusedResult:
+        """The fusion on the device.  topk=k: only the first k entries of every fused list are produced (what main() reads of them:
+        predictions(1000), hybrid.py:537) -- the rows are selected, not sorted (ops.select_topk); the entries and their order are those
+        of the full lists, bit for bit.  Aggregator.fuse always returns the full lists, as the reference does."""
         names = list(systems.keys())
         S = [systems[n] for n in names]
         Q = S[0].Q
@@ -232,11 +236,21 @@ class Aggregator:
 
         if all_full:
             # first-insertion order == system 0's ranking: its rank plane places every doc (coalesced, no gather)
+            if topk is not None and topk < N:
+                sel = ops.select_topk(fused, S[0].rank, topk)
+                if sel is not None:
+                    return FusedResult(order=sel[0], scores=sel[1], lens=sel[2], ids=S[0].ids)
             lens_out = torch.full((Q,), N, dtype=torch.int32, device=dev)
             order, sk, _ = ops.sort_rows_desc(fused, init_rank=S[0].rank)
         else:
             lens = torch.stack([s.lens for s in S]).contiguous()
-            ins, U = ops.insertion_order([s.order for s in S], lens, N)
+            if topk is not None and topk < N:
+                ins, U, pos = ops.insertion_order([s.order for s in S], lens, N, want_pos=True)
+                sel = ops.select_topk(fused, pos, topk)
+                if sel is not None:
+                    return FusedResult(order=sel[0], scores=sel[1], lens=sel[2], ids=S[0].ids)
+            else:
+                ins, U = ops.insertion_order([s.order for s in S], lens, N)
             lens_out = U
             order, sk, _ = ops.sort_rows_desc(fused, init_order=ins, row_len=U)
         return FusedResult(order=order, scores=sk, lens=lens_out, ids=S[0].ids)
@@ -272,12 +286,7 @@ class Aggregator:
             pos = S[0].rank
         else:
             lens = torch.stack([s.lens for s in S]).contiguous()
-            ins, U = ops.insertion_order([s.order for s in S], lens, N)
-            pos = ops.alloc_plane(Q, N, torch.int32, dev, fill=-1)
-            r = torch.arange(N, device=dev, dtype=torch.int32).unsqueeze(0).expand(Q, N)
-            valid = r < U.unsqueeze(1)
-            rows = torch.arange(Q, device=dev).unsqueeze(1).expand(Q, N)
-            pos[rows[valid], ins.long()[valid]] = r[valid]
+            ins, U, pos = ops.insertion_order([s.order for s in S], lens, N, want_pos=True)
         weights = torch.tensor([[float(w[n]) for n in names] for w in weight_combinations],      # KeyError as hybrid.py:214
                                dtype=torch.float64).to(torch.float64 if wide else torch.float32).to(dev)
         id2pos = {cid: j for j, cid in enumerate(S[0].ids.tolist())}
@@ -334,7 +343,7 @@ class Aggregator:
         """Generic path (float64 'none' arithmetic, > 4 systems): one device fusion + evaluation per weight vector."""
         out = []
         for w in weight_combinations:
-            fused = cls.fuse_device(systems, "nsf", normalization, w, percentile_distributions)
+            fused = cls.fuse_device(systems, "nsf", normalization, w, percentile_distributions, topk=1000)   # every cut-off is <= 1000
             out.append(run_evaluation(fused.predictions(1000), labels, print2console=False))
         return out
 
@@ -540,8 +549,8 @@ def main(args):
     weights = {s: 1 / len(results) for s in results} if args.fusion == "nsf" else {}
     distr = distributions() if args.fusion == "nsf" else {}
     print(f"{sep}\n# Fusing results with {args.fusion.upper()}{' (' + args.normalization + ')' if args.fusion == 'nsf' else ''}\n{sep}")
-    fused = Aggregator.fuse(results, method=args.fusion, normalization=args.normalization, percentile_distributions=distr,
-                            linear_weights=weights, as_device=True)
+    # main() reads 1000 entries of every fused list (hybrid.py:467 via Metrics' largest cut-off): the rows are selected, not sorted
+    fused = Aggregator.fuse_device(Aggregator._to_device(results), args.fusion, args.normalization, weights, distr, topk=1000)
     predictions = fused.predictions(1000)
     if args.run_monobert:   # hybrid.py:460-462, with the argument bug fixed: rerank the fused top-k with the cross-encoder
         print(f"{sep}\n# Re-ranking with monoBERT \n{sep}")

@@ -122,6 +122,17 @@ int fz_sort_rows_desc_placed(const void* keys, int key_bits, const int32_t* init
                              int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* Top-k form of the final ordering (what main() reads of the fused lists: predictions(1000), hybrid.py:537).  Per row: the candidates for the
+ * first k places of the sort above -- every column with pos >= 0 whose fused score, rounded to float32, is not below the k-th largest such
+ * value (the k best and every tie at the k-th place) -- written in no particular order as cand_cols [rows][cap] (column), cand_vals
+ * [rows][cap] (its fused score, same type as `fused`), cand_negpos [rows][cap] (-(float)pos: a descending sort of it is ascending insertion
+ * order), cand_len [rows].  pos [rows][ld] = first-insertion position of the column (< 0: in no list; NULL: the column index).  Sorting the
+ * candidates by cand_negpos and then, stably, by cand_vals (fz_sort_rows_desc twice, rows of cap keys) gives the first k entries of the
+ * full sort exactly.  *overflow (device int32, zeroed by the caller) is set when a row has more than cap candidates (a tie run longer
+ * than cap - k at the k-th place): sort that batch in full.  n <= 28,672 (one workgroup holds the row), k <= cap. */
+int fz_select_topk_f(const void* fused, int key_bits, const int32_t* pos, int rows, int n, int ld, int k, int cap, int32_t* cand_cols,
+                     void* cand_vals, float* cand_negpos, int32_t* cand_len, int32_t* overflow, void* stream);
+
 /* ---- K5b: rank-based fusion, hybrid.py:206-211,248-252,301-304 ------------------------- */
 /* fused[q][j] = sum over systems s (in the given order, fp64, starting from 0.0) of
  *   rrf: 1/(60+rank+1)     bcf: (len-rank+1)/len      for rank >= 0;  -inf if j is in no list.
@@ -192,10 +203,11 @@ int fz_fuse_wsum_f64(const void* const* planes_h, const int32_t* plane_is_f64_h,
 /* ---- first-insertion order of the fused dict, hybrid.py:301-304 (tie-break, SURVEY KAT-1) */
 /* ins_order[q][0..U[q]) = docs in the order aggregate_scores first inserts them: system by system,
  * each in its rank order, skipping docs already seen.  orders_h: HOST array of S device pointers
- * [Q][ld]; lens [S][Q].  Workspace: fz_insertion_order_workspace_bytes(Q, N). */
+ * [Q][ld]; lens [S][Q].  pos (nullable, [Q][ld], pre-filled with -1 by the caller): the inverse, pos[q][doc] = its first-insertion
+ * position -- what fz_gold_ranks_* and fz_select_topk_f take.  Workspace: fz_insertion_order_workspace_bytes(Q, N). */
 size_t fz_insertion_order_workspace_bytes(int Q, int N);
 int fz_insertion_order(const int32_t* const* orders_h, const int32_t* lens, int S, int Q, int N, int ld, int32_t* ins_order,
-                       int32_t* U, void* workspace, size_t workspace_bytes, void* stream);
+                       int32_t* U, int32_t* pos, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- top-k + shard merge: sentence_transformers.py:346-364 (chunked score -> topk -> heap) */
 /* k best of each row by (score desc, id asc); ids = id_base + column. out [rows][k]; rows with

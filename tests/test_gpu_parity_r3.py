@@ -153,11 +153,11 @@ def test_c_abi_sweep_recipe_with_a_partial_list(ops, oracle):
         T.append(t)
     dlens = dev(lens.astype(np.int32))
     ins = torch.full((Q, ld), -1, dtype=torch.int32, device="cuda"); U = torch.zeros(Q, dtype=torch.int32, device="cuda")
-    assert L.fz_insertion_order((C.c_void_p * S)(*[o.data_ptr() for o in dorders]), P(dlens), S, Q, N, ld, P(ins), P(U), None, 0, st) == 0
     pos = torch.full((Q, ld), -1, dtype=torch.int32, device="cuda")
-    Uh, insh = U.cpu().numpy(), ins.cpu().numpy()
+    assert L.fz_insertion_order((C.c_void_p * S)(*[o.data_ptr() for o in dorders]), P(dlens), S, Q, N, ld, P(ins), P(U), P(pos), None, 0, st) == 0
+    Uh, insh, posh = U.cpu().numpy(), ins.cpu().numpy(), pos.cpu().numpy()
     for q in range(Q):
-        pos[q, torch.from_numpy(insh[q, : Uh[q]].astype(np.int64)).cuda()] = torch.arange(int(Uh[q]), dtype=torch.int32, device="cuda")
+        assert np.array_equal(posh[q, insh[q, : Uh[q]]], np.arange(Uh[q])) and (posh[q, :N] >= 0).sum() == Uh[q]      # pos is the inverse of ins
     W = z["weights"][::9]
     G = L.fz_tune_max_gold()
     id2pos = {int(c): j for j, c in enumerate(ids)}
@@ -270,3 +270,67 @@ def test_splade_encoder_fused_head_equals_materialising_head():
     plain = enc.encode_ids(torch.where(mask.bool(), ids_d, torch.ones_like(ids_d)), mask)
     assert float((fused - unfused).abs().max()) <= 2e-6
     assert float((fused - plain).abs().max()) <= 5e-6
+
+
+# ---- top-k form of the fused-list ordering ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("Q,N,k", [(5, 27942, 1000), (3, 1000, 1000), (4, 1500, 1000), (6, 300, 10), (3, 28672, 1)])
+def test_select_topk_equals_the_head_of_the_full_sort(ops, oracle, dtype, Q, N, k):
+    """ops.select_topk(fused, pos, k) == the first k entries of the stable sort of the row in first-insertion order (hybrid.py:301-306),
+    with exact ties across the k-th place, absent documents (pos < 0), NaN, +-0 and fewer listed documents than k."""
+    rng = np.random.default_rng(Q * N + k)
+    x = rng.normal(0, 1, (Q, N)).astype(dtype)
+    if dtype == np.float64:
+        x[0] = x[0].astype(np.float32) + 1e-12 * rng.normal(0, 1, N)            # distinct float64 scores that round to equal float32 ones
+    x[1, ::7] = x[1, 3]                                                          # a tie run that usually straddles the k-th place
+    if N > 50:
+        x[2, 5] = np.nan; x[2, 9] = 0.0; x[2, 10] = -0.0
+    perm = np.stack([rng.permutation(N) for _ in range(Q)]).astype(np.int32)      # pos[q, j]: insertion position of column j
+    listed = rng.random((Q, N)) < (0.7 if Q > 2 else 1.0)
+    listed[0] = True
+    pos = np.where(listed, perm, -1).astype(np.int32)
+    # make positions dense per row (0 .. U-1) as the insertion order is
+    for q in range(Q):
+        idx = np.flatnonzero(pos[q] >= 0)
+        pos[q, idx[np.argsort(pos[q, idx])]] = np.arange(len(idx), dtype=np.int32)
+    U = (pos >= 0).sum(1).astype(np.int32)
+    ins = np.full((Q, N), -1, dtype=np.int32)
+    for q in range(Q):
+        idx = np.flatnonzero(pos[q] >= 0)
+        ins[q, pos[q, idx]] = idx
+    e_order, e_keys = oracle.sort_rows_desc(x, init_order=ins, row_len=U)
+    got = ops.select_topk(plane_of(ops, x), plane_of(ops, pos), k)
+    assert got is not None
+    cols, sc, lens = (t.cpu().numpy() for t in got)
+    kk = min(k, N)
+    np.testing.assert_array_equal(lens, np.minimum(U, kk))
+    for q in range(Q):
+        n = int(lens[q])
+        np.testing.assert_array_equal(cols[q, :n], e_order[q, :n])
+        np.testing.assert_array_equal(sc[q, :n], e_keys[q, :n])
+        assert np.all(cols[q, n:] == -1)
+
+
+def test_select_topk_reports_a_tie_run_it_cannot_hold(ops):
+    x = np.zeros((2, 5000), dtype=np.float32)                                    # 5000 equal scores: every one is a candidate for any k
+    assert ops.select_topk(plane_of(ops, x), None, 100) is None
+
+
+@pytest.mark.parametrize("method,norm", [("rrf", None), ("bcf", None), ("nsf", "min-max"), ("nsf", "z-score"), ("nsf", "none")])
+def test_fuse_device_topk_is_the_head_of_the_full_lists(ops, method, norm):
+    from fusion_amd.retrievers.hybrid import Aggregator, _rank_scores
+    rng = np.random.default_rng(3)
+    Q, N, k = 7, 27942, 1000
+    ids = np.arange(N) + 5
+    hidden = rng.normal(0, 1, (Q, N))
+    mk = lambda s: (hidden + s * rng.normal(0, 1, (Q, N))).astype(np.float32)
+    for cut in (None, int(0.6 * N)):                                             # all lists full | one PLAID-style short list
+        systems = {"a": _rank_scores(plane_of(ops, np.maximum(mk(1.0), 0.0)), ids, None), "b": _rank_scores(plane_of(ops, mk(0.5)), ids, None),
+                   "c": _rank_scores(plane_of(ops, mk(0.8)), ids, cut)}
+        w = {"a": 0.2, "b": 0.5, "c": 0.3}
+        full = Aggregator.fuse_device(systems, method, norm, w, {})
+        head = Aggregator.fuse_device(systems, method, norm, w, {}, topk=k)
+        assert head.order.shape == (Q, k) and head.scores.dtype == full.scores.dtype
+        np.testing.assert_array_equal(head.order.cpu().numpy(), full.order.cpu().numpy()[:, :k])
+        np.testing.assert_array_equal(head.scores.cpu().numpy(), full.scores.cpu().numpy()[:, :k])
+        assert head.predictions(1000) == full.predictions(1000)

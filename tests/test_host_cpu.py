@@ -81,7 +81,7 @@ def test_workspace_planning_is_consistent():
     assert L.fz_fuse_nsf_stats_f32(None, None, None, 1, 1, 1, 1, 1, None, None, None, None, None, 0, None, None) == ERR
     assert L.fz_fuse_none_f64(None, None, None, 1, 1, 1, 1, None, None) == ERR
     assert L.fz_fuse_wsum_f64(None, None, None, None, None, 1, 1, 1, 1, None, None) == ERR
-    assert L.fz_insertion_order(None, None, 1, 1, 1, 1, None, None, None, 0, None) == ERR
+    assert L.fz_insertion_order(None, None, 1, 1, 1, 1, None, None, None, None, 0, None) == ERR
     assert L.fz_topk_rows_f32(None, 1, 10, 10, 5, 0, None, None, None, 0, None) == ERR
     assert L.fz_topk_rows_f32(None, 1, 10, 10, kmax + 1, 0, None, None, None, 0, None) in (ERR, _lib.FZ_ERR_UNSUPPORTED)
     assert L.fz_topk_merge(None, None, 2, 1, 10, None, None, None) == ERR
