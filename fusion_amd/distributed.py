@@ -71,13 +71,13 @@ class ShardedDenseIndex:
 
     def __init__(self, Dn_local: torch.Tensor, id_base: int, group=None):
         self.Dn, self.id_base, self.group = Dn_local, int(id_base), group
-        self.last_overflow = 0   # 1 after a local_topk whose streaming pass overflowed a candidate buffer (it was then redone exactly)
+        self.last_overflow = 0   # windows of the last local_topk whose candidate buffers overflowed (each was redone exactly, ops.TopkStream)
 
     def local_topk(self, Qn: torch.Tensor, k: int, streaming: bool = True, mark=None):
         """Chunked score -> top-k over this shard.  The first HEAD documents get an exact top-k (one sort-kernel row per query);
         after that only scores above a query's running k-th best can enter, so every later chunk goes through the streaming
-        threshold filter and the candidates are folded into the list a few times per shard (ops.TopkStream).  If any row
-        overflowed its candidate buffer the search is redone on the exact path (flag read once, at the end).
+        threshold filter and the candidates are folded into the list a few times per shard (ops.TopkStream).  A window in which a
+        row overflowed its candidate buffer is redone exactly, on its own (flag read at every fold: 4 small reads per shard).
         `mark(name)`: optional instrumentation hook (bench.py records a HIP event per call).
         Everything runs on ONE stream: issuing the top-k work of chunk c on a second stream under the GEMM of chunk c + 1 was
         measured twice and lost both times (17.3 vs 15.5 ms per 1.1 M-document shard in round 2: the persistent GEMM owns every
@@ -97,12 +97,8 @@ class ShardedDenseIndex:
             for c0 in range(head, n, self.CHUNK):
                 c1 = min(n, c0 + self.CHUNK)
                 stream.feed_gemm(Qn, self.Dn[c0:c1], self.id_base + c0, mark=mark)
-            best_s, best_i, overflow = stream.result(); mark("shard_topk_stream")
-            if int(overflow.item()) != 0:
-                out = self.local_topk(Qn, k, streaming=False, mark=mark)
-                self.last_overflow = 1
-                return out
-            self.last_overflow = 0
+            best_s, best_i, _ = stream.result(); mark("shard_topk_stream")
+            self.last_overflow = stream.windows_redone
             return best_s, best_i
         for c0 in range(0, max(n, 1), self.CHUNK):
             c1 = min(n, c0 + self.CHUNK)
@@ -121,11 +117,8 @@ class ShardedDenseIndex:
                 best_s, best_i = ops.topk_merge(torch.stack([best_s, s]), torch.stack([best_i, i])); mark("shard_topk_exact")
         self.last_overflow = 0
         if stream is not None:
-            best_s, best_i, overflow = stream.result(); mark("shard_topk_stream")
-            if int(overflow.item()) != 0:
-                out = self.local_topk(Qn, k, streaming=False, mark=mark)
-                self.last_overflow = 1
-                return out
+            best_s, best_i, _ = stream.result(); mark("shard_topk_stream")
+            self.last_overflow = stream.windows_redone
         return best_s, best_i
 
     def search(self, Qn: torch.Tensor, k: int = 1000, mark=None):

@@ -679,9 +679,13 @@ class TopkStream:
     are folded into the list (fz_topk_fold_f32: one row sort) only when their EXPECTED number -- k * (documents since the fold) /
     (documents before it), for scores in no particular order -- reaches half the candidate capacity.  The windows between folds
     therefore grow geometrically: 4 folds for a 1.1 M-document shard at k = 1000, cap = 7168 after an 8192-document head, however the scoring is chunked.
-    `overflow` (device int32) becomes 1 if a row ever had more than `cap` candidates: the caller redoes the search exactly."""
+    `overflow` (device int32) becomes 1 if a row had more than `cap` candidates in a window.  With `exact_on_overflow` (default) the
+    flag is read at every fold (one small device -> host read per window: 4 per 1.1 M-document shard) and an overflowed WINDOW is redone
+    exactly -- per-piece top-k (fz_topk_rows_f32) merged into the list as it stood before the window -- so a corpus ordered by relevance
+    (every window overflows) costs the exact search once, not a wasted streaming pass plus the exact search of the whole shard;
+    `windows_redone` counts them.  Without it the flag stays set and the caller redoes the search."""
 
-    def __init__(self, run_scores: torch.Tensor, run_ids: torch.Tensor, seen: int, cap: int = 7168):
+    def __init__(self, run_scores: torch.Tensor, run_ids: torch.Tensor, seen: int, cap: int = 7168, exact_on_overflow: bool = True):
         _dev(run_scores, torch.float32, "TopkStream(run_scores)"); _dev(run_ids, torch.int64, "TopkStream(run_ids)")
         rows, k = run_scores.shape
         _need(tuple(run_ids.shape) == (rows, k) and seen > 0 and cap > 0, "TopkStream: lists [rows, k], seen > 0, cap > 0 expected")
@@ -699,6 +703,9 @@ class TopkStream:
         self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         self.seen = int(seen)            # documents folded into (best_s, tau)
         self.pending = 0                 # documents filtered against tau since
+        self.exact_on_overflow = bool(exact_on_overflow)
+        self.windows_redone = 0
+        self._pieces = []                # what the current window was fed with: ("scores", piece, id_base) | ("gemm", Qn, Dpiece, id_base)
         wsb = int(_lib.lib().fz_topk_fold_workspace_bytes(rows, k, cap))
         self._ws, self._wsb = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev), wsb
 
@@ -718,6 +725,7 @@ class TopkStream:
             check(lib.fz_topk_filter_append_f32(_ptr(piece), self.rows, hi - lo, _ld(scores), int(id_base) + lo, _ptr(self.tau), _ptr(self.cand_s),
                                                 _ptr(self.cand_i), _ptr(self.cand_len), self.cap, _ptr(self.overflow), _stream(scores)),
                   "fz_topk_filter_append_f32")
+            self._pieces.append(("scores", piece, int(id_base) + lo))
             self.pending += hi - lo
             lo = hi
             if self.pending >= self._window():
@@ -740,6 +748,7 @@ class TopkStream:
                                                _ptr(self._tau_pad), _ptr(self.cand_s), _ptr(self.cand_i), _ptr(self.cand_len), self.cap,
                                                _ptr(self.overflow), _stream(Qn)), "fz_dot_scores_filter_f32")
             if mark: mark("shard_gemm_filter")
+            self._pieces.append(("gemm", Qn, piece, int(id_base) + lo))
             self.pending += hi - lo
             lo = hi
             if self.pending >= self._window():
@@ -753,6 +762,25 @@ class TopkStream:
         check(_lib.lib().fz_topk_fold_f32(_ptr(self.best_s), _ptr(self.best_i), self.rows, self.k, _ptr(self.cand_s), _ptr(self.cand_i),
                                           _ptr(self.cand_len), self.cap, 1 if self.unordered else 0, _ptr(ns), _ptr(ni), _ptr(self.tau),
                                           _ptr(self.overflow), _ptr(self._ws), self._wsb, _stream(self.best_s)), "fz_topk_fold_f32")
+        if self.exact_on_overflow and int(self.overflow.item()) != 0:
+            # a candidate list was cut short (or a tie run was too long to order): this window again, exactly, on top of the list as it
+            # stood before it -- per piece: scores -> fz_topk_rows_f32 -> merge (ties by ascending id, as everywhere)
+            ns, ni = self.best_s, self.best_i
+            for kind, *args in self._pieces:
+                if kind == "gemm":
+                    Qn_, piece, base = args
+                    sc = dot_scores(Qn_, piece)
+                else:
+                    sc, base = args
+                if sc.shape[1] == 0:
+                    continue
+                ps, pi = topk_rows(sc, self.k, id_base=base)
+                ns, ni = topk_merge(torch.stack([ns, ps]), torch.stack([ni, pi]))
+            self.tau.copy_(ns[:, self.k - 1])
+            self.cand_len.zero_()
+            self.overflow.zero_()
+            self.windows_redone += 1
+        self._pieces.clear()
         self.best_s, self.best_i = ns, ni
         self.seen += self.pending
         self.pending = 0

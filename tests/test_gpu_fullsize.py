@@ -94,8 +94,8 @@ def test_config5_shard_fused_equals_two_pass_equals_oracle(ops, oracle, mmarco_s
 
 
 def test_config5_fused_search_survives_a_relevance_sorted_corpus(ops, oracle):
-    """A corpus whose best passages come LAST makes every window overflow its candidate buffer: the flag must send the search to the
-    exact path (same answer), never to a wrong list."""
+    """A corpus whose best passages come LAST makes every window overflow its candidate buffer: every such window is redone exactly (same
+    answer), never a wrong list -- and a single overflowing window in an otherwise random corpus costs that window only."""
     from fusion_amd.distributed import ShardedDenseIndex
     g = torch.Generator(device="cuda").manual_seed(9)
     N, d, Q, k = 120_000, 64, 16, 1000
@@ -105,9 +105,20 @@ def test_config5_fused_search_survives_a_relevance_sorted_corpus(ops, oracle):
     Dn = Dn[order].contiguous()
     Qn = ops.normalize_rows(q + 0.05 * torch.randn((Q, d), generator=g, device="cuda"))
     idx = ShardedDenseIndex(Dn, id_base=0)
+    for fused in (True, False):
+        idx.FUSED = fused
+        s, i = idx.local_topk(Qn, k)
+        assert idx.last_overflow >= 2                                # every window behind the head
+        es, ei = oracle.topk_rows(ops.dot_scores(Qn, Dn).cpu().numpy(), k)
+        np.testing.assert_array_equal(s.cpu().numpy(), es)
+        np.testing.assert_array_equal(i.cpu().numpy(), ei)
+    # one hot window in a random corpus: 9,000 near-copies of the query direction in one stretch
+    Dr = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
+    Dr[60_000:69_000] = ops.normalize_rows(q + 0.2 * torch.randn((9_000, d), generator=g, device="cuda"))
+    idx = ShardedDenseIndex(Dr, id_base=7)
     s, i = idx.local_topk(Qn, k)
     assert idx.last_overflow == 1
-    es, ei = oracle.topk_rows(ops.dot_scores(Qn, Dn).cpu().numpy(), k)
+    es, ei = oracle.topk_rows(ops.dot_scores(Qn, Dr).cpu().numpy(), k, id_base=7)
     np.testing.assert_array_equal(s.cpu().numpy(), es)
     np.testing.assert_array_equal(i.cpu().numpy(), ei)
 

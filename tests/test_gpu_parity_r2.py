@@ -620,9 +620,16 @@ def test_topk_stream_flags_candidate_overflow(ops):
     rows, n, k = 3, 40_000, 50
     S = ops.as_plane((torch.arange(rows * n, device="cuda", dtype=torch.float32).reshape(rows, n) / 7.0).contiguous())
     bs, bi = ops.topk_rows(S[:, :4096], k)
-    st = ops.TopkStream(bs, bi, seen=4096, cap=500)
+    st = ops.TopkStream(bs, bi, seen=4096, cap=500, exact_on_overflow=False)
     st.feed(S[:, 4096:], 4096)
     assert int(st.result()[2].item()) == 1
+    # default: every overflowed window is redone exactly as it is folded -- the lists are the exact top-k, the flag is clear again
+    st = ops.TopkStream(bs, bi, seen=4096, cap=500)
+    st.feed(S[:, 4096:], 4096)
+    rs, ri, flag = st.result()
+    es, ei = ops.topk_rows(S, k)
+    assert st.windows_redone >= 1 and int(flag.item()) == 0
+    assert torch.equal(rs, es) and torch.equal(ri, ei)
 
 
 # ---- percentile-rank / NCE: the windowed nearest-entry look-up against the plain first-argmin ------------------------------------------
@@ -721,10 +728,11 @@ def test_fused_gemm_filter_flags_a_tie_run_it_cannot_order(ops, oracle):
     Qn = Dn[20_000:20_002].clone()               # the queries ARE documents: their copies score exactly 1.0
     Dn[9_000:9_200] = Dn[20_000]                 # 200 copies behind the head: all tie at the top of query 0's list
     idx = ShardedDenseIndex(Dn, id_base=0)
-    st = ops.TopkStream(*ops.topk_rows(ops.dot_scores(Qn, Dn[:8192]), k), seen=8192, cap=7168)
+    st = ops.TopkStream(*ops.topk_rows(ops.dot_scores(Qn, Dn[:8192]), k), seen=8192, cap=7168, exact_on_overflow=False)
     st.feed_gemm(Qn, Dn[8192:], 8192)
     assert int(st.result()[2].item()) == 1
     s, i = idx.local_topk(Qn, k)
+    assert idx.last_overflow >= 1
     es, ei = oracle.topk_rows(ops.dot_scores(Qn, Dn).cpu().numpy(), k)
     np.testing.assert_array_equal(s.cpu().numpy(), es)
     np.testing.assert_array_equal(i.cpu().numpy(), ei)
