@@ -441,11 +441,13 @@ def measure_configs(dev, N=27942):
         ms = timeit_ms(lambda: Aggregator.fuse_device(systems, "nsf", "min-max", dict(zip(names, w)), {}), n=5)
         out.append(dict(config="4: Aggregator.fuse_device nsf min-max END TO END (stats + fuse + insertion order + final sort)", shape=dict(Q=Q, N=N, S=4),
                         ms=ms, queries_per_s=Q / (ms * 1e-3)))
-        for meth in ("rrf",):   # float64 fused rows: full lists (what Aggregator.fuse returns) vs the top-1000 form main() reads (hybrid.py:537)
-            ms_full = timeit_ms(lambda: Aggregator.fuse_device(systems, meth, None, {}, {}), n=5)
-            ms_top = timeit_ms(lambda: Aggregator.fuse_device(systems, meth, None, {}, {}, topk=1000), n=5)
-            out.append(dict(config=f"4: Aggregator.fuse_device {meth} S=4, topk=1000 (rows selected, not sorted: fz_select_topk_f + two 2k-key sorts) vs the full lists",
-                            shape=dict(Q=Q, N=N, S=4, k=1000), ms=ms_top, ms_full_lists=ms_full, queries_per_s=Q / (ms_top * 1e-3)))
+        # float64 fused rows over full lists (the BM25 + DPR RRF hybrid of the headline step): the full lists Aggregator.fuse returns vs the
+        # top-1000 form main() reads (hybrid.py:537; rows selected, not sorted)
+        two = {n: systems[n] for n in ("bm25", "dpr")}
+        ms_full = timeit_ms(lambda: Aggregator.fuse_device(two, "rrf", None, {}, {}), n=5)
+        ms_top = timeit_ms(lambda: Aggregator.fuse_device(two, "rrf", None, {}, {}, topk=1000), n=5)
+        out.append(dict(config="1: Aggregator.fuse_device rrf BM25+DPR, topk=1000 (fz_select_topk_f + two 2k-key sorts; NOT what Aggregator.fuse returns) vs the full lists",
+                        shape=dict(Q=Q, N=N, S=2, k=1000), ms=ms_top, ms_full_lists=ms_full, queries_per_s=Q / (ms_top * 1e-3)))
         if Q == 195:   # the 1771-vector sweep of hybrid.py:404-426 on the LLeQA test split size
             grid = weight_grid(names)
             labels = [rng.choice(N, size=int(rng.integers(1, 6)), replace=False).tolist() for _ in range(Q)]

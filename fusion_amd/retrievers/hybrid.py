@@ -234,9 +234,10 @@ class Aggregator:
         else:                                               # unknown method: raw scores are summed (hybrid.py:203-218)
             fused = ops.fuse_wsum([s.scores if s.scores64 is None else s.scores64 for s in S], ranks, [1.0] * len(S))
 
-        # topk: float64 fused rows (rrf / bcf / 'none' / np.float64 weights) are selected, not sorted -- two thirds of the full float64 sort's
-        # time at N = 27,942; for float32 rows the selection costs what the four-pass sort costs, so those are sorted and cut
-        select = topk is not None and topk < N and fused.dtype == torch.float64
+        # topk: float64 fused rows (rrf / bcf / 'none' / np.float64 weights) over full lists are selected, not sorted -- two thirds of the
+        # full float64 sort's time at N = 27,942.  float32 rows (the selection costs what their four-pass sort costs) and partial lists
+        # (the inverse insertion order costs more than the selection saves) are sorted and cut
+        select = topk is not None and topk < N and fused.dtype == torch.float64 and all_full
         if all_full:
             # first-insertion order == system 0's ranking: its rank plane places every doc (coalesced, no gather)
             if select:
@@ -247,13 +248,7 @@ class Aggregator:
             order, sk, _ = ops.sort_rows_desc(fused, init_rank=S[0].rank)
         else:
             lens = torch.stack([s.lens for s in S]).contiguous()
-            if select:
-                ins, U, pos = ops.insertion_order([s.order for s in S], lens, N, want_pos=True)
-                sel = ops.select_topk(fused, pos, topk)
-                if sel is not None:
-                    return FusedResult(order=sel[0], scores=sel[1], lens=sel[2], ids=S[0].ids)
-            else:
-                ins, U = ops.insertion_order([s.order for s in S], lens, N)
+            ins, U = ops.insertion_order([s.order for s in S], lens, N)
             lens_out = U
             order, sk, _ = ops.sort_rows_desc(fused, init_order=ins, row_len=U)
         if topk is not None and topk < N:
