@@ -247,12 +247,16 @@ int fzo_row_stats_f32(const float* scores, const int32_t* rank /*nullable: valid
         const int32_t* v = rank ? rank + (size_t)r * ld : NULL;
         if (norm == NORM_MINMAX) {
             float mn = INFINITY, mx = -INFINITY;
+            int anynan = 0, cnt = 0;
             for (int j = 0; j < N; ++j) {
                 if (v && v[j] < 0) continue;
+                ++cnt;
+                if (x[j] != x[j]) anynan = 1;   /* torch.min / torch.max propagate a NaN (hybrid.py:255-258) */
                 if (x[j] < mn) mn = x[j];
                 if (x[j] > mx) mx = x[j];
             }
-            stat_a[r] = mn; stat_b[r] = mx;
+            if (cnt == 0) { mn = 0.f; mx = 0.f; }   /* an empty list: nothing is transformed with these */
+            stat_a[r] = anynan ? NAN : mn; stat_b[r] = anynan ? NAN : mx;
         } else if (norm == NORM_ZSCORE) {
             double sum = 0.0; long cnt = 0;
             for (int j = 0; j < N; ++j) { if (v && v[j] < 0) continue; sum += (double)x[j]; ++cnt; }

