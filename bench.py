@@ -235,7 +235,7 @@ def step_lleqa(st, ev=None):
             t.record_stream(torch.cuda.current_stream())
     fused = ops.fuse_rank([r_b, r_d], st["lens2"], "rrf")
     if ev: ev.mark("fuse_rrf")
-    order, scores, _ = ops.sort_rows_desc(fused, init_rank=r_b)   # ties keep BM25's (system 0) order
+    order, scores, _ = ops.sort_rows_desc(fused, init_rank=r_b, covers_all=True)   # ties keep BM25's (system 0) order; full lists, as fuse_device calls it
     if ev: ev.mark("final_order")
     return order, scores, (S, B, q_emb)
 

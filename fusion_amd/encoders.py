@@ -261,10 +261,15 @@ class PackedBertForward(FusedBertForward):
         # while GEMM tuning is on, the row count is padded to a multiple of ROW_GRANULE (zero rows: every op between the GEMMs is
         # row-wise, so they never touch a real row) -- tuned solutions are keyed by the exact shape
         Tp = -(-T // self.ROW_GRANULE) * self.ROW_GRANULE if torch.cuda.tunable.is_enabled() else T
-        x = torch.zeros((Tp, self.word.shape[1]), dtype=torch.float32, device=dev) if Tp != T else None
+        x = None
+        if Tp != T:                               # only the pad rows need zeros: the real ones are written by the kernel below
+            x = torch.empty((Tp, self.word.shape[1]), dtype=torch.float32, device=dev)
+            x[T:].zero_()
         # embedding gather + position + type + LayerNorm in one pass over the packed rows
         x = ops.embed_layernorm(self.word, self.pos, self.type0, ids, meta[T:], *self.emb_ln, out=x)
-        ctx = torch.zeros_like(x)                 # attention writes the real rows of this buffer in every layer
+        ctx = torch.empty_like(x)                 # attention writes the real rows of this buffer in every layer; the pad rows stay zero
+        if Tp != T:
+            ctx[T:].zero_()
         mark = mark or (lambda name: None)
         mark("encode_embed")
         for ly in self.layers:

@@ -198,7 +198,7 @@ def sort_max_n(dtype=torch.float32) -> int:
 
 def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, row_len: torch.Tensor | None = None,
                    want_order=True, want_keys=True, want_rank=False, init_rank: torch.Tensor | None = None,
-                   stats_out: torch.Tensor | None = None, stats_len: torch.Tensor | None = None):
+                   stats_out: torch.Tensor | None = None, stats_len: torch.Tensor | None = None, covers_all: bool = False):
     """Stable descending row sort (Python sorted(reverse=True): bm25.py:104, hybrid.py:306).
     Incoming sequence: identity (default), `init_order` (column at each sequence position) or `init_rank`
     (sequence position of each column: a rank plane; read coalesced, the fast form).
@@ -206,7 +206,9 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
     rank entries of elements outside the sequence are -1.
     stats_out: a contiguous fp32 tensor [4, rows] that receives mean | unbiased std | min | max of each list's float32 values as a
     by-product of the sort (identity / init_order sequences, rows that fit one workgroup); stats_len [rows] int32 restricts the
-    statistics to the first stats_len[row] entries of the sorted list (a ranking cut to its top-k; fp32 keys only)."""
+    statistics to the first stats_len[row] entries of the sorted list (a ranking cut to its top-k; fp32 keys only).
+    covers_all: the caller vouches that the incoming sequence holds every column of every row (init_rank is a full ranking's rank
+    plane, no row_len): the outputs are then written in full and need no -1 / -inf pre-fill (two plane-sized fill launches)."""
     _dev(keys, None, "sort_rows_desc(keys)")
     if keys.dtype not in (torch.float32, torch.float64):
         raise TypeError("keys must be float32 or float64")
@@ -217,7 +219,7 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
 
     if init_order is not None and init_rank is not None:
         raise ValueError("pass init_order or init_rank, not both")
-    partial = row_len is not None or init_order is not None or init_rank is not None  # some slots may stay unwritten: pre-fill them
+    partial = (row_len is not None or init_order is not None or init_rank is not None) and not covers_all  # some slots may stay unwritten: pre-fill them
 
     def mk(dtype, fill):
         shape = (max(rows, 1), ld)

@@ -245,7 +245,7 @@ class Aggregator:
                 if sel is not None:
                     return FusedResult(order=sel[0], scores=sel[1], lens=sel[2], ids=S[0].ids)
             lens_out = torch.full((Q,), N, dtype=torch.int32, device=dev)
-            order, sk, _ = ops.sort_rows_desc(fused, init_rank=S[0].rank)
+            order, sk, _ = ops.sort_rows_desc(fused, init_rank=S[0].rank, covers_all=True)   # every list is full: every slot gets written
         else:
             lens = torch.stack([s.lens for s in S]).contiguous()
             ins, U = ops.insertion_order([s.order for s in S], lens, N)
