@@ -237,7 +237,7 @@ class Aggregator:
         # topk: float64 fused rows (rrf / bcf / 'none' / np.float64 weights) over full lists are selected, not sorted -- two thirds of the
         # full float64 sort's time at N = 27,942.  float32 rows (the selection costs what their four-pass sort costs) and partial lists
         # (the inverse insertion order costs more than the selection saves) are sorted and cut
-        select = topk is not None and topk < N and fused.dtype == torch.float64 and all_full
+        select = topk is not None and topk < N and fused.dtype == torch.float64 and all_full and Q >= 512   # (small batches: launch- and sync-bound, the sort wins)
         if all_full:
             # first-insertion order == system 0's ranking: its rank plane places every doc (coalesced, no gather)
             if select:
