@@ -18,6 +18,8 @@
 // blocks of one corpus tile run back-to-back on one XCD (workgroup id % 8), so a corpus tile is fetched from HBM once and hit
 // in that XCD's L2 afterwards.  What each of these steps bought is in DESIGN.md section 5 (K1).
 #include <stdlib.h>
+
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -64,8 +66,10 @@ struct GemmArgs {
     const float* A; int lda;   // queries  [Q][lda]
     const float* B; int ldb;   // corpus   [N][ldb]
     float* C; int ldc;         // scores   [Q][ldc]
-    int Q, N, d, QB, TN;
+    int Q, N, d, QB, TN;       // QB: query blocks of 128 rows run as whole-height tiles
     int full, halves;          // tile ids < full are whole 128x128 tiles; then `halves` 128x64 half tiles (at most one per workgroup)
+    int tail_ids, tail_row0;   // ids of the tiles of a last query block of 1..96 rows (0: none), which start at row tail_row0 ...
+    int tail_rows;             // ... and are 32, 64 or 96 rows high
     // FILTER form (fz_dot_scores_filter_f32): no score plane; what beats a query's threshold goes to its candidate list
     const float* tau;          // [QB * 128]: tau[q] for q < Q, +inf beyond
     float* cand_s;             // [Q][cap]
@@ -87,14 +91,17 @@ enum { EPI_STORE = 0, EPI_FILTER = 1, EPI_SPLADE = 2 };
 // ALL those tiles form one stream through the software pipeline: the operand loads of a tile's first two k-tiles are issued
 // during the last two k-tiles of the tile before it, and its score stores drain under the next tile's MFMAs -- a workgroup
 // pays the pipeline fill once per launch, not once per tile.
-template <int BN, bool RAGGED /* d is not a whole number of k-tile pairs */, int EPI>
-__device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int first, const int end, const int step) {
-    constexpr int NI = BN / 64;          // 32x32 MFMA tiles per wave along N (wave tile = 64 x BN/2)
+template <int BN, int MI /* 32-row MFMA blocks per wave */, int WN /* waves along the corpus side: 2 (2 x 2 waves) or 4 (1 x 4) */, bool RAGGED /* d is not a whole number of k-tile pairs */, int EPI>
+__device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int first, const int end, const int step, const int qblocks, const int row_origin) {
+    constexpr int WM = 4 / WN;           // waves along the query side
+    constexpr int BMT = 32 * MI * WM;    // tile height: 128 (whole query blocks: 2 x 2 waves, MI = 2), 64 (MI = 1) or 32 (1 x 4 waves, MI = 1)
+    constexpr int AROWS = BMT / 32;      // staging float4 per thread for the query tile
+    constexpr int NI = BN / (32 * WN);   // 32x32 MFMA tiles per wave along N (wave tile = 32 MI x BN / WN)
     constexpr int BROWS = BN / 32;       // staging float4 per thread for the corpus tile
     // [stage][A: 128 rows | B: BN rows][LDT]
-    constexpr int BUF = (BM + BN) * LDT;
+    constexpr int BUF = (BMT + BN) * LDT;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = w / WN, wc = w % WN;
 
     // tile id -> (query row, corpus column) of its corner; ids of the XCD padding decode to nothing
     auto decode = [&](int b, int& row0, int& col0) -> bool {
@@ -105,8 +112,8 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
             half = (h >> 3) & 1;
         }
         const int x = b & 7, idx = b >> 3;
-        const int dt = (idx / g.QB) * 8 + x;     // 128-wide corpus tile
-        row0 = (idx % g.QB) * BM;
+        const int dt = (idx / qblocks) * 8 + x;     // 128-wide corpus tile
+        row0 = row_origin + (idx % qblocks) * BMT;
         col0 = dt * 128 + half * 64;
         return dt < g.TN;
     };
@@ -129,19 +136,19 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
     // for the whole tile: the k-loop spends no vector instruction on addressing
     const float* abase;
     const float* bbase;
-    int32_t oa[4], ob[BROWS];
+    int32_t oa[AROWS], ob[BROWS];
     auto point_at = [&](int row0, int col0) {
         row0 = min(row0, g.Q - 1);         // (a half tile may start past the last corpus row)
         col0 = min(col0, g.N - 1);
         abase = g.A + (size_t)row0 * g.lda;
         bbase = g.B + (size_t)col0 * g.ldb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) oa[i] = (min(srow + 32 * i, g.Q - 1 - row0) * g.lda + sk) * 4;
+        for (int i = 0; i < AROWS; ++i) oa[i] = (min(srow + 32 * i, g.Q - 1 - row0) * g.lda + sk) * 4;
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) ob[i] = (min(srow + 32 * i, g.N - 1 - col0) * g.ldb + sk) * 4;
     };
     const int KT = ((g.d + 2 * BK - 1) / (2 * BK)) * 2;
-    struct Stage { float4 a[4], b[BROWS]; };
+    struct Stage { float4 a[AROWS], b[BROWS]; };
     // `edge` (compile time): this k-tile may reach past d -- only the last two of a tile can; all the others take the plain path
     auto gload = [&](Stage& r, int kt, auto edge) __attribute__((always_inline)) {
         const char* ab = reinterpret_cast<const char*>(abase + kt * BK);
@@ -149,13 +156,13 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
         // d % 4 == 0: a float4 is entirely inside or outside.  Outside: step back to the row's last float4 (zeroed in sstore)
         const int32_t back = (RAGGED && decltype(edge)::value) ? max(0, kt * BK + sk + 4 - g.d) * 4 : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r.a[i] = *reinterpret_cast<const float4*>(ab + (ptrdiff_t)(oa[i] - back));
+        for (int i = 0; i < AROWS; ++i) r.a[i] = *reinterpret_cast<const float4*>(ab + (ptrdiff_t)(oa[i] - back));
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) r.b[i] = *reinterpret_cast<const float4*>(bb + (ptrdiff_t)(ob[i] - back));
     };
     auto sstore = [&](const Stage& r, int kt, auto edge) __attribute__((always_inline)) {   // kt: the k-tile the registers hold
         float* As = lds + (kt & 1) * BUF;
-        float* Bs = As + BM * LDT;
+        float* Bs = As + BMT * LDT;
         const uint32_t m = RAGGED && kt * BK + sk >= g.d ? 0u : ~0u;
         auto keep = [&](float4 v) {
             if (!(RAGGED && decltype(edge)::value)) return v;
@@ -163,15 +170,15 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
                                __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
         };
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDT + sk) = keep(r.a[i]);
+        for (int i = 0; i < AROWS; ++i) *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDT + sk) = keep(r.a[i]);
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDT + sk) = keep(r.b[i]);
     };
 
-    f32x16 acc[2][NI];
+    f32x16 acc[MI][NI];
     auto clear = [&]() {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -179,14 +186,14 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
     };
 
     // fragments of one group of 8 k's: lanes 0-31 hold k 0..3, lanes 32-63 k 4..7 (see the header)
-    struct Frag { float4 a[2], b[NI]; };
+    struct Frag { float4 a[MI], b[NI]; };
     const int fr = lane & 31, fh = (lane >> 5) * 4;
-    const int aoff = (wr * 64 + fr) * LDT + fh, boff = BM * LDT + (wc * (BN / 2) + fr) * LDT + fh;
+    const int aoff = (wr * (32 * MI) + fr) * LDT + fh, boff = BMT * LDT + (wc * (BN / WN) + fr) * LDT + fh;
     auto fread = [&](Frag& f, int buf, int kg) __attribute__((always_inline)) {
         const float* As = lds + buf * BUF + aoff + kg * 8;
         const float* Bs = lds + buf * BUF + boff + kg * 8;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) f.a[mi] = *reinterpret_cast<const float4*>(As + mi * 32 * LDT);
+        for (int mi = 0; mi < MI; ++mi) f.a[mi] = *reinterpret_cast<const float4*>(As + mi * 32 * LDT);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) f.b[ni] = *reinterpret_cast<const float4*>(Bs + ni * 32 * LDT);
     };
@@ -194,7 +201,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const float av = kk == 0 ? f.a[mi].x : kk == 1 ? f.a[mi].y : kk == 2 ? f.a[mi].z : f.a[mi].w;
@@ -261,10 +268,10 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
             // their steps' slots with ONE round of atomics (64 steps in parallel); pass B recomputes the ballots and stores.
             // Candidates of one (query, step) are in document order; ACROSS steps, waves and workgroups the order is arbitrary:
             // fz_topk_fold_f32(unordered) re-establishes "ties by ascending id".
-            constexpr int STEPS = 2 * NI * 16;
+            constexpr int STEPS = MI * NI * 16;
             const int h = lane >> 5;
-            const int qw = crow + wr * 64 + 4 * h;                      // + mi*32 + (r&3) + 8*(r>>2)
-            const int dw = ccol + wc * (BN / 2) + (lane & 31);          // + ni*32
+            const int qw = crow + wr * (32 * MI) + 4 * h;               // + mi*32 + (r&3) + 8*(r>>2)
+            const int dw = ccol + wc * (BN / WN) + (lane & 31);         // + ni*32
             bool over = false;
             // `edge` (compile time): the tile reaches past the last query or document and every score is bounds-checked; inside the
             // matrix -- the usual tile -- a score costs ONE compare per pass (the two passes are ~3 % of the kernel)
@@ -277,7 +284,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
                 };
                 uint32_t counts = 0u;
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         const float4 t4 = *reinterpret_cast<const float4*>(g.tau + qw + mi * 32 + 8 * rg);   // this lane half's thresholds, 4 rows
@@ -295,13 +302,13 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
                 int base_lo = 0, base_hi = 0;
                 if (lane < STEPS) {
                     const int r = lane & 15, mi = lane / (16 * NI);
-                    const int qa = crow + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2);
+                    const int qa = crow + wr * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2);
                     const int c_lo = counts & 0xffff, c_hi = counts >> 16;
                     if (c_lo) base_lo = atomicAdd(&g.cand_len[qa], c_lo);
                     if (c_hi) base_hi = atomicAdd(&g.cand_len[qa + 4], c_hi);
                 }
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         const float4 t4 = *reinterpret_cast<const float4*>(g.tau + qw + mi * 32 + 8 * rg);   // (again: 32 registers are not to spare)
@@ -327,7 +334,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
                     }
             };
             // (rows past Q carry tau = +inf, but a NaN score beats even that: the last query block keeps its row check)
-            if (ccol + BN <= g.N && crow + BM <= g.Q) passes(std::false_type{});   // workgroup-uniform
+            if (ccol + BN <= g.N && crow + BMT <= g.Q) passes(std::false_type{});   // workgroup-uniform
             else passes(std::true_type{});
             if (over) atomicExch(g.overflow, 1);
         } else if constexpr (EPI == EPI_SPLADE) {
@@ -338,8 +345,8 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
             // atomicMax.  A wave's 64 rows are cut at the sequence boundaries (cu_rows: packed rows, sequences back to back); per piece:
             // an in-lane max over the accumulator registers whose row lies in the piece, one permlane32 swap to join the lane halves,
             // and one atomic per column from lanes 0-31.
-            const int R0 = crow + wr * 64;
-            const int Rend = min(R0 + 64, g.Q);
+            const int R0 = crow + wr * (32 * MI);
+            const int Rend = min(R0 + 32 * MI, g.Q);
             if (R0 < Rend) {      // wave-uniform
                 int lo_s = 0, hi_s = g.nseq;             // first sequence that ends after R0 (scalar binary search)
                 while (lo_s < hi_s) { const int mid = (lo_s + hi_s) >> 1; if (g.cu_rows[mid + 1] > R0) hi_s = mid; else lo_s = mid + 1; }
@@ -353,7 +360,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) m[ni] = -INFINITY;
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + h4;
@@ -366,7 +373,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
                         float other = m[ni];
                         swap32(m[ni], other);                 // m = [lo half, lo half], other = [hi half, hi half]
                         const float best = fmaxf(m[ni], other);
-                        const int c = ccol + wc * (BN / 2) + ni * 32 + (lane & 31);
+                        const int c = ccol + wc * (BN / WN) + ni * 32 + (lane & 31);
                         if (lane < 32 && c < g.N) {
                             const float logit = best + g.bias[c];
                             const float v = log1pf(fmaxf(logit, 0.0f));
@@ -376,13 +383,13 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
                 }
             }
         } else {
-        const bool whole = crow + BM <= g.Q && ccol + BN <= g.N;
+        const bool whole = crow + BMT <= g.Q && ccol + BN <= g.N;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int c = ccol + wc * (BN / 2) + ni * 32 + (lane & 31);
-                const int q0 = crow + wr * 64 + mi * 32 + 4 * (lane >> 5);
+                const int c = ccol + wc * (BN / WN) + ni * 32 + (lane & 31);
+                const int q0 = crow + wr * (32 * MI) + mi * 32 + 4 * (lane >> 5);
                 float* cp = g.C + (size_t)q0 * g.ldc + c;
                 if (whole) {
 #pragma unroll
@@ -403,14 +410,33 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
 // XCD-aware: workgroups i and i+8 share an XCD (round-robin dispatch) and grid % 8 == 0, so the QB query blocks of one corpus tile
 // are consecutive ids on one XCD, run at about the same time, and the corpus tile is fetched from HBM once.  The first `g.full`
 // ids are 128x128 tiles; the rest is the LAST partial round cut into 128x64 halves, so that the tail occupies every CU for half a
-// tile time instead of half the CUs for a whole one (1792 equal tiles on 512 slots otherwise cost 4 rounds for 3.5 of work).
+// tile time instead of half the CUs for a whole one (1792 equal tiles on 512 resident slots otherwise cost 4 rounds for 3.5 of work).
+// Query batches that are not a multiple of 128 rows: a last block of up to 96 rows runs as tiles of its own height -- 32 or 96 rows
+// (1 x 4 waves, one or three MFMA row blocks each) or 64 rows (2 x 2 waves, one row block each) -- whose ids follow the whole tiles in every
+// workgroup's sequence: 195 queries are 128 + 96 rows of MFMA work instead of 256, 64 or fewer half of what a 128-row tile costs.  Every
+// shape accumulates a score as the same chain of fused multiply-adds in the same k order: a query's scores do not depend on the tile
+// its row fell into.
 template <bool RAGGED, int EPI>
 __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    gemm_stream<128, RAGGED, EPI>(g, lds, blockIdx.x, g.full, gridDim.x);
-    if ((int)blockIdx.x < g.halves) {
+    const int b0 = (int)blockIdx.x, G = (int)gridDim.x;
+    gemm_stream<128, 2, 2, RAGGED, EPI>(g, lds, b0, g.full, G, g.QB, 0);
+    if (b0 < g.halves) {
         __syncthreads();                     // the half tile restarts the pipeline in stage 0
-        gemm_stream<64, RAGGED, EPI>(g, lds, g.full + blockIdx.x, g.full + blockIdx.x + 1, 1);
+        gemm_stream<64, 2, 2, RAGGED, EPI>(g, lds, g.full + b0, g.full + b0 + 1, 1, g.QB, 0);
+    }
+    if constexpr (EPI != EPI_SPLADE) {
+        if (g.tail_ids > 0) {                // this workgroup's id sequence b0, b0 + G, ... continues through the last query block's tiles
+            int t = b0;
+            if (t < g.full) t += ((g.full - t + G - 1) / G) * G;
+            t -= g.full;
+            if (t < g.tail_ids) {            // (workgroup-uniform)
+                __syncthreads();
+                if (g.tail_rows == 32) gemm_stream<128, 1, 4, RAGGED, EPI>(g, lds, t, g.tail_ids, G, 1, g.tail_row0);
+                else if (g.tail_rows == 64) gemm_stream<128, 1, 2, RAGGED, EPI>(g, lds, t, g.tail_ids, G, 1, g.tail_row0);
+                else gemm_stream<128, 3, 4, RAGGED, EPI>(g, lds, t, g.tail_ids, G, 1, g.tail_row0);
+            }
+        }
     }
 }
 
@@ -429,21 +455,32 @@ extern "C" int fz_normalize_rows_f32(const float* X, int rows, int d, int ldx, f
 }
 
 static int launch_gemm(GemmArgs& g, int epi, hipStream_t st) {
-    g.QB = (g.Q + BM - 1) / BM;
+    // rows -> whole 128-row query blocks + a last block in its own height class (32, 64 or 96 rows; more than 96: a padded whole block)
+    int nfull = g.Q / BM;
+    const int rem = g.Q % BM;
+    int tail = 0;
+    if (epi == EPI_SPLADE || rem > 96) nfull += rem > 0;
+    else if (rem > 0) tail = (rem + 31) / 32 * 32;
+    g.QB = nfull;
     g.TN = (g.N + 127) / 128;
-    const long B = 8L * g.QB * ((g.TN + 7) / 8);        // ids of whole tiles (incl. the XCD padding, which decodes to nothing)
+    const long TN8 = 8L * ((g.TN + 7) / 8);             // corpus-tile ids incl. the XCD padding, which decodes to nothing
+    const long B = TN8 * nfull;                           // ids of whole tiles
+    g.tail_ids = tail ? (int)TN8 : 0; g.tail_row0 = nfull * BM; g.tail_rows = tail;
+    const long Bt = g.tail_ids;
     static int cus[64];
     int dev = 0;
     FZ_HIP_TRY(hipGetDevice(&dev));
     if (dev >= 64) return FZ_ERR_UNSUPPORTED;
     if (!cus[dev]) FZ_HIP_TRY(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
     const long slots = 2L * cus[dev] / 8 * 8;            // resident workgroups (two per CU), a multiple of the 8 XCDs
-    if (slots <= 0 || B > 0x3fffffffL) return FZ_ERR_UNSUPPORTED;
+    if (slots <= 0 || B + Bt > 0x3fffffffL) return FZ_ERR_UNSUPPORTED;
     long R = B % slots;                                  // the partial last round ...
-    if (R > slots / 2 || B < slots) R = 0;               // ... is only worth halving when it is at most half full
+    if (R > slots / 2 || B < slots || Bt > 0) R = 0;     // ... is only worth halving when it is at most half full (and nothing follows it)
     g.full = (int)(B - R);
     g.halves = (int)(2 * R);
-    const long nblk = B < slots ? B : slots;
+    const long ids = B + Bt;
+    const long nblk = ids < slots ? ids : slots;
+    if (nblk <= 0) return FZ_OK;
     constexpr size_t lds_db = 2 * (BM + 128) * LDT * sizeof(float);
     // per-lane offsets are signed 32-bit byte offsets inside one 128-row operand tile
     if (128.0 * g.lda * 4 >= 2147483648.0 || 128.0 * g.ldb * 4 >= 2147483648.0) return FZ_ERR_UNSUPPORTED;

@@ -334,3 +334,40 @@ def test_fuse_device_topk_is_the_head_of_the_full_lists(ops, method, norm):
         np.testing.assert_array_equal(head.order.cpu().numpy(), full.order.cpu().numpy()[:, :k])
         np.testing.assert_array_equal(head.scores.cpu().numpy(), full.scores.cpu().numpy()[:, :k])
         assert head.predictions(1000) == full.predictions(1000)
+
+
+# ---- score GEMM: query batches that are not a multiple of 128 rows ---------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [768, 100, 36])
+def test_dot_scores_do_not_depend_on_the_row_class(ops, d):
+    """195 queries run as one 128-row block of MFMA tiles + a 64-row block (2 x 2 waves, one row block each) + a 32-row block (1 x 4 waves).
+    Every tile shape accumulates a score as the same chain of fused multiply-adds in the same k order: a query's scores are the same
+    bits whichever tile its row falls into (and whatever the batch size)."""
+    g = torch.Generator(device="cuda").manual_seed(d)
+    N = 5003
+    Dn = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
+    Qn = ops.normalize_rows(torch.randn((211, d), generator=g, device="cuda"))
+    S195 = ops.dot_scores(Qn[:195].contiguous(), Dn)                 # 128 + 64 + 32 (3 rows used)
+    assert torch.equal(S195[192:195], ops.dot_scores(Qn[192:195].contiguous(), Dn))     # the last rows as a batch of their own (Q = 3: a 32-row tile)
+    assert torch.equal(S195[128:192], ops.dot_scores(Qn[128:192].contiguous(), Dn))     # the 64-row block on its own
+    assert torch.equal(S195[64:192], ops.dot_scores(Qn[64:192].contiguous(), Dn))       # ... and inside a whole 128-row block
+    S211 = ops.dot_scores(Qn, Dn)                                    # 128 + 83: 64 + 32
+    assert torch.equal(S211[:195], S195)
+    S137 = ops.dot_scores(Qn[:137].contiguous(), Dn)                 # 128 + 32 (9 rows used)
+    assert torch.equal(S137, S195[:137])
+    S16 = ops.dot_scores(Qn[:16].contiguous(), Dn)                   # a small batch: 32-row tiles only
+    S100 = ops.dot_scores(Qn[:100].contiguous(), Dn)                 # 64 + 32 + ... 100 > 96: one padded 128-row block
+    assert torch.equal(S100, S195[:100])
+    assert torch.equal(S16, S195[:16])
+    ref = (Qn[:195].double() @ Dn.double().T)
+    assert float((S195.double() - ref).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("Q", [3, 64, 65, 80, 81, 129, 144, 145, 195, 201, 209, 300, 1024 + 67])
+def test_dot_scores_every_tiling_of_the_query_rows(ops, oracle, Q):
+    g = torch.Generator(device="cuda").manual_seed(Q)
+    N, d = 1283, 64
+    Dn = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
+    Qn = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
+    S = ops.dot_scores(Qn, Dn).cpu().numpy()
+    exp = oracle.dot_scores(Qn.cpu().numpy(), Dn.cpu().numpy(), fma_chain=True)
+    assert S.shape == (Q, N) and np.max(np.abs(S - exp)) <= 2e-6
