@@ -181,6 +181,7 @@ def build_lleqa(args, dev, rank):
                       doc_len=torch.from_numpy(lens.astype(np.int32)).to(dev), avgdl=float(lens.mean()),
                       qoff=torch.from_numpy(qoff).to(dev), qterms=torch.from_numpy(qterms).to(dev))
     st["bm25"]["doc_norm"] = ops.bm25_doc_norms(st["bm25"]["doc_len"], st["bm25"]["avgdl"], 2.5, 0.2)   # per index, like the idf table
+    st["bm25"]["slice_off"] = ops.bm25_slice_offsets(st["bm25"]["toff"], st["bm25"]["pdoc"], N)         # ditto
     st["lens2"] = torch.full((2, Q), N, dtype=torch.int32, device=dev)
     st["Q"], st["N"], st["d"] = Q, N, d
     st["buckets"] = args.encode_buckets
@@ -200,7 +201,7 @@ def step_lleqa(st, ev=None):
 
     def bm25_branch():
         B = ops.bm25_scores(b["toff"], b["pdoc"], b["ptf"], b["idf"], b["doc_len"], b["avgdl"], 2.5, 0.2, b["qoff"], b["qterms"], Q, N,
-                            doc_norm=b["doc_norm"])
+                            doc_norm=b["doc_norm"], slice_off=b["slice_off"])
         if ev: ev.mark("bm25_score")
         o_b, _, r_b = ops.sort_rows_desc(B, want_keys=False, want_rank=True)
         if ev: ev.mark("bm25_rank")
@@ -519,6 +520,7 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
     bm = dict(toff=torch.from_numpy(toff).to(dev), pdoc=torch.from_numpy(pd.astype(np.int32)).to(dev), ptf=torch.from_numpy(tf.astype(np.int32)).to(dev),
               idf=torch.from_numpy(np.log10((N - df + 0.5) / (df + 0.5))).to(dev), doc_len=torch.from_numpy(blens.astype(np.int32)).to(dev), avgdl=float(blens.mean()))
     bm["doc_norm"] = ops.bm25_doc_norms(bm["doc_len"], bm["avgdl"], 2.5, 0.2)
+    bm["slice_off"] = ops.bm25_slice_offsets(bm["toff"], bm["pdoc"], N)
 
     log("pipeline4: corpus side built")
     for Q in queries:
@@ -535,7 +537,8 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
 
         def step(mark):
             mark("start")
-            B = ops.bm25_scores(bm["toff"], bm["pdoc"], bm["ptf"], bm["idf"], bm["doc_len"], bm["avgdl"], 2.5, 0.2, qoff, qterms, Q, N, doc_norm=bm["doc_norm"])
+            B = ops.bm25_scores(bm["toff"], bm["pdoc"], bm["ptf"], bm["idf"], bm["doc_len"], bm["avgdl"], 2.5, 0.2, qoff, qterms, Q, N, doc_norm=bm["doc_norm"],
+                                slice_off=bm["slice_off"])
             mark("bm25_score")
             st4 = torch.empty((4, Q), dtype=torch.float32, device=dev)
             o_b, sk_b, r_b = ops.sort_rows_desc(B, want_rank=True, stats_out=st4)

@@ -12,6 +12,8 @@ namespace fz {
 struct Bm25Args {
     const int64_t* toff; const int32_t* pdoc; const int32_t* ptf; const double* idf; const int32_t* doc_len;
     const double* doc_norm;   // nullable: k1*(1-b+b*|d|/avgdl) per document (fz_bm25_doc_norms_f64), same bits as inline
+    const int64_t* slice_off; // nullable: [V][NS + 1] first posting of term t whose document is >= s * BM25_SLICE (fz_bm25_slice_offsets):
+                              //   without it every workgroup finds its posting sub-ranges by ~30 dependent loads per term
     double avgdl, k1, b;
     const int64_t* qoff; const int32_t* qterms;
     int N; double* scores; int lds;
@@ -52,8 +54,13 @@ __global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
             int64_t e0 = 0, e1 = 0; double w = 0.0;
             if (t >= 0) {     // out of vocabulary: idf 0, contributes nothing
                 w = a.idf[t];
-                e0 = lower_bound_doc(a.pdoc, a.toff[t], a.toff[t + 1], d0);
-                e1 = lower_bound_doc(a.pdoc, e0, a.toff[t + 1], d1);
+                if (a.slice_off) {   // per-index table: two loads instead of two binary searches
+                    const int64_t* so = a.slice_off + (size_t)t * (gridDim.x + 1) + blockIdx.x;
+                    e0 = so[0]; e1 = so[1];
+                } else {
+                    e0 = lower_bound_doc(a.pdoc, a.toff[t], a.toff[t + 1], d0);
+                    e1 = lower_bound_doc(a.pdoc, e0, a.toff[t + 1], d1);
+                }
             }
             s_e0[threadIdx.x] = e0; s_e1[threadIdx.x] = e1; s_w[threadIdx.x] = w;
         }
@@ -62,7 +69,9 @@ __global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
             const int64_t e0 = s_e0[k], e1 = s_e1[k];
             const double w = s_w[k];
             if (e1 <= e0) continue;             // block-uniform
-            // the walk is latency-bound (posting -> per-document gather -> accumulate): U postings per lane in flight
+            // the walk is latency-bound (posting -> per-document gather -> accumulate): U postings per lane in flight (U = 8 and a
+            // three-stage pipeline across steps and terms -- fetch i + 2, gather i + 1, accumulate i -- were both slower: 0.375 / 0.374
+            // vs 0.339 ms per 1024 queries)
             constexpr int U = 4;
             for (int64_t eb = e0; eb < e1; eb += (int64_t)blockDim.x * U) {
                 int doc[U]; double tf[U], kd[U];
@@ -95,6 +104,13 @@ __global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
     for (int j = threadIdx.x; j < n; j += blockDim.x) row[j] = acc[j];
 }
 
+__global__ void bm25_slice_offsets_kernel(const int64_t* __restrict__ toff, const int32_t* __restrict__ pdoc, int V, int NS, int64_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)V * (NS + 1)) return;
+    const int t = (int)(i / (NS + 1)), s_ = (int)(i % (NS + 1));
+    out[i] = s_ == NS ? toff[t + 1] : lower_bound_doc(pdoc, toff[t], toff[t + 1], s_ * BM25_SLICE);
+}
+
 __global__ void bm25_doc_norms_kernel(const int32_t* __restrict__ doc_len, int N, double avgdl, double k1, double b, double* __restrict__ out) {
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x)
         out[j] = k1 * (1.0 - b + b * (double)doc_len[j] / avgdl);   // the sub-expression of bm25.py:154, once per document
@@ -113,13 +129,26 @@ extern "C" int fz_bm25_doc_norms_f64(const int32_t* doc_len, int N, double avgdl
     return FZ_OK;
 }
 
+extern "C" int fz_bm25_slice_docs(void) { return BM25_SLICE; }
+
+extern "C" int fz_bm25_slice_offsets(const int64_t* toff, const int32_t* pdoc, int V, int N, int64_t* out, void* stream) {
+    if (V < 0 || N < 0) return FZ_ERR_ARG;
+    if (V == 0) return FZ_OK;
+    if (!toff || !out) return FZ_ERR_ARG;
+    const int NS = N > 0 ? (N + BM25_SLICE - 1) / BM25_SLICE : 1;
+    const long total = (long)V * (NS + 1);
+    bm25_slice_offsets_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(toff, pdoc, V, NS, out);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
 extern "C" int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf,
-                                  const int32_t* doc_len, const double* doc_norm, double avgdl, double k1, double b, const int64_t* qoff,
-                                  const int32_t* qterms, int Q, int N, double* scores, int lds, void* stream) {
+                                  const int32_t* doc_len, const double* doc_norm, const int64_t* slice_off, double avgdl, double k1, double b,
+                                  const int64_t* qoff, const int32_t* qterms, int Q, int N, double* scores, int lds, void* stream) {
     if (Q < 0 || N < 0 || lds < N) return FZ_ERR_ARG;
     if (Q == 0 || N == 0) return FZ_OK;           // empty tensors carry null pointers
     if (!toff || !idf || !doc_len || !qoff || !scores) return FZ_ERR_ARG;
-    Bm25Args a{toff, pdoc, ptf, idf, doc_len, doc_norm, avgdl, k1, b, qoff, qterms, N, scores, lds};
+    Bm25Args a{toff, pdoc, ptf, idf, doc_len, doc_norm, slice_off, avgdl, k1, b, qoff, qterms, N, scores, lds};
     constexpr size_t lds_bytes = (size_t)BM25_SLICE * sizeof(double);
     static unsigned long long lds_set = 0ull;
     if (int rc = raise_lds_limit((const void*)bm25_kernel, lds_bytes, lds_set)) return rc;

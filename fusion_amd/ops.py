@@ -817,8 +817,21 @@ def bm25_doc_norms(doc_len: torch.Tensor, avgdl: float, k1: float, b: float) -> 
     return out
 
 
+def bm25_slice_offsets(toff: torch.Tensor, pdoc: torch.Tensor, N: int) -> torch.Tensor:
+    """Per-index table [V, NS + 1] int64 for bm25_scores(slice_off=...): where every term's postings cross the document slices one
+    workgroup scores (fz_bm25_slice_offsets; built once per index, like the idf table)."""
+    _dev(toff, torch.int64, "bm25_slice_offsets(toff)"); _dev(pdoc, torch.int32, "bm25_slice_offsets(pdoc)")
+    _need(toff.is_contiguous() and pdoc.is_contiguous() and toff.numel() >= 1, "bm25_slice_offsets: contiguous toff [V + 1] and pdoc expected")
+    V = toff.numel() - 1
+    lib = _lib.lib()
+    NS = max(1, -(-int(N) // int(lib.fz_bm25_slice_docs())))
+    out = torch.empty((V, NS + 1), dtype=torch.int64, device=toff.device)
+    check(lib.fz_bm25_slice_offsets(_ptr(toff), _ptr(pdoc), V, int(N), _ptr(out), _stream(toff)), "fz_bm25_slice_offsets")
+    return out
+
+
 def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float, qoff, qterms, Q: int, N: int,
-                doc_norm: torch.Tensor | None = None) -> torch.Tensor:
+                doc_norm: torch.Tensor | None = None, slice_off: torch.Tensor | None = None) -> torch.Tensor:
     dev = idf.device
     for t, dt, what in ((toff, torch.int64, "toff"), (pdoc, torch.int32, "pdoc"), (ptf, torch.int32, "ptf"), (idf, torch.float64, "idf"),
                         (doc_len, torch.int32, "doc_len"), (qoff, torch.int64, "qoff"), (qterms, torch.int32, "qterms")):
@@ -828,8 +841,12 @@ def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float
     _need(doc_len.numel() == N and qoff.numel() == Q + 1, f"bm25_scores: doc_len must hold {N} lengths and qoff {Q + 1} offsets")
     if doc_norm is not None:
         _need(_dev(doc_norm, torch.float64, "bm25_scores(doc_norm)").numel() == N and doc_norm.is_contiguous(), f"bm25_scores: doc_norm must hold {N} values")
+    if slice_off is not None:
+        NS = max(1, -(-int(N) // int(_lib.lib().fz_bm25_slice_docs())))
+        _need(_dev(slice_off, torch.int64, "bm25_scores(slice_off)").is_contiguous() and tuple(slice_off.shape) == (idf.numel(), NS + 1),
+              f"bm25_scores(slice_off): expected a contiguous [{idf.numel()}, {NS + 1}] table (ops.bm25_slice_offsets)")
     out = torch.empty((max(Q, 1), max(round_up(N, _PAD), _PAD)), dtype=torch.float64, device=dev)[:Q, :N]
-    check(_lib.lib().fz_bm25_scores_f64(_ptr(toff), _ptr(pdoc), _ptr(ptf), _ptr(idf), _ptr(doc_len), _ptr(doc_norm), float(avgdl), float(k1),
+    check(_lib.lib().fz_bm25_scores_f64(_ptr(toff), _ptr(pdoc), _ptr(ptf), _ptr(idf), _ptr(doc_len), _ptr(doc_norm), _ptr(slice_off), float(avgdl), float(k1),
                                         float(b), _ptr(qoff), _ptr(qterms), Q, N, _ptr(out), _ld(out), _stream(idf)), "fz_bm25_scores_f64")
     return out
 

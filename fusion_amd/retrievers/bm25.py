@@ -48,6 +48,8 @@ class BM25:
         self.doc_len = torch.from_numpy(self.doc_len_host).to(d)
 
         self._norm_key, self._norm = None, None
+        # where every term's postings cross the document slices one workgroup scores: per index, like the idf table
+        self.slice_off = ops.bm25_slice_offsets(self.toff, self.pdoc, self.corpus_size) if self.device.type == "cuda" and V > 0 else None
 
     def update_params(self, k1: float, b: float) -> None:
         self.k1, self.b = k1, b
@@ -67,7 +69,7 @@ class BM25:
         flat = np.array([t for x in qt for t in x] or [0], dtype=np.int32)
         return ops.bm25_scores(self.toff, self.pdoc, self.ptf, self.idf, self.doc_len, self.avgdl, self.k1, self.b,
                                torch.from_numpy(qoff).to(self.device), torch.from_numpy(flat).to(self.device), len(queries), self.corpus_size,
-                               doc_norm=self._doc_norm())
+                               doc_norm=self._doc_norm(), slice_off=self.slice_off)
 
     def search_device(self, queries: list[str], ids: np.ndarray | None = None) -> RankedSystem:
         sc64 = self.scores(queries)

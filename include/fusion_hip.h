@@ -259,9 +259,14 @@ int fz_topk_allgather(const float* local_scores, const int64_t* local_ids, int Q
  * doc_norm (nullable): per-document k1*(1-b+b*dl/avgdl) from fz_bm25_doc_norms_f64 -- the same fp64 bits as the inline
  * sub-expression, computed once per document instead of once per posting. */
 int fz_bm25_doc_norms_f64(const int32_t* doc_len, int N, double avgdl, double k1, double b, double* out, void* stream);
+/* slice_off (nullable): per-index table [V][NS + 1] int64, NS = ceil(N / fz_bm25_slice_docs()): the first posting of term t whose document
+ * is >= s * fz_bm25_slice_docs() (entry NS = toff[t + 1]), from fz_bm25_slice_offsets -- a workgroup scores one (query, document slice) and
+ * otherwise finds every query term's posting sub-range by two binary searches of ~15 dependent loads each. */
+int fz_bm25_slice_docs(void);
+int fz_bm25_slice_offsets(const int64_t* toff, const int32_t* pdoc, int V, int N, int64_t* out, void* stream);
 int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf, const int32_t* doc_len,
-                       const double* doc_norm, double avgdl, double k1, double b, const int64_t* qoff, const int32_t* qterms,
-                       int Q, int N, double* scores, int lds, void* stream);
+                       const double* doc_norm, const int64_t* slice_off, double avgdl, double k1, double b, const int64_t* qoff,
+                       const int32_t* qterms, int Q, int N, double* scores, int lds, void* stream);
 
 /* ---- N1: weight-grid sweep of the linear fusion, hybrid.py:404-426 ------------------------ */
 /* Fused ranks of the gold documents for W weight vectors at once, without fusing or sorting:
