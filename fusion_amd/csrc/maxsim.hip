@@ -231,7 +231,30 @@ __global__ __launch_bounds__(512, 2) void maxsim_kernel(MaxSimArgs a) {
             for (int r = 0; r < 4; ++r) m = fmaxf(m, hi[r]);
             run[cb] = m;
         };
-        if (ncb == NCB) {   // wave-uniform: the full load (every wave of every full query group)
+        if (rows_valid <= 16) {
+            // the last tile of a document with at most 16 tokens left: its second row block is all padding -- only the first one's chains
+            // run (half the MFMAs of the tile; tiles are aligned to document starts, so on average 16 of a document's rows are padding)
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb += 2) {
+                if (cb < ncb) {
+                    f32x4 aL = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][0], bq[cb][0], (f32x4)0.f, 0, 0, 0);
+                    f32x4 bL = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][0], bq[cb + 1][0], (f32x4)0.f, 0, 0, 0);
+#pragma unroll
+                    for (int ks = 1; ks < 4; ++ks) {
+                        aL = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][ks], bq[cb][ks], aL, 0, 0, 0);
+                        bL = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][ks], bq[cb + 1][ks], bL, 0, 0, 0);
+                    }
+                    const int r0 = 4 * (lane >> 4);
+                    float ma = run[cb], mb = run[cb + 1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ma = fmaxf(ma, r0 + r < rows_valid ? aL[r] : -INFINITY);
+                        mb = fmaxf(mb, r0 + r < rows_valid ? bL[r] : -INFINITY);
+                    }
+                    run[cb] = ma; run[cb + 1] = mb;
+                }
+            }
+        } else if (ncb == NCB) {   // wave-uniform: the full load (every wave of every full query group)
             f32x4 aL, aH, bL, bH;
             chain(0, aL, aH);
             chain(1, bL, bH);
