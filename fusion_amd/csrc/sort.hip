@@ -274,33 +274,38 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         // ---- 1. rank inside the wave ------------------------------------------------
         uint32_t* my = cnt + w * 256;
         my[lane] = 0; my[lane + 64] = 0; my[lane + 128] = 0; my[lane + 192] = 0;
-        SLOT_FRESH();
+        // FULL (wave-uniform: every bit of the digit varies) is one straight-line block over the 28 items, no scalar branch per bit
+        auto rank_items = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            SLOT_FRESH();
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const uint32_t kw = ks[i];
-            const uint32_t d = (kw >> shift) & 0xffu;
-            // wave64 match-any on the digit's VARYING bits (a bit that is constant over the row cannot separate peers;
-            // dmask is wave-uniform, the skip is a scalar branch), 4 VALU per bit: sign-extended bit (0 / -1), ballot,
-            // and mask &= ~(ballot ^ sext) as one v_bitop3 per 32-lane half
-            uint32_t mlo = 0xffffffffu, mhi = 0xffffffffu;
+            for (int i = 0; i < E; ++i) {
+                const uint32_t kw = ks[i];
+                const uint32_t d = (kw >> shift) & 0xffu;
+                // wave64 match-any on the digit's VARYING bits (a bit that is constant over the row cannot separate peers;
+                // dmask is wave-uniform, the skip is a scalar branch), 4 VALU per bit: sign-extended bit (0 / -1), ballot,
+                // and mask &= ~(ballot ^ sext) as one v_bitop3 per 32-lane half
+                uint32_t mlo = 0xffffffffu, mhi = 0xffffffffu;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                if (!((dmask >> b) & 1u)) continue;
-                const uint32_t sx = (uint32_t)__builtin_amdgcn_sbfe((int)kw, (unsigned)(shift + b), 1u);
-                const unsigned long long bal = __ballot(sx != 0u);
-                mlo &= ~(((uint32_t)bal) ^ sx);
-                mhi &= ~(((uint32_t)(bal >> 32)) ^ sx);
+                for (int b = 0; b < 8; ++b) {
+                    if (!FULL && !((dmask >> b) & 1u)) continue;
+                    const uint32_t sx = (uint32_t)__builtin_amdgcn_sbfe((int)kw, (unsigned)(shift + b), 1u);
+                    const unsigned long long bal = __ballot(sx != 0u);
+                    mlo &= ~(((uint32_t)bal) ^ sx);
+                    mhi &= ~(((uint32_t)(bal >> 32)) ^ sx);
+                }
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                const uint32_t npeer = __popc(mlo) + __popc(mhi);
+                const uint32_t old = my[d];
+                if (below == 0) my[d] = old + npeer;
+                // bytes {3,2} <- (old+below), bytes {1,0} <- payload : one v_perm_b32
+                meta[i] = __builtin_amdgcn_perm(old + below, meta[i], 0x05040100u);
+                // opaque to the optimiser: otherwise hipcc keeps old, below, payload and &my[d] in four separate
+                // registers per item across the barrier (6.6 VGPRs/item -> scratch spills at E = 28)
+                asm volatile("" : "+v"(meta[i]));
             }
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-            const uint32_t npeer = __popc(mlo) + __popc(mhi);
-            const uint32_t old = my[d];
-            if (below == 0) my[d] = old + npeer;
-            // bytes {3,2} <- (old+below), bytes {1,0} <- payload : one v_perm_b32
-            meta[i] = __builtin_amdgcn_perm(old + below, meta[i], 0x05040100u);
-            // opaque to the optimiser: otherwise hipcc keeps old, below, payload and &my[d] in four separate
-            // registers per item across the barrier (6.6 VGPRs/item -> scratch spills at E = 28)
-            asm volatile("" : "+v"(meta[i]));
-        }
+        };
+        if (dmask == 0xffu) rank_items(std::true_type{}); else rank_items(std::false_type{});
         __syncthreads();
         // ---- 2. exclusive prefix over (digit, wave), digit-major ----------------------
         uint32_t tot = 0, incl = 0;
@@ -395,6 +400,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
 
     static_assert(KW == 1 || E <= 32, "fp64: per-thread slot masks are 32 bits");
     uint32_t signm = 0u, nanm = 0u;   // fp64: bit i = slot i's key has its (ascending-key) sign bit set / is the NaN key
+    uint32_t contm = 0u;              // fp64: bit i = slot i continues the equal-high-word run of the slot before it
     for (int pass = 0; pass < 4; ++pass) {
         if (((diff >> (pass * 8)) & 0xffu) == 0u) continue;  // constant digit among real keys: order unchanged
         radix_pass(pass * 8, (diff_match >> (pass * 8)) & 0xffu);
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         for (int i = 0; i < E; ++i) {
             const int p = (slot0 + i * 64);
             const bool ps = p > 0 && p < m && exch[p - 1] == ks[i];
+            contm |= (uint32_t)ps << i;
             const unsigned long long bal = __ballot(ps);
             if (lane == 0) { runbits[(w * E + i) * 2] = (uint32_t)bal; runbits[(w * E + i) * 2 + 1] = (uint32_t)(bal >> 32); }
             // the sorted key's high half is final now (the repair only moves keys inside runs of EQUAL high words)
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         }
         __syncthreads();
         // ---- low words: re-derived by the thread that loaded the element, published under its payload ----
-        constexpr int LGG = 4;
+        constexpr int LGG = 4;   // (7 in flight measured the same)
         SLOT_FRESH();
 #pragma unroll
         for (int i0 = 0; i0 < E; i0 += LGG) {
@@ -494,8 +501,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         // ---- repair.  The runs are described completely by LDS state -- runbits ("same high word as the slot before")
         // and the low words by slot in exch[] -- so the work is done by whichever thread is convenient, not by the slots'
         // owners:
-        //   1. thread t inspects the 32 slots of runbits word t: a misordered neighbour pair inside a run marks the
-        //      run's head (nearest clear bit to the left) in dirtybits;
+        //   1. a misordered neighbour pair inside a run marks the run's head (nearest clear bit to the left) in dirtybits;
         //   2. the thread whose word holds a DIRTY head re-sorts the run: up to WALK + 1 slots by itself (stable counting
         //      sort; the usual case is a pair), leaving every member's move as a signed byte in delta[]; a longer run
         //      (up to 2 T slots) goes on a short list;
@@ -521,22 +527,25 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             if (t == 0) { misc[12] = 0u; misc[13] = 0u; }
         }
         __syncthreads();
+        // 1. every owner compares its slot's low word with the left neighbour's (consecutive lanes, consecutive LDS words: the walk
+        //    over a runbits word by ONE thread read slots 32 t + k -- one bank for the whole wave -- and cost 25 us per row on rows
+        //    with long runs of equal keys, BM25's zeros)
         bool anybad = false;
-        if (t < NWORDS) {
-            const uint32_t b = runbits[t], bn = (t + 1 < NWORDS) ? runbits[t + 1] : 0u;
-            uint32_t cont = (b >> 1) | (bn << 31);             // bit k: slot 32 t + k + 1 continues the run of slot 32 t + k
-            while (cont) {
-                const int k = __builtin_ctz(cont);
-                cont &= cont - 1;
-                const int p = 32 * t + k;
-                if (exch[p] > exch[p + 1]) {                   // out of order in the low word
-                    anybad = true;
-                    int wd = t;
-                    uint32_t z = ~b & ((2u << k) - 1u);        // clear bits at or below slot p in this word (k = 31: all of it)
-                    while (z == 0u) { --wd; z = ~runbits[wd]; }   // terminates: slot 0 never continues a run
-                    const int h = wd * 32 + 31 - __builtin_clz(z);
-                    atomicOr(&dirtybits[h >> 5], 1u << (h & 31));
-                }
+        SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int p = (slot0 + i * 64);
+            const bool cont = (contm >> i) & 1u;
+            if (__ballot(cont) == 0ull) continue;              // wave-uniform: nobody in this item continues a run
+            const uint32_t prev = exch[p > 0 ? p - 1 : 0];
+            if (cont && prev > ks[i]) {                        // out of order in the low word (rare): mark the run's head
+                anybad = true;
+                const int q = p - 1;                           // the head is the nearest clear runbit at or below slot q
+                int wd = q >> 5;
+                uint32_t z = ~runbits[wd] & ((2u << (q & 31)) - 1u);
+                while (z == 0u) { --wd; z = ~runbits[wd]; }    // terminates: slot 0 never continues a run
+                const int h = wd * 32 + 31 - __builtin_clz(z);
+                atomicOr(&dirtybits[h >> 5], 1u << (h & 31));
             }
         }
         if (__syncthreads_or(anybad ? 1 : 0)) {
