@@ -14,6 +14,8 @@ namespace fz {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
 // Reductions across the four 16-lane groups of a wave on the VALU (common.h: swap16 / swap32) instead of two ds_bpermute
 // round trips through the LDS pipe: every lane ends up with the result of its column.
@@ -41,6 +43,7 @@ struct AttnArgs {
     float* out;  // [T][ldo]
     int ldo;
     float scale_log2e;   // scale * log2(e): softmax runs in the base-2 domain
+    _Float16* out16;     // non-null: the context rows go out as float16 instead ([T][ldo] halves: the next Linear's operand in the mixed-precision forward)
 };
 
 #define FZ_ATTN_NQ 2   // 16-query sub-strips per wave; the strip table is cut every 16 * FZ_ATTN_NQ queries
@@ -169,21 +172,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(my + r * ATT_LDT + 16 * kg + 4 * g) =
                 make_float4(o[u][0][g] * inv, o[u][1][g] * inv, o[u][2][g] * inv, o[u][3][g] * inv);
-        float* const op = a.out + (size_t)(tok0 + q0 + 16 * u) * a.ldo + h * 64 + r * 4;
+        const size_t o0 = (size_t)(tok0 + q0 + 16 * u) * a.ldo + h * 64 + r * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 4 * i + kg;
             const float4 t4 = *reinterpret_cast<const float4*>(my + row * ATT_LDT + r * 4);
-            if (q0 + 16 * u + row < L) *reinterpret_cast<float4*>(op + (size_t)row * a.ldo) = t4;
+            if (q0 + 16 * u + row < L) {
+                if (a.out16) *reinterpret_cast<h4v*>(a.out16 + o0 + (size_t)row * a.ldo) = h4v{(_Float16)t4.x, (_Float16)t4.y, (_Float16)t4.z, (_Float16)t4.w};
+                else *reinterpret_cast<float4*>(a.out + o0 + (size_t)row * a.ldo) = t4;
+            }
         }
     }
 }
 
-// LayerNorm(x + res) * gamma + beta; one wave per row, VPL float4 per lane (d <= 256 * VPL)
-template <int VPL>
-__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ res, int ldr,
+// LayerNorm(x + res) * gamma + beta; one wave per row, VPL float4 per lane (d <= 256 * VPL).  XH: x is float16 (a mixed-precision Linear's
+// output; the sum and the normalisation are float32 all the same); out16 non-null: the result is stored a second time as float16, the
+// operand of the next Linear (the float32 copy stays the residual stream).
+template <int VPL, bool XH>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const void* __restrict__ xv, int ldx, const float* __restrict__ res, int ldr,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                            int rows, int d, float* __restrict__ out, int ldo) {
+                                                            int rows, int d, float* __restrict__ out, int ldo, _Float16* __restrict__ out16, int ldo16) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const int nv = d >> 2;
@@ -194,8 +202,14 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
         const int c = i * 64 + lane;
         if (c < nv) {
             typedef float f4v __attribute__((ext_vector_type(4)));   // both inputs are streamed once: non-temporal loads
-            const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(x + (size_t)row * ldx) + c);
-            float4 t = make_float4(tv.x, tv.y, tv.z, tv.w);
+            float4 t;
+            if (XH) {
+                const h4v tv = __builtin_nontemporal_load(reinterpret_cast<const h4v*>(reinterpret_cast<const _Float16*>(xv) + (size_t)row * ldx) + c);
+                t = make_float4((float)tv.x, (float)tv.y, (float)tv.z, (float)tv.w);
+            } else {
+                const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(xv) + (size_t)row * ldx) + c);
+                t = make_float4(tv.x, tv.y, tv.z, tv.w);
+            }
             if (res) {
                 const f4v u = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(res + (size_t)row * ldr) + c);
                 t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
             y.z = (v[i].z - mean) * rstd * g.z + b.z;
             y.w = (v[i].w - mean) * rstd * g.w + b.w;
             reinterpret_cast<float4*>(out + (size_t)row * ldo)[c] = y;
+            if (out16) reinterpret_cast<h4v*>(out16 + (size_t)row * ldo16)[c] = h4v{(_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
         }
     }
 }
@@ -244,6 +259,21 @@ __global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, 
         o.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752440f));
         o.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752440f));
         reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+// The same on float16 activations (mixed-precision forward): float32 arithmetic, one rounding on the way out -- what torch.nn.functional.gelu
+// does with a float16 tensor.  8 values per lane and step.
+__global__ __launch_bounds__(256) void gelu_h_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const h8v v = __builtin_nontemporal_load(reinterpret_cast<const h8v*>(x) + i);
+        h8v o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = (float)v[j];
+            o[j] = (_Float16)(0.5f * f * (1.0f + erff(f * 0.70710678118654752440f)));
+        }
+        reinterpret_cast<h8v*>(y)[i] = o;
     }
 }
 
@@ -346,7 +376,24 @@ extern "C" int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strip
     if (ld < 3 * H * 64 || ldo < H * 64) return FZ_ERR_ARG;
     if ((ld & 3) || (ldo & 3) || !aligned16(qkv) || !aligned16(out) || !aligned16(strips)) return FZ_ERR_UNSUPPORTED;
     if ((long long)ld * 4 * 16384 > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;   // in-sequence byte offsets are 32-bit
-    AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(strips), n_strips, H, out, ldo, scale * 1.4426950408889634f};
+    AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(strips), n_strips, H, out, ldo, scale * 1.4426950408889634f, nullptr};
+    const long long grid = (long long)((n_strips + 3) / 4) * H;
+    if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
+    attn_varlen_kernel<FZ_ATTN_NQ><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+extern "C" int fz_attn_varlen_f32_out16(const float* qkv, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
+                                        void* out, int ldo, void* stream) {
+    if (n_strips < 0 || H <= 0 || !(scale > 0.0f)) return FZ_ERR_ARG;
+    if (n_strips == 0) return FZ_OK;
+    if (!qkv || !strips || !out) return FZ_ERR_ARG;
+    if (head_dim != 64) return FZ_ERR_UNSUPPORTED;
+    if (ld < 3 * H * 64 || ldo < H * 64) return FZ_ERR_ARG;
+    if ((ld & 3) || (ldo & 3) || !aligned16(qkv) || (reinterpret_cast<uintptr_t>(out) & 7) || !aligned16(strips)) return FZ_ERR_UNSUPPORTED;
+    if ((long long)ld * 4 * 16384 > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
+    AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(strips), n_strips, H, nullptr, ldo, scale * 1.4426950408889634f, reinterpret_cast<_Float16*>(out)};
     const long long grid = (long long)((n_strips + 3) / 4) * H;
     if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
     attn_varlen_kernel<FZ_ATTN_NQ><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
@@ -366,9 +413,29 @@ extern "C" int fz_add_layernorm_f32(const float* x, int ldx, const float* res, i
     const unsigned grid = (unsigned)((rows + 3) / 4);
     hipStream_t s = as_stream(stream);
     if (d <= 1024)
-        add_layernorm_kernel<4><<<grid, 256, 0, s>>>(x, ldx, res, ldr, gamma, beta, eps, rows, d, out, ldo);
+        add_layernorm_kernel<4, false><<<grid, 256, 0, s>>>(x, ldx, res, ldr, gamma, beta, eps, rows, d, out, ldo, nullptr, 0);
     else
-        add_layernorm_kernel<16><<<grid, 256, 0, s>>>(x, ldx, res, ldr, gamma, beta, eps, rows, d, out, ldo);
+        add_layernorm_kernel<16, false><<<grid, 256, 0, s>>>(x, ldx, res, ldr, gamma, beta, eps, rows, d, out, ldo, nullptr, 0);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+extern "C" int fz_add_layernorm_x16(const void* x, int ldx, const float* res, int ldr, const float* gamma, const float* beta, float eps,
+                                    int rows, int d, float* out, int ldo, void* out16v, int ldo16, void* stream) {
+    _Float16* out16 = reinterpret_cast<_Float16*>(out16v);
+    if (rows < 0 || d <= 0) return FZ_ERR_ARG;
+    if (rows == 0) return FZ_OK;
+    if (!x || !gamma || !beta || !out) return FZ_ERR_ARG;
+    if (ldx < d || ldo < d || (res && ldr < d) || (out16 && ldo16 < d)) return FZ_ERR_ARG;
+    if ((d & 3) || (ldx & 3) || (ldo & 3) || (res && (ldr & 3)) || (out16 && (ldo16 & 3)) || d > 4096 || (reinterpret_cast<uintptr_t>(x) & 7) ||
+        !aligned16(out) || !aligned16(gamma) || !aligned16(beta) || (res && !aligned16(res)) || (out16 && (reinterpret_cast<uintptr_t>(out16) & 7)))
+        return FZ_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    hipStream_t s = as_stream(stream);
+    if (d <= 1024)
+        add_layernorm_kernel<4, true><<<grid, 256, 0, s>>>(x, ldx, res, ldr, gamma, beta, eps, rows, d, out, ldo, out16, ldo16);
+    else
+        add_layernorm_kernel<16, true><<<grid, 256, 0, s>>>(x, ldx, res, ldr, gamma, beta, eps, rows, d, out, ldo, out16, ldo16);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }
@@ -380,6 +447,19 @@ extern "C" int fz_gelu_f32(const float* x, float* y, size_t count, void* stream)
     const size_t n4 = count >> 2;
     const size_t blocks = (n4 + 255) / 256;
     gelu_kernel<<<(unsigned)(blocks < 256 * 32 ? blocks : 256 * 32), 256, 0, as_stream(stream)>>>(x, y, n4);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+extern "C" int fz_gelu_f16(const void* xv, void* yv, size_t count, void* stream) {
+    const _Float16* x = reinterpret_cast<const _Float16*>(xv);
+    _Float16* y = reinterpret_cast<_Float16*>(yv);
+    if (count == 0) return FZ_OK;
+    if (!x || !y) return FZ_ERR_ARG;
+    if ((count & 7) || !aligned16(x) || !aligned16(y)) return FZ_ERR_UNSUPPORTED;
+    const size_t n8 = count >> 3;
+    const size_t blocks = (n8 + 255) / 256;
+    gelu_h_kernel<<<(unsigned)(blocks < 256 * 32 ? blocks : 256 * 32), 256, 0, as_stream(stream)>>>(x, y, n8);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

@@ -226,6 +226,47 @@ class PackedBertForward(FusedBertForward):
     head_dim must be 64 (BERT-base family)."""
 
     ROW_GRANULE = 512
+    # Mixed precision as torch.autocast applies it to a BERT forward (what colbert-ai's Checkpoint wraps every query() / doc() in):
+    # the Linears take float16 operands (float32 accumulate on the matrix pipe); everything between them -- attention, GELU,
+    # residual + LayerNorm -- stays in float32 here (autocast keeps LayerNorm and softmax in float32 and lets GELU follow its float16
+    # input: this forward is never less precise than that).  None = float32 Linears.
+    amp_dtype = None
+
+    def _low(self, t: torch.Tensor) -> torch.Tensor:
+        """The weight / bias in amp_dtype, converted once."""
+        cache = self.__dict__.setdefault("_low_cache", {})
+        key = (id(t), self.amp_dtype)
+        if key not in cache:
+            cache[key] = (t, t.detach().to(self.amp_dtype))      # keeps `t` alive: ids are not reused
+        return cache[key][1]
+
+    def _linear(self, x, w, b):
+        if self.amp_dtype is None:
+            return torch.nn.functional.linear(x, w, b)
+        return torch.nn.functional.linear(x.to(self.amp_dtype), self._low(w), self._low(b)).float()
+
+    def _layers_f16(self, x, ctx, strips_d, H, mark):
+        """The encoder layers with float16 Linears end to end: every Linear takes a float16 operand written by the kernel in front of it
+        (attention, residual + LayerNorm and GELU emit it next to / instead of their float32 result) and returns float16, as under
+        autocast; the residual stream, the attention arithmetic and the normalisations are float32.  One conversion pass is left per layer
+        (the fused-QKV rows, which the attention kernel reads as float32)."""
+        from . import ops
+        F = torch.nn.functional
+        lo = self._low
+        x16 = x.to(torch.float16)
+        ctx16 = torch.empty(ctx.shape, dtype=torch.float16, device=x.device)
+        if ctx16.shape[0] != 0:
+            ctx16.copy_(ctx)                       # the pad rows' zeros
+        for ly in self.layers:
+            qkv = F.linear(x16, lo(ly["wqkv"]), lo(ly["bqkv"])).float(); mark("encode_gemm")
+            ops.attn_varlen_out16(qkv, strips_d, H, ctx16); mark("encode_attn")
+            y16 = F.linear(ctx16, lo(ly["wo"]), lo(ly["bo"])); mark("encode_gemm")
+            x = ops.add_layernorm_x16(y16, x, *ly["ln1"], out16=x16); mark("encode_ln")
+            h16 = F.linear(x16, lo(ly["w1"]), lo(ly["b1"])); mark("encode_gemm")
+            ops.gelu_f16_(h16); mark("encode_gelu")
+            y16 = F.linear(h16, lo(ly["w2"]), lo(ly["b2"])); mark("encode_gemm")
+            x = ops.add_layernorm_x16(y16, x, *ly["ln2"], out16=x16); mark("encode_ln")
+        return x
 
     @staticmethod
     def supports(config) -> bool:
@@ -272,14 +313,16 @@ class PackedBertForward(FusedBertForward):
             ctx[T:].zero_()
         mark = mark or (lambda name: None)
         mark("encode_embed")
+        if self.amp_dtype == torch.float16 and self.word.shape[1] % 8 == 0 and self.layers[0]["w1"].shape[0] % 8 == 0:
+            return self._layers_f16(x, ctx, strips_d, H, mark)[:T], cu_d
         for ly in self.layers:
-            qkv = F.linear(x, ly["wqkv"], ly["bqkv"]); mark("encode_gemm")
+            qkv = self._linear(x, ly["wqkv"], ly["bqkv"]); mark("encode_gemm")
             ops.attn_varlen(qkv, strips_d, H, out=ctx); mark("encode_attn")
-            y = F.linear(ctx, ly["wo"], ly["bo"]); mark("encode_gemm")
+            y = self._linear(ctx, ly["wo"], ly["bo"]); mark("encode_gemm")
             x = ops.add_layernorm(y, x, *ly["ln1"]); mark("encode_ln")
-            h = F.linear(x, ly["w1"], ly["b1"]); mark("encode_gemm")
+            h = self._linear(x, ly["w1"], ly["b1"]); mark("encode_gemm")
             h = ops.gelu_(h); mark("encode_gelu")                   # in place, non-temporal loads
-            y = F.linear(h, ly["w2"], ly["b2"]); mark("encode_gemm")
+            y = self._linear(h, ly["w2"], ly["b2"]); mark("encode_gemm")
             x = ops.add_layernorm(y, x, *ly["ln2"]); mark("encode_ln")
         return x[:T], cu_d
 
@@ -446,9 +489,13 @@ class ColbertEncoder(_Base):
     dim = 128
 
     def __init__(self, backbone, tokenizer, device, punct_ids: tuple[int, ...] = (), linear_weight: torch.Tensor | None = None,
-                 q_marker_id: int | None = None, d_marker_id: int | None = None, attend_to_mask_tokens: bool = True):
+                 q_marker_id: int | None = None, d_marker_id: int | None = None, attend_to_mask_tokens: bool = True, amp: bool = True):
         super().__init__(tokenizer, device)
         self.backbone = backbone.to(self._device).eval()
+        # colbert-ai encodes under mixed precision: Checkpoint wraps query() / doc() in its MixedPrecisionManager's autocast context, and the
+        # repository's ColBERT runs set 'amp': True (multi_dense_biencoder.py:55; colbert_ir.py:110,124 for the training forward).  On a GPU
+        # the Linears of the backbone therefore take float16 operands (fp32 accumulate); amp=False keeps the whole forward in float32.
+        self.amp = bool(amp) and self._device.type == "cuda"
         if linear_weight is not None:
             self.dim = int(linear_weight.shape[0])
         self.linear = nn.Linear(backbone.config.hidden_size, self.dim, bias=False).to(self._device)
@@ -461,6 +508,12 @@ class ColbertEncoder(_Base):
         self.punct_ids = torch.tensor(list(punct_ids), dtype=torch.long, device=self._device)
         self.q_marker_id, self.d_marker_id, self.attend_to_mask_tokens = q_marker_id, d_marker_id, attend_to_mask_tokens
 
+    def _packed_forward(self, backbone):
+        fwd = super()._packed_forward(backbone)
+        if fwd is not None:
+            fwd.amp_dtype = torch.float16 if self.amp else None
+        return fwd
+
     def _marked(self, texts: list[str], max_len: int, marker_id: int | None, pad_to_max: bool):
         """colbert-ai tensorize(): '. ' + text, tokenise, ids[:, 1] = marker."""
         if marker_id is None:
@@ -471,8 +524,9 @@ class ColbertEncoder(_Base):
 
     @torch.no_grad()
     def _tokens(self, ids, mask):
-        h = self.backbone(input_ids=ids, attention_mask=mask).last_hidden_state
-        v = self.linear(h)
+        with torch.autocast(self._device.type, dtype=torch.float16, enabled=self.amp):      # the HF module as colbert-ai runs it
+            h = self.backbone(input_ids=ids, attention_mask=mask).last_hidden_state
+            v = self.linear(h)
         return torch.nn.functional.normalize(v.float(), p=2, dim=-1)
 
     @torch.no_grad()
@@ -663,7 +717,7 @@ def from_pretrained(model_name_or_path: str, kind: str, device="cuda"):
                              linear_weight=lin,
                              q_marker_id=hf_tok.convert_tokens_to_ids(meta.get("query_token_id", "[unused0]")),
                              d_marker_id=hf_tok.convert_tokens_to_ids(meta.get("doc_token_id", "[unused1]")),
-                             attend_to_mask_tokens=bool(meta.get("attend_to_mask_tokens", True)))
+                             attend_to_mask_tokens=bool(meta.get("attend_to_mask_tokens", True)), amp=bool(meta.get("amp", True)))
         enc.max_query_length = min(enc.max_query_length, int(meta.get("query_maxlen", enc.max_query_length)))   # hybrid.py:129 passes 64 / 512
         enc.max_doc_length = min(enc.max_doc_length, int(meta.get("doc_maxlen", enc.max_doc_length)))
         return enc

@@ -905,6 +905,57 @@ def attn_varlen(qkv: torch.Tensor, strips: torch.Tensor, heads: int, scale: floa
     return out
 
 
+def attn_varlen_out16(qkv: torch.Tensor, strips: torch.Tensor, heads: int, out: torch.Tensor) -> torch.Tensor:
+    """attn_varlen with the context rows stored as float16 (`out` [T, heads*64] float16, contiguous rows): the operand of the output
+    projection in the mixed-precision forward."""
+    _dev(qkv, torch.float32, "attn_varlen_out16(qkv)")
+    _dev(strips, torch.int32, "attn_varlen_out16(strips)")
+    _dev(out, torch.float16, "attn_varlen_out16(out)")
+    T, W = qkv.shape
+    if W != 3 * heads * 64:
+        raise ValueError(f"attn_varlen_out16: qkv is {W} wide, expected 3*{heads}*64 (head_dim 64 only)")
+    if strips.dim() != 2 or strips.shape[1] != 4 or not strips.is_contiguous():
+        raise ValueError("attn_varlen_out16: strips must be a contiguous [n_strips, 4] int32 tensor (ops.attn_strips)")
+    _need(tuple(out.shape) == (T, heads * 64), f"attn_varlen_out16(out): expected shape {(T, heads * 64)}, got {tuple(out.shape)}")
+    check(_lib.lib().fz_attn_varlen_f32_out16(_ptr(qkv), qkv.stride(0) if T > 1 else W, _ptr(strips), strips.shape[0], heads, 64, float(64 ** -0.5),
+                                              _ptr(out), out.stride(0) if T > 1 else heads * 64, _stream(qkv)), "fz_attn_varlen_f32_out16")
+    return out
+
+
+def add_layernorm_x16(x16: torch.Tensor, res: torch.Tensor | None, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                      out: torch.Tensor | None = None, out16: torch.Tensor | None = None):
+    """LayerNorm(x16 + res) with a float16 x (a mixed-precision Linear's output), float32 residual and result; out16 (float16, same
+    shape) receives a second, rounded copy of the result.  -> out."""
+    _dev(x16, torch.float16, "add_layernorm_x16(x16)")
+    rows, d = x16.shape
+    if res is not None:
+        _dev(res, torch.float32, "add_layernorm_x16(res)")
+        if res.shape != x16.shape:
+            raise ValueError("add_layernorm_x16: x16 and res differ in shape")
+    _need(gamma.numel() == d and beta.numel() == d and gamma.is_contiguous() and beta.is_contiguous(), f"add_layernorm_x16: gamma and beta must hold {d} values")
+    if out is None:
+        out = torch.empty((rows, d), dtype=torch.float32, device=x16.device)
+    else:
+        _dev(out, torch.float32, "add_layernorm_x16(out)")
+        _need(tuple(out.shape) == (rows, d), f"add_layernorm_x16(out): expected shape {(rows, d)}, got {tuple(out.shape)}")
+    if out16 is not None:
+        _dev(out16, torch.float16, "add_layernorm_x16(out16)")
+        _need(tuple(out16.shape) == (rows, d), f"add_layernorm_x16(out16): expected shape {(rows, d)}, got {tuple(out16.shape)}")
+    ldr = 0 if res is None else (res.stride(0) if rows > 1 else d)
+    check(_lib.lib().fz_add_layernorm_x16(_ptr(x16), x16.stride(0) if rows > 1 else d, _ptr(res), ldr, _ptr(_dev(gamma, torch.float32, "gamma")),
+                                          _ptr(_dev(beta, torch.float32, "beta")), float(eps), rows, d, _ptr(out), out.stride(0) if rows > 1 else d,
+                                          _ptr(out16), 0 if out16 is None else (out16.stride(0) if rows > 1 else d), _stream(x16)), "fz_add_layernorm_x16")
+    return out
+
+
+def gelu_f16_(x: torch.Tensor) -> torch.Tensor:
+    """In-place erf-GELU of a contiguous float16 tensor (float32 arithmetic, one rounding: torch.nn.functional.gelu on float16)."""
+    _dev(x, torch.float16, "gelu_f16_(x)")
+    _need(x.is_contiguous() and x.numel() % 8 == 0, "gelu_f16_: contiguous tensor with a multiple of 8 elements")
+    check(_lib.lib().fz_gelu_f16(_ptr(x), _ptr(x), x.numel(), _stream(x)), "fz_gelu_f16")
+    return x
+
+
 def add_layernorm(x: torch.Tensor, res: torch.Tensor | None, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor | None = None):
     """LayerNorm(x + res) over the last dimension, fp32, one HBM pass."""
     _dev(x, torch.float32, "add_layernorm(x)")

@@ -394,3 +394,60 @@ def test_bm25_slice_offsets_change_nothing_but_the_time(ops, oracle):
     without = ours.scores(queries).cpu().numpy()
     np.testing.assert_array_equal(with_table, without)
     np.testing.assert_array_equal(with_table, oracle.BM25(docs, 2.5, 0.2).scores(queries))
+
+
+# ---- mixed-precision encoder forward (ColBERT: colbert-ai's autocast) ------------------------------------------------------------------
+def test_f16_encoder_kernels_vs_torch(ops):
+    """fz_add_layernorm_x16 / fz_gelu_f16 / fz_attn_varlen_f32_out16 against torch on the same float16 values."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    F = torch.nn.functional
+    for rows, d in ((1, 128), (37, 768), (5, 2048)):
+        x16 = (torch.randn((rows, d), generator=g, device="cuda") * 2).half()
+        res = torch.randn((rows, d), generator=g, device="cuda")
+        gamma, beta = torch.rand(d, generator=g, device="cuda") + 0.5, torch.randn(d, generator=g, device="cuda")
+        out16 = torch.empty((rows, d), dtype=torch.float16, device="cuda")
+        out = ops.add_layernorm_x16(x16, res, gamma, beta, 1e-5, out16=out16)
+        ref = F.layer_norm(x16.float() + res, (d,), gamma, beta, 1e-5)
+        assert (out - ref).abs().max().item() <= 2e-5
+        assert torch.equal(out16, out.half())
+        assert torch.equal(ops.add_layernorm_x16(x16, None, gamma, beta, 1e-5), ops.add_layernorm(x16.float(), None, gamma, beta, 1e-5))
+    for n in (8, 4096, 3072 * 37):
+        h = (torch.randn(n, generator=g, device="cuda") * 3).half()
+        ref = F.gelu(h.float()).half()
+        got = ops.gelu_f16_(h.clone())
+        # one float16 rounding of the float32 value: at most one unit in the last place from torch's (erff implementations differ in the last float32 bit)
+        assert ((got.float() - ref.float()).abs() <= 2.0 ** -10 * ref.float().abs().clamp_min(2.0 ** -14)).all()
+    lengths = np.array([5, 64, 1, 33, 17])
+    strips, cu = ops.attn_strips(lengths)
+    T = int(cu[-1])
+    qkv = torch.randn((T, 3 * 2 * 64), generator=g, device="cuda")
+    strips_d = torch.from_numpy(strips).cuda()
+    ctx = ops.attn_varlen(qkv, strips_d, 2)
+    ctx16 = torch.zeros((T, 128), dtype=torch.float16, device="cuda")
+    ops.attn_varlen_out16(qkv, strips_d, 2, ctx16)
+    assert torch.equal(ctx16, ctx.half())
+
+
+def test_colbert_mixed_precision_forward_matches_fp32_and_autocast():
+    """ColbertEncoder(amp=True): float16 Linears in the padding-free forward (float32 everywhere else) -- token vectors within float16
+    rounding of the float32 forward's, and of the HF module under torch.autocast (what colbert-ai runs)."""
+    from fusion_amd import encoders
+    cfg = dict(encoders.TINY, hidden_size=128, num_attention_heads=2, intermediate_size=256)
+    rng = np.random.default_rng(5)
+    texts = [" ".join(f"w{rng.integers(0, 40)}" for _ in range(int(k))) for k in rng.integers(1, 90, size=23)]
+    tok = encoders.HashTokenizer(cfg["vocab_size"])
+    torch.manual_seed(2)
+    backbone = encoders._backbone(cfg)
+    a = encoders.ColbertEncoder(backbone, tok, "cuda", amp=True)
+    b = encoders.ColbertEncoder(backbone, tok, "cuda", amp=False)
+    b.linear.load_state_dict(a.linear.state_dict())
+    Qa, Qb = a.encode_queries(texts[:7]).float(), b.encode_queries(texts[:7]).float()
+    assert a._packed.amp_dtype == torch.float16 and b._packed_forward(b.backbone).amp_dtype is None
+    a._packed_forward(a.backbone)
+    assert (Qa - Qb).abs().max().item() <= 4e-3
+    (Da, Oa), (Db, Ob) = a.encode_docs(texts), b.encode_docs(texts)
+    assert torch.equal(Oa, Ob) and (Da.float() - Db.float()).abs().max().item() <= 4e-3
+    for i, t in enumerate(texts[:5]):      # the HF module under autocast
+        ids1, m1 = tok([t], a.max_doc_length)
+        ref = a._tokens(ids1.cuda(), m1.cuda())[0]
+        assert (Da[int(Oa[i]): int(Oa[i + 1])].float() - ref).abs().max().item() <= 6e-3
