@@ -86,7 +86,7 @@ _PROTOS = {
     "fz_attn_varlen_f32": (_i, [_vp, _i, _vp, _i, _i, _i, C.c_float, _vp, _i, _vp]),
     "fz_add_layernorm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, C.c_float, _i, _i, _vp, _i, _vp]),
     "fz_gelu_f32": (_i, [_vp, _vp, _sz, _vp]),
-    "fz_attn_varlen_f32_out16": (_i, [_vp, _i, _vp, _i, _i, _i, C.c_float, _vp, _i, _vp]),
+    "fz_attn_varlen_f16": (_i, [_vp, _i, _vp, _i, _i, _i, C.c_float, _vp, _i, _vp]),
     "fz_add_layernorm_x16": (_i, [_vp, _i, _vp, _i, _vp, _vp, C.c_float, _i, _i, _vp, _i, _vp, _i, _vp]),
     "fz_gelu_f16": (_i, [_vp, _vp, _sz, _vp]),
     "fz_embed_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i, _i, _vp, _i, _vp]),

@@ -14,6 +14,7 @@ namespace fz {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
@@ -35,7 +36,7 @@ __device__ __forceinline__ float xgroup_sum(float x) {
 }
 
 struct AttnArgs {
-    const float* qkv;   // [T][ld]: q | k | v, each H*64 wide
+    const void* qkv;    // [T][ld]: q | k | v, each H*64 wide; float32, or float16 in the QH instantiation
     int ld;
     const int4* strips;  // (first row of the sequence, its length L, first query of this strip of <= 16 * FZ_ATTN_NQ queries, unused)
     int n_strips;
@@ -70,8 +71,11 @@ struct AttnArgs {
 //   O^T step i takes register i of S^T (key 4(l/16) + i of the tile) against V[that key][4 (l%16) + t] (output tile t = dims 4 r + t).
 // NQ = 16-query sub-strips per wave.  NQ = 2: every K/V tile a wave loads serves 32 queries -- half the re-reads of the
 // sequence's K/V rows through the load path (the kernel's bound, see above) for 112 instead of 72 VGPRs.
-template <int NQ>
+// QH: the fused-QKV rows are float16 (the mixed-precision forward's Linear output): same lane -> element map, 8-byte loads, converted on the way
+// into LDS / the V registers; the arithmetic is the float32 kernel's.
+template <int NQ, bool QH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7 : 4, 8))) void attn_varlen_kernel(AttnArgs a) {
+    constexpr int ES = QH ? 2 : 4;   // bytes per qkv element
     __shared__ __attribute__((aligned(16))) float lds[4 * 16 * ATT_LDT];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int grp = blockIdx.x / a.H;
@@ -83,23 +87,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7
     if (q0 >= L) return;
     const int r = lane & 15, kg = lane >> 4;
     const int hid = a.H * 64;
-    const int ldb = a.ld * 4;   // row pitch in bytes
+    const int ldb = a.ld * ES;   // row pitch in bytes
     // one descriptor per wave: base = the sequence's first row, this head's q columns; range = the sequence
-    const float* base = a.qkv + (size_t)tok0 * a.ld + h * 64;
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (L * a.ld - h * 64) * 4, 0x00020000);
+    const char* base = reinterpret_cast<const char*>(a.qkv) + ((size_t)tok0 * a.ld + h * 64) * ES;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (L * a.ld - h * 64) * ES, 0x00020000);
 
     float* my = lds + wave * (16 * ATT_LDT);
-    const int voff_t = kg * ldb + r * 16;                 // tile load: lane = (row kg of 4, float4 r of 16) per instruction
+    const int voff_t = kg * ldb + r * (4 * ES);           // tile load: lane = (row kg of 4, elements 4 r .. 4 r + 3 of the head's 64) per instruction
     float* const wr = my + kg * ATT_LDT + r * 4;
     const float* const rd = my + r * ATT_LDT + kg * 16;
-    const int voff_v = (4 * kg) * ldb + r * 16;
+    const int voff_v = (4 * kg) * ldb + r * (4 * ES);
 
     auto load_tile = [&](int row0, int col_bytes, float (&f)[16]) {   // rows row0..row0+15 -> f[i] = [row r][16 kg + i]
-        i32x4 raw[4];
+        if constexpr (QH) {
+            i32x2 raw[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_t, (row0 + 4 * i) * ldb + col_bytes, 0);
+            for (int i = 0; i < 4; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff_t, (row0 + 4 * i) * ldb + col_bytes, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(wr + 4 * i * ATT_LDT) = raw[i];
+            for (int i = 0; i < 4; ++i) {
+                const h4v hv = __builtin_bit_cast(h4v, raw[i]);
+                *reinterpret_cast<float4*>(wr + 4 * i * ATT_LDT) = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
+            }
+        } else {
+            i32x4 raw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_t, (row0 + 4 * i) * ldb + col_bytes, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(wr + 4 * i * ATT_LDT) = raw[i];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float4 t = *reinterpret_cast<const float4*>(rd + 4 * i);
@@ -122,12 +137,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7
     for (int j0 = 0; j0 < L; j0 += 16) {
         float kf[16];
         f32x4 v[4];      // [step]; component t feeds dim tile t
-        load_tile(j0, hid * 4, kf);
+        load_tile(j0, hid * ES, kf);
         // V: one 16-byte load per key and lane -- lane (r, kg) takes dims 4r..4r+3 of key 4 kg + i, i.e. output tile t holds the
         // dims 4 r + t (any assignment of dims to MFMA rows is as good as another; this one reads whole 256-B head rows)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_v, (j0 + i) * ldb + 2 * hid * 4, 0));
+            if constexpr (QH) {
+                const h4v hv = __builtin_bit_cast(h4v, __builtin_amdgcn_raw_buffer_load_b64(rs, voff_v, (j0 + i) * ldb + 2 * hid * ES, 0));
+                v[i] = f32x4{(float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w};
+            } else {
+                v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_v, (j0 + i) * ldb + 2 * hid * 4, 0));
+            }
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             if (u == 1 && !second) break;
@@ -379,24 +399,24 @@ extern "C" int fz_attn_varlen_f32(const float* qkv, int ld, const int32_t* strip
     AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(strips), n_strips, H, out, ldo, scale * 1.4426950408889634f, nullptr};
     const long long grid = (long long)((n_strips + 3) / 4) * H;
     if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
-    attn_varlen_kernel<FZ_ATTN_NQ><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
+    attn_varlen_kernel<FZ_ATTN_NQ, false><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }
 
-extern "C" int fz_attn_varlen_f32_out16(const float* qkv, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
-                                        void* out, int ldo, void* stream) {
+extern "C" int fz_attn_varlen_f16(const void* qkv, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
+                                 void* out, int ldo, void* stream) {
     if (n_strips < 0 || H <= 0 || !(scale > 0.0f)) return FZ_ERR_ARG;
     if (n_strips == 0) return FZ_OK;
     if (!qkv || !strips || !out) return FZ_ERR_ARG;
     if (head_dim != 64) return FZ_ERR_UNSUPPORTED;
     if (ld < 3 * H * 64 || ldo < H * 64) return FZ_ERR_ARG;
-    if ((ld & 3) || (ldo & 3) || !aligned16(qkv) || (reinterpret_cast<uintptr_t>(out) & 7) || !aligned16(strips)) return FZ_ERR_UNSUPPORTED;
-    if ((long long)ld * 4 * 16384 > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
+    if ((ld & 3) || (ldo & 3) || (reinterpret_cast<uintptr_t>(qkv) & 7) || (reinterpret_cast<uintptr_t>(out) & 7) || !aligned16(strips)) return FZ_ERR_UNSUPPORTED;
+    if ((long long)ld * 2 * 16384 > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
     AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(strips), n_strips, H, nullptr, ldo, scale * 1.4426950408889634f, reinterpret_cast<_Float16*>(out)};
     const long long grid = (long long)((n_strips + 3) / 4) * H;
     if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
-    attn_varlen_kernel<FZ_ATTN_NQ><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
+    attn_varlen_kernel<FZ_ATTN_NQ, true><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

@@ -248,8 +248,7 @@ class PackedBertForward(FusedBertForward):
     def _layers_f16(self, x, ctx, strips_d, H, mark):
         """The encoder layers with float16 Linears end to end: every Linear takes a float16 operand written by the kernel in front of it
         (attention, residual + LayerNorm and GELU emit it next to / instead of their float32 result) and returns float16, as under
-        autocast; the residual stream, the attention arithmetic and the normalisations are float32.  One conversion pass is left per layer
-        (the fused-QKV rows, which the attention kernel reads as float32)."""
+        autocast; the residual stream, the attention arithmetic and the normalisations are float32.  No conversion pass anywhere."""
         from . import ops
         F = torch.nn.functional
         lo = self._low
@@ -258,8 +257,8 @@ class PackedBertForward(FusedBertForward):
         if ctx16.shape[0] != 0:
             ctx16.copy_(ctx)                       # the pad rows' zeros
         for ly in self.layers:
-            qkv = F.linear(x16, lo(ly["wqkv"]), lo(ly["bqkv"])).float(); mark("encode_gemm")
-            ops.attn_varlen_out16(qkv, strips_d, H, ctx16); mark("encode_attn")
+            qkv16 = F.linear(x16, lo(ly["wqkv"]), lo(ly["bqkv"])); mark("encode_gemm")
+            ops.attn_varlen_f16(qkv16, strips_d, H, ctx16); mark("encode_attn")
             y16 = F.linear(ctx16, lo(ly["wo"]), lo(ly["bo"])); mark("encode_gemm")
             x = ops.add_layernorm_x16(y16, x, *ly["ln1"], out16=x16); mark("encode_ln")
             h16 = F.linear(x16, lo(ly["w1"]), lo(ly["b1"])); mark("encode_gemm")

@@ -905,20 +905,20 @@ def attn_varlen(qkv: torch.Tensor, strips: torch.Tensor, heads: int, scale: floa
     return out
 
 
-def attn_varlen_out16(qkv: torch.Tensor, strips: torch.Tensor, heads: int, out: torch.Tensor) -> torch.Tensor:
-    """attn_varlen with the context rows stored as float16 (`out` [T, heads*64] float16, contiguous rows): the operand of the output
-    projection in the mixed-precision forward."""
-    _dev(qkv, torch.float32, "attn_varlen_out16(qkv)")
-    _dev(strips, torch.int32, "attn_varlen_out16(strips)")
-    _dev(out, torch.float16, "attn_varlen_out16(out)")
-    T, W = qkv.shape
+def attn_varlen_f16(qkv16: torch.Tensor, strips: torch.Tensor, heads: int, out: torch.Tensor) -> torch.Tensor:
+    """attn_varlen on float16 fused-QKV rows with the context rows stored as float16 (`out` [T, heads*64] float16): the attention of the
+    mixed-precision forward -- float32 scores, softmax and weighted sum between two float16 Linears."""
+    _dev(qkv16, torch.float16, "attn_varlen_f16(qkv16)")
+    _dev(strips, torch.int32, "attn_varlen_f16(strips)")
+    _dev(out, torch.float16, "attn_varlen_f16(out)")
+    T, W = qkv16.shape
     if W != 3 * heads * 64:
-        raise ValueError(f"attn_varlen_out16: qkv is {W} wide, expected 3*{heads}*64 (head_dim 64 only)")
+        raise ValueError(f"attn_varlen_f16: qkv is {W} wide, expected 3*{heads}*64 (head_dim 64 only)")
     if strips.dim() != 2 or strips.shape[1] != 4 or not strips.is_contiguous():
-        raise ValueError("attn_varlen_out16: strips must be a contiguous [n_strips, 4] int32 tensor (ops.attn_strips)")
-    _need(tuple(out.shape) == (T, heads * 64), f"attn_varlen_out16(out): expected shape {(T, heads * 64)}, got {tuple(out.shape)}")
-    check(_lib.lib().fz_attn_varlen_f32_out16(_ptr(qkv), qkv.stride(0) if T > 1 else W, _ptr(strips), strips.shape[0], heads, 64, float(64 ** -0.5),
-                                              _ptr(out), out.stride(0) if T > 1 else heads * 64, _stream(qkv)), "fz_attn_varlen_f32_out16")
+        raise ValueError("attn_varlen_f16: strips must be a contiguous [n_strips, 4] int32 tensor (ops.attn_strips)")
+    _need(tuple(out.shape) == (T, heads * 64), f"attn_varlen_f16(out): expected shape {(T, heads * 64)}, got {tuple(out.shape)}")
+    check(_lib.lib().fz_attn_varlen_f16(_ptr(qkv16), qkv16.stride(0) if T > 1 else W, _ptr(strips), strips.shape[0], heads, 64, float(64 ** -0.5),
+                                        _ptr(out), out.stride(0) if T > 1 else heads * 64, _stream(qkv16)), "fz_attn_varlen_f16")
     return out
 
 

@@ -317,11 +317,12 @@ int fz_gelu_f32(const float* x, float* y, size_t count, void* stream);
 /* The same three steps for a MIXED-PRECISION forward -- colbert-ai wraps every query() / doc() of the ColBERT encoder in torch.cuda.amp.autocast
  * (requirements.txt:15; the repository's own ColBERT runs set 'amp': True, multi_dense_biencoder.py:55, and wrap the model in amp.context(),
  * colbert_ir.py:110,124): the Linears take and return float16, these kernels compute in float32 and hand the next Linear its float16 operand.
- *   fz_attn_varlen_f32_out16: as fz_attn_varlen_f32, context rows stored as float16 (out 8-byte aligned, ldo in elements);
+ *   fz_attn_varlen_f16:       as fz_attn_varlen_f32 with float16 fused-QKV rows in and float16 context rows out (8-byte aligned, ld / ldo in
+ *                             elements); scores, softmax and the weighted sum are float32;
  *   fz_add_layernorm_x16:     x float16 (a Linear's output), res / out float32 (the residual stream), out16 nullable: a float16 copy of out;
  *   fz_gelu_f16:              float16 in and out (float32 arithmetic, as torch.nn.functional.gelu on a float16 tensor), count % 8 == 0. */
-int fz_attn_varlen_f32_out16(const float* qkv, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
-                             void* out /* float16 */, int ldo, void* stream);
+int fz_attn_varlen_f16(const void* qkv /* float16 */, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
+                       void* out /* float16 */, int ldo, void* stream);
 int fz_add_layernorm_x16(const void* x /* float16 */, int ldx, const float* res, int ldr, const float* gamma, const float* beta, float eps,
                          int rows, int d, float* out, int ldo, void* out16 /* float16, nullable */, int ldo16, void* stream);
 int fz_gelu_f16(const void* x /* float16 */, void* y /* float16 */, size_t count, void* stream);

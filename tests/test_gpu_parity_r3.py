@@ -398,7 +398,7 @@ def test_bm25_slice_offsets_change_nothing_but_the_time(ops, oracle):
 
 # ---- mixed-precision encoder forward (ColBERT: colbert-ai's autocast) ------------------------------------------------------------------
 def test_f16_encoder_kernels_vs_torch(ops):
-    """fz_add_layernorm_x16 / fz_gelu_f16 / fz_attn_varlen_f32_out16 against torch on the same float16 values."""
+    """fz_add_layernorm_x16 / fz_gelu_f16 / fz_attn_varlen_f16 against torch on the same float16 values."""
     g = torch.Generator(device="cuda").manual_seed(3)
     F = torch.nn.functional
     for rows, d in ((1, 128), (37, 768), (5, 2048)):
@@ -422,9 +422,10 @@ def test_f16_encoder_kernels_vs_torch(ops):
     T = int(cu[-1])
     qkv = torch.randn((T, 3 * 2 * 64), generator=g, device="cuda")
     strips_d = torch.from_numpy(strips).cuda()
-    ctx = ops.attn_varlen(qkv, strips_d, 2)
+    qkv16 = qkv.half()
+    ctx = ops.attn_varlen(qkv16.float(), strips_d, 2)           # the float32 kernel on the same (float16-representable) values
     ctx16 = torch.zeros((T, 128), dtype=torch.float16, device="cuda")
-    ops.attn_varlen_out16(qkv, strips_d, 2, ctx16)
+    ops.attn_varlen_f16(qkv16, strips_d, 2, ctx16)
     assert torch.equal(ctx16, ctx.half())
 
 
