@@ -154,11 +154,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 16; ++i) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[u][i], s, 0, 0, 0);
-            // s[g] = <q_{q0+16u+r}, k_j>, j = j0 + 4 kg + g
-            if (j0 + 16 > L) {   // last, partial tile: keys past the sequence (read as zeros) drop out
+            // s[g] = <q_{q0+16u+r}, k_j>, j = j0 + 4 kg + g.  Keys past the sequence (a last, partial tile: read as zeros) drop out -- as selects
+            // in EVERY tile, not under `if (j0 + 16 > L)`: with the branch hipcc (ROCm 7.2) left the first reader of the MFMA chain's result,
+            // the tile maximum below, at the head of the join block with no wait states behind the branch (tools/check_mfma_hazards.py).  The
+            // maximum then saw the score registers before the last MFMA had written them: harmless (any shift works in a softmax; the
+            // probabilities were computed later, from the finished registers) but different from run to run in the last bits.
+            {
+                const int left = L - (j0 + 4 * kg);
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (j0 + 4 * kg + g >= L) s[g] = -INFINITY;
+                for (int g = 0; g < 4; ++g) s[g] = g < left ? s[g] : -INFINITY;
             }
             float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
             mx = xgroup_max(mx);

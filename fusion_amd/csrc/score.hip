@@ -259,6 +259,12 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
         if (nxt >= 0) point_at(lrow, lcol);
         ktile(KT - 2, 0, KT - 1, r0, r1, EDGE);
         ktile(KT - 1, 1, 0, r1, r0, EDGE);
+        // The epilogues read the accumulators behind branches.  hipcc pads 'MFMA write -> read' inside a basic block, but across a branch it
+        // has been seen to leave a reader too close (tools/check_mfma_hazards.py: attn_varlen_kernel, and 11-17 of the 18 wait states a
+        // 16-pass MFMA needs on some epilogue paths here): one full-length wait per TILE (80 of ~40,000 cycles) makes every path safe.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
+        __builtin_amdgcn_sched_barrier(0);
 
         // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
         if constexpr (EPI == EPI_FILTER) {

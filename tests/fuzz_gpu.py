@@ -440,7 +440,7 @@ _ENC = {}
 def case_encoder(rng):
     """Padding-free forward (HIP attention / residual+LayerNorm / pooling on packed rows) vs the HF module on padded batches."""
     from fusion_amd import encoders
-    if not _ENC:
+    if "dpr" not in _ENC:
         cfg = dict(encoders.TINY, hidden_size=128, num_attention_heads=2, intermediate_size=256)
         torch.manual_seed(0)
         _ENC["dpr"] = encoders.DenseEncoder(encoders._backbone(cfg), encoders.HashTokenizer(cfg["vocab_size"]), "cuda")
@@ -458,6 +458,57 @@ def case_encoder(rng):
     err = (a - b).abs().max().item()
     assert b.shape == a.shape and err <= 5e-5, err
     return f"encoder n={n} Lmax={Lmax} err={err:.1e}"
+
+
+def case_f16_kernels(rng):
+    """The float16 steps of the mixed-precision forward against their float32 twins / torch on the same float16 values."""
+    g = torch.Generator(device="cuda").manual_seed(int(rng.integers(0, 1 << 30)))
+    F = torch.nn.functional
+    rows, d = int(rng.integers(1, 2000)), int(rng.integers(1, 1025) * 4)
+    x16 = (torch.randn((rows, d), generator=g, device="cuda") * 2 + 0.5).half()
+    res = torch.randn((rows, d), generator=g, device="cuda") if rng.random() < 0.7 else None
+    ga, be = torch.randn(d, generator=g, device="cuda"), torch.randn(d, generator=g, device="cuda")
+    o16 = torch.empty((rows, d), dtype=torch.float16, device="cuda") if rng.random() < 0.7 else None
+    y = ops.add_layernorm_x16(x16, res, ga, be, 1e-5, out16=o16)
+    assert torch.equal(y, ops.add_layernorm(x16.float(), res, ga, be, 1e-5))          # same arithmetic on the same values
+    assert o16 is None or torch.equal(o16, y.half())
+    n = int(rng.integers(1, 40000)) * 8
+    h = (torch.randn(n, generator=g, device="cuda") * float(rng.choice([0.5, 3.0, 20.0]))).half()
+    ref = F.gelu(h.float())
+    got = ops.gelu_f16_(h.clone()).float()
+    assert ((got - ref).abs() <= 2.0 ** -10 * ref.abs().clamp_min(2.0 ** -14)).all()
+    H = int(rng.integers(1, 13))
+    lens = rng.integers(1, int(rng.choice([20, 70, 600])), int(rng.integers(1, 12)))
+    T = int(lens.sum())
+    qkv16 = (torch.randn((T, 3 * H * 64), generator=g, device="cuda") * float(rng.choice([0.3, 1.0, 3.0]))).half()
+    strips, _ = ops.attn_strips(lens)
+    sd = torch.from_numpy(strips).cuda()
+    ctx16 = torch.empty((T, H * 64), dtype=torch.float16, device="cuda")
+    ops.attn_varlen_f16(qkv16, sd, H, ctx16)
+    assert torch.equal(ctx16, ops.attn_varlen(qkv16.float(), sd, H).half())
+    return f"f16 kernels rows={rows} d={d} n={n} H={H} lens={lens.tolist()}"
+
+
+def case_encoder_amp(rng):
+    """ColBERT encoder, float16 Linears (the padding-free mixed-precision forward) vs the same encoder in float32."""
+    from fusion_amd import encoders
+    if "cb" not in _ENC:
+        cfg = dict(encoders.TINY, hidden_size=128, num_attention_heads=2, intermediate_size=256)
+        torch.manual_seed(1)
+        _ENC["cb"] = encoders.ColbertEncoder(encoders._backbone(cfg), encoders.HashTokenizer(cfg["vocab_size"]), "cuda", amp=True)
+        _ENC["cb_cfg"] = cfg
+    enc, cfg = _ENC["cb"], _ENC["cb_cfg"]
+    n, Lmax = int(rng.integers(1, 30)), int(rng.integers(1, 120))
+    lens = rng.integers(1, Lmax + 1, n)
+    ids = torch.from_numpy(rng.integers(7, cfg["vocab_size"], size=(n, Lmax))).cuda()
+    enc.amp = True
+    a, oa = enc.encode_doc_ids(ids, lens)
+    enc.amp = False
+    b, ob = enc.encode_doc_ids(ids, lens)
+    enc.amp = True
+    err = (a.float() - b.float()).abs().max().item() if a.numel() else 0.0
+    assert torch.equal(oa, ob) and err <= 5e-3, err
+    return f"encoder amp n={n} Lmax={Lmax} err={err:.1e}"
 
 
 def case_empty(rng):
@@ -482,7 +533,7 @@ def case_empty(rng):
 
 
 CASES = [case_encoder, case_lists, case_empty, case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
-         case_topk_stream, case_segments, case_fused_search, case_sort_stats, case_select, case_splade_head, case_fuse_ranked, case_maxsim]
+         case_topk_stream, case_segments, case_fused_search, case_sort_stats, case_select, case_splade_head, case_fuse_ranked, case_maxsim, case_f16_kernels, case_encoder_amp]
 
 
 def main():

@@ -46,3 +46,23 @@ def test_c_abi_host_side_under_asan_ubsan():
              "tests/test_host_cpu.py::test_integration_md_binding_matches_the_abi", "tests/test_host_cpu.py::test_workspace_planning_is_consistent"]
     rc, out = _run([sys.executable, "-m", "pytest", *tests, "-x", "-q", "-p", "no:cacheprovider"], dict(LD_PRELOAD=rt, FUSION_AMD_LIB=so), timeout=900)
     assert rc == 0 and "4 passed" in out and "ERROR: AddressSanitizer" not in out and "runtime error" not in out, out[-4000:]
+
+
+def test_no_mfma_result_is_read_before_it_is_written(tmp_path):
+    """tools/check_mfma_hazards.py over the gfx950 assembly of every kernel file that issues MFMAs: hipcc pads 'MFMA write -> read' inside a
+    basic block; across a branch it once left the first reader unpadded (attn_varlen_kernel's tile maximum: results correct but different
+    from run to run).  The kernels are written so that no reader sits behind a branch unpadded; this keeps it that way (cross-compiles, no GPU)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "fusion_amd", "csrc")
+    files = [f for f in sorted(os.listdir(src)) if f.endswith(".hip") and "mfma" in open(os.path.join(src, f)).read()]
+    assert {"score.hip", "maxsim.hip", "encoder.hip"} <= set(files)
+    outs = []
+    for f in files:
+        out = str(tmp_path / (f[:-4] + ".s"))
+        subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only",
+                        os.path.join(src, f), "-o", out], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        outs.append(out)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazards.py"), *outs], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
