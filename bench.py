@@ -145,6 +145,19 @@ def synth_query_tokens(rng, Q, vocab_size, pad_id, L=64):
     return np.where(mask == 1, ids, pad_id), mask, qlen
 
 
+def splade_like(rng, rows, V, nnz_mean, dev):
+    """rows x V float32 SPLADE-shaped vectors (columns padded to a multiple of 4): per row ~nnz_mean distinct Zipf-distributed terms with
+    log1p(relu(.)) weights -- a few hundred non-zeros of 32,005 per document is what splade/splade.py:88-99 yields after training."""
+    p = 1.0 / np.arange(1, V + 1) ** 0.9; p /= p.sum()
+    X = torch.zeros((rows, -(-V // 4) * 4), device=dev)
+    k = np.maximum(1, rng.poisson(nnz_mean, rows))
+    r = np.repeat(np.arange(rows), k)
+    c = rng.choice(V, size=int(k.sum()), p=p)
+    w = np.log1p(np.maximum(rng.normal(1.0, 1.0, int(k.sum())), 0.05)).astype(np.float32)
+    X[torch.from_numpy(r).to(dev), torch.from_numpy(c).to(dev)] = torch.from_numpy(w).to(dev)
+    return X
+
+
 def build_lleqa(args, dev, rank):
     from fusion_amd import encoders, ops
     rng = np.random.default_rng(1234 + rank)
@@ -503,11 +516,11 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
     V, Vp = cfg.vocab_size, -(-cfg.vocab_size // 4) * 4
     # ---- corpus side, static --------------------------------------------------------------------------------------
     Dn = ops.normalize_rows(torch.randn((N, 768), generator=g, device=dev))
-    Ds = torch.zeros((N, Vp), device=dev)
-    for c0 in range(0, N, 4096):
-        c1 = min(N, c0 + 4096)
-        Ds[c0:c1, :V] = torch.log1p(torch.relu(torch.randn((c1 - c0, V), generator=g, device=dev) - 1.0))
-    Ds = ops.normalize_rows(Ds)
+    # SPLADE corpus side: SPLADE-shaped vectors (~200 active terms of 32,005 per document), kept as the product keeps them (Ranker.single_vector_search):
+    # an inverted index of the normalised rows.  The dense matrix stays around only to time the dense GEMM on the same data for the record.
+    Ds = ops.normalize_rows(splade_like(rng, N, V, 200, dev))
+    Ds_index = ops.sparse_index(Ds, V)
+    enc["splade"].calibrate_sparsity()                # random-init head -> a trained SPLADE's sparsity (a few dozen active terms per query)
     dl = np.clip(rng.normal(300, 120, N), 16, 512).astype(np.int64)
     off = np.zeros(N + 1, dtype=np.int64); off[1:] = np.cumsum(dl)
     Dtok = torch.nn.functional.normalize(torch.randn((int(off[-1]), 128), generator=g, device=dev), dim=-1).half()
@@ -549,7 +562,7 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
             S_d = ops.dot_scores(ops.normalize_rows(e), Dn); mark("dpr_score")
             sys_d = _rank_scores(S_d, ids_np, None); mark("dpr_rank")
             v = enc["splade"].encode_ids_packed(qids_d, qlen); mark("splade_encode")
-            S_s = ops.dot_scores(ops.normalize_rows(v), Ds); mark("splade_score")
+            S_s = ops.sparse_cos_scores(v, Ds_index); mark("splade_score")      # normalise + non-zero lists + fz_sparse_dot_f32
             sys_s = _rank_scores(S_s, ids_np, None); mark("splade_rank")
             Qtok = enc["colbert"].encode_query_ids(cq_d); mark("colbert_encode")
             S_c = ops.maxsim(Qtok, Dtok, Doff, max_doc_len=512); mark("colbert_maxsim")
@@ -572,6 +585,11 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
         torch.cuda.synchronize()
         stages, _ = ev.durations_ms()
         sumL = int(off[-1])
+        v_last = enc["splade"].encode_ids_packed(qids_d, qlen)
+        splade_dense_ms = timeit_ms(lambda: ops.dot_scores(ops.normalize_rows(v_last), Ds), n=2, warm=1)    # the reference's dense form on the same vectors
+        splade_query_nnz = float(torch.count_nonzero(v_last).item()) / Q
+        splade_diff = float((ops.dot_scores(ops.normalize_rows(v_last), Ds) - ops.sparse_cos_scores(v_last, Ds_index)).abs().max())
+        del v_last
         enc["colbert"].amp = False                 # the same query encode with float32 Linears, for the record (not part of the pipeline time)
         colbert_fp32_ms = timeit_ms(lambda: enc["colbert"].encode_query_ids(cq_d), n=2, warm=1)
         enc["colbert"].amp = True
@@ -581,11 +599,13 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
                                     colbert="encoder Linears float16 (colbert-ai runs query() / doc() under autocast; multi_dense_biencoder.py:55 'amp': True), everything "
                                             "else of the forward float32; token vectors float16; MaxSim f16 MFMA, f32 accumulate"),
                         colbert_encode_fp32_ms=colbert_fp32_ms,
+                        splade=dict(scoring="inverted index of the normalised corpus vectors (fz_sparse_dot_f32): the dense cos_sim's products minus its exact zeros",
+                                    doc_nnz_mean=Ds_index.nnz / N, query_nnz_mean=splade_query_nnz, index_MB=(Ds_index.nnz * 8 + (V + 1) * 8) / 1e6,
+                                    dense_MB=N * Vp * 4 / 1e6, dense_gemm_ms_same_vectors=splade_dense_ms, max_abs_diff_vs_dense=splade_diff),
                         dominant_stage=max(stages, key=stages.get),
                         stage_rooflines={"dpr_score": roof("dot_scores_kernel", stages["dpr_score"], 2.0 * Q * N * 768, "mfma_f32")["frac"],
-                                         "splade_score": roof("dot_scores_kernel", stages["splade_score"], 2.0 * Q * N * V, "mfma_f32")["frac"],
                                          "colbert_maxsim": roof("maxsim_kernel", stages["colbert_maxsim"], 2.0 * Q * 64 * sumL * 128, "mfma_f16")["frac"]}))
-    del Ds, Dtok, Dn
+    del Ds, Ds_index, Dtok, Dn
 
     # ---- corpus-side encode (hybrid.py:101; the reference's dominant cost, re-paid by each of run_hybrid.sh's processes) -----------
     n = N // 8

@@ -418,6 +418,19 @@ class SpladeEncoder(_Base):
         logits = self.mlm(input_ids=input_ids, attention_mask=attention_mask).logits
         return torch.amax(torch.log1p(torch.relu(logits * attention_mask.unsqueeze(-1))), dim=1)
 
+    @torch.no_grad()
+    def calibrate_sparsity(self, per_token: float = 3.5e-5, seed: int = 0):
+        """Synthetic runs only: shift the decoder bias of a RANDOM-INIT head so that a token's logit is positive with probability `per_token`
+        -- a trained SPLADE's FLOPS regulariser leaves a few dozen active terms per query and a few hundred per document (3.5e-5 x 36 / 300
+        tokens of 32,005 terms ~ 40 / 330); a random head activates half the vocabulary.  Measured on one random batch."""
+        g = torch.Generator().manual_seed(seed)
+        ids = torch.randint(7, self.dim - 1, (8, 64), generator=g).to(self._device)
+        logits = self.mlm(input_ids=ids, attention_mask=torch.ones_like(ids)).logits.float()
+        z = float(torch.distributions.Normal(0.0, 1.0).icdf(torch.tensor(1.0 - per_token)))
+        bias = self.mlm.lm_head.decoder.bias
+        bias -= logits.mean() + z * logits.std()
+        return self
+
     HEAD_TOKENS = 65536     # token rows per forward + head pass (the fused head writes no [T, vocab] logits: 16384 rows of them were 2.1 GB)
     FUSED_HEAD = True       # False: decoder GEMM -> [T, vocab] logits -> fz_segment_splade_max_f32 (the reference's shape, splade.py:94)
 

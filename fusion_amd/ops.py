@@ -851,6 +851,91 @@ def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float
     return out
 
 
+# ---------------------------------------------------------------------------------------
+# A3, sparse form: SPLADE cosine scoring over an inverted index
+# ---------------------------------------------------------------------------------------
+class SparseIndex:
+    """L2-normalised corpus vectors as postings: toff [V + 1] int64, pdoc [nnz] int32 (ascending inside a term), pw [nnz] float32,
+    slice_off [V, NS + 1] int64 (fz_sparse_slice_offsets).  N documents over a vocabulary of V terms."""
+
+    def __init__(self, toff, pdoc, pw, N: int, V: int, slice_off=None):
+        self.toff, self.pdoc, self.pw, self.N, self.V = toff, pdoc, pw, int(N), int(V)
+        self.slice_off = slice_off if slice_off is not None else sparse_slice_offsets(toff, pdoc, self.V, self.N)
+
+    @property
+    def nnz(self) -> int:
+        return int(self.pdoc.numel())
+
+    def tensors(self):
+        return self.toff, self.pdoc, self.pw
+
+
+def sparse_slice_offsets(toff: torch.Tensor, pdoc: torch.Tensor, V: int, N: int) -> torch.Tensor:
+    _need(_dev(toff, torch.int64, "sparse_slice_offsets(toff)").is_contiguous() and toff.numel() == V + 1, f"sparse_slice_offsets: toff must hold {V + 1} offsets")
+    _need(_dev(pdoc, torch.int32, "sparse_slice_offsets(pdoc)").is_contiguous(), "sparse_slice_offsets(pdoc) must be contiguous")
+    NS = max(1, -(-int(N) // int(_lib.lib().fz_sparse_slice_docs())))
+    out = torch.empty((V, NS + 1), dtype=torch.int64, device=toff.device)
+    check(_lib.lib().fz_sparse_slice_offsets(_ptr(toff), _ptr(pdoc), V, int(N), _ptr(out), _stream(toff)), "fz_sparse_slice_offsets")
+    return out
+
+
+def density(X: torch.Tensor) -> float:
+    """Fraction of non-zero entries (one device reduction)."""
+    return float(torch.count_nonzero(X).item()) / max(1, X.numel())
+
+
+def sparse_index(Dn: torch.Tensor, V: int | None = None, rows: int = 4096) -> SparseIndex:
+    """Inverted index of the rows of Dn [N, >= V] (already L2-normalised, e.g. ops.normalize_rows): built from row blocks (a block's
+    non-zeros, then one stable sort by term -- documents stay ascending inside a term)."""
+    _dev(Dn, torch.float32, "sparse_index(Dn)")
+    N = Dn.shape[0]
+    V = Dn.shape[1] if V is None else int(V)
+    docs, terms, vals = [], [], []
+    for r0 in range(0, N, rows):
+        blk = Dn[r0: r0 + rows, :V]
+        nz = blk.nonzero()
+        docs.append((nz[:, 0] + r0).int()); terms.append(nz[:, 1]); vals.append(blk[nz[:, 0], nz[:, 1]])
+    doc = torch.cat(docs) if docs else torch.zeros(0, dtype=torch.int32, device=Dn.device)
+    term = torch.cat(terms) if terms else torch.zeros(0, dtype=torch.int64, device=Dn.device)
+    val = torch.cat(vals) if vals else torch.zeros(0, dtype=torch.float32, device=Dn.device)
+    order = torch.sort(term, stable=True).indices           # documents were appended ascending: stable keeps them so inside a term
+    toff = torch.zeros(V + 1, dtype=torch.int64, device=Dn.device)
+    toff[1:] = torch.cumsum(torch.bincount(term, minlength=V), 0)
+    return SparseIndex(toff, doc[order].contiguous(), val[order].contiguous(), N, V)
+
+
+def sparse_rows(Qn: torch.Tensor, V: int | None = None):
+    """The non-zero (term, weight) lists of the rows of Qn [Q, >= V]: (qoff [Q + 1] int64, qterms int32, qw float32), terms ascending."""
+    _dev(Qn, torch.float32, "sparse_rows(Qn)")
+    V = Qn.shape[1] if V is None else int(V)
+    blk = Qn[:, :V]
+    nz = blk.nonzero()                                        # row-major: by query, then ascending term
+    qoff = torch.zeros(Qn.shape[0] + 1, dtype=torch.int64, device=Qn.device)
+    qoff[1:] = torch.cumsum(torch.bincount(nz[:, 0], minlength=Qn.shape[0]), 0)
+    return qoff, nz[:, 1].int().contiguous(), blk[nz[:, 0], nz[:, 1]].contiguous()
+
+
+def sparse_dot(index: SparseIndex, qoff: torch.Tensor, qterms: torch.Tensor, qw: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """scores[q][d] = sum over query q's terms of qw * (document d's weight of that term): [Q, N] float32 plane."""
+    for t, dt, what in ((qoff, torch.int64, "qoff"), (qterms, torch.int32, "qterms"), (qw, torch.float32, "qw")):
+        _need(_dev(t, dt, f"sparse_dot({what})").is_contiguous(), f"sparse_dot({what}) must be contiguous")
+    Q = qoff.numel() - 1
+    _need(Q >= 0 and qterms.numel() == qw.numel(), "sparse_dot: qoff must hold Q + 1 offsets, qterms and qw one entry per non-zero")
+    if out is None:
+        out = alloc_plane(Q, index.N, torch.float32, qoff.device)
+    else:
+        _dev(out, torch.float32, "sparse_dot(out)")
+        _need(tuple(out.shape) == (Q, index.N), f"sparse_dot(out): expected shape {(Q, index.N)}, got {tuple(out.shape)}")
+    check(_lib.lib().fz_sparse_dot_f32(_ptr(index.toff), _ptr(index.pdoc), _ptr(index.pw), _ptr(index.slice_off), _ptr(qoff), _ptr(qterms), _ptr(qw),
+                                       Q, index.N, _ptr(out), _ld(out), _stream(qoff)), "fz_sparse_dot_f32")
+    return out
+
+
+def sparse_cos_scores(Qe: torch.Tensor, index: SparseIndex) -> torch.Tensor:
+    """Cosine scores of dense query vectors Qe [Q, >= V] against a SparseIndex (whose rows were normalised before indexing)."""
+    return sparse_dot(index, *sparse_rows(normalize_rows(pad_dim(Qe)), index.V))
+
+
 def f64_to_f32(src: torch.Tensor) -> torch.Tensor:
     """Plane-preserving fp64 -> fp32 (what torch.tensor(..., dtype=float32) does to BM25's Python floats, hybrid.py:255)."""
     _dev(src, torch.float64, "f64_to_f32")

@@ -296,6 +296,19 @@ int fz_tune_metrics_f64(const int32_t* ranks, const int32_t* gold, const int32_t
                         const double* disc, int top, const int32_t* cuts, int n_recall, int n_map, int n_mrr, int n_ndcg, int W, int Q,
                         double* out, void* stream);
 
+/* ---- A3, sparse form: SPLADE cosine scoring over an inverted index ------------------------------------------------------------------
+ * util.semantic_search(query_embeddings, corpus_embeddings, score_function=util.cos_sim) (hybrid.py:103) on SPLADE vectors
+ * (splade/splade.py:88-99: a few hundred non-zeros of 32,005) without the dense [N, 32005] matrix: the L2-normalised corpus vectors as
+ * postings -- toff [V + 1] (device int64), pdoc / pw [nnz]: (document, weight) of term t in [toff[t], toff[t+1]), documents ascending --
+ * and the L2-normalised queries as qoff [Q + 1], qterms / qw: the non-zero terms of query q, ascending.
+ *     scores[q][d] = sum over the query's terms t, ascending, of qw * pw        (float32, one rounding per product and per add)
+ * = the dense product minus its exact zeros.  slice_off (nullable): fz_sparse_slice_offsets' [V][NS + 1] table, NS = ceil(N /
+ * fz_sparse_slice_docs()) -- where every term's postings cross the document slices a workgroup owns.  scores [Q][lds] float32. */
+int fz_sparse_slice_docs(void);
+int fz_sparse_slice_offsets(const int64_t* toff, const int32_t* pdoc, int V, int N, int64_t* out, void* stream);
+int fz_sparse_dot_f32(const int64_t* toff, const int32_t* pdoc, const float* pw, const int64_t* slice_off, const int64_t* qoff,
+                      const int32_t* qterms, const float* qw, int Q, int N, float* scores, int lds, void* stream);
+
 /* ---- encoder side: the per-sequence parts of SentenceTransformer.encode (hybrid.py:97-102) on PACKED token rows -- */
 /* Self-attention of a BERT/CamemBERT layer for ragged sequences without padding: for every sequence and head,
  * out = softmax(q k^T * scale) v in fp32 (MFMA products, online softmax over 16-key tiles), scale > 0.  qkv [T][ld] = fused

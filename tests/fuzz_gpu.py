@@ -552,6 +552,25 @@ def case_rerun(rng):
     return f"rerun splade_head n={n} d={d} V={V} T={int(lens.sum())}"
 
 
+def case_sparse(rng):
+    """fz_sparse_dot_f32 (SPLADE scoring over an inverted index) vs the float64 product of the same matrices; reruns bit-identical."""
+    Q, N, V = int(rng.integers(1, 40)), int(rng.choice([rng.integers(1, 500), rng.integers(28000, 60000)])), int(rng.integers(1, 3000))
+    dens_d, dens_q = float(rng.choice([0.0, 0.002, 0.02, 0.2])), float(rng.choice([0.0, 0.01, 0.3]))
+    g = torch.Generator(device="cuda").manual_seed(int(rng.integers(0, 1 << 30)))
+    Vp = -(-V // 4) * 4
+    def mat(rows, dens):
+        X = torch.zeros((rows, Vp), device="cuda")
+        X[:, :V] = (torch.rand((rows, V), generator=g, device="cuda") < dens) * torch.randn((rows, V), generator=g, device="cuda")
+        return ops.normalize_rows(X)
+    Dn, Qn = mat(N, dens_d), mat(Q, dens_q)
+    idx = ops.sparse_index(Dn, V)
+    got = ops.sparse_dot(idx, *ops.sparse_rows(Qn, V))
+    ref = Qn.double() @ Dn.double().T
+    assert got.shape == (Q, N) and (got.double() - ref).abs().max().item() <= 2e-6
+    assert torch.equal(got, ops.sparse_dot(idx, *ops.sparse_rows(Qn, V)))
+    return f"sparse Q={Q} N={N} V={V} nnz={idx.nnz}"
+
+
 def case_empty(rng):
     """Zero-sized batches: every op returns an empty (or all-default) result without touching a pointer."""
     n = int(rng.integers(1, 500))
@@ -574,7 +593,7 @@ def case_empty(rng):
 
 
 CASES = [case_encoder, case_lists, case_empty, case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
-         case_topk_stream, case_segments, case_fused_search, case_sort_stats, case_select, case_splade_head, case_fuse_ranked, case_maxsim, case_f16_kernels, case_encoder_amp, case_rerun, case_rerun]
+         case_topk_stream, case_segments, case_fused_search, case_sort_stats, case_select, case_splade_head, case_fuse_ranked, case_maxsim, case_f16_kernels, case_encoder_amp, case_rerun, case_rerun, case_sparse]
 
 
 def main():

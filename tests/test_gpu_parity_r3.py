@@ -452,3 +452,68 @@ def test_colbert_mixed_precision_forward_matches_fp32_and_autocast():
         ids1, m1 = tok([t], a.max_doc_length)
         ref = a._tokens(ids1.cuda(), m1.cuda())[0]
         assert (Da[int(Oa[i]): int(Oa[i + 1])].float() - ref).abs().max().item() <= 6e-3
+
+
+# ---- SPLADE scoring over an inverted index (fz_sparse_dot_f32) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("Q,N,V,dn,qn", [(5, 300, 997, 40, 9), (33, 27942, 32005, 200, 40), (3, 30000, 500, 30, 400), (1, 1, 4, 2, 2)])
+def test_sparse_dot_equals_the_dense_contraction(ops, Q, N, V, dn, qn):
+    """The sparse form of util.cos_sim over SPLADE vectors: same scores as the dense fp32 GEMM of the same (normalised) matrices and as a
+    float64 product; bit-identical when repeated; documents without any query term score exactly 0; two document slices at N = 30,000."""
+    rng = np.random.default_rng(Q * 7 + N)
+    def rows(n, k):
+        X = np.zeros((n, -(-V // 4) * 4), dtype=np.float32)
+        for i in range(n):
+            c = rng.choice(V, size=min(V, max(1, rng.poisson(k))), replace=False)
+            X[i, c] = np.log1p(np.maximum(rng.normal(1, 1, c.size), 0.05)).astype(np.float32)
+        return X
+    D, Qm = rows(N, dn), rows(Q, qn)
+    if N > 2: D[1] = 0                                         # an empty document: norm clamp, no postings
+    Dn, Qn = ops.normalize_rows(dev(D)), ops.normalize_rows(dev(Qm))
+    idx = ops.sparse_index(Dn, V)
+    assert idx.nnz == int((D[:, :V] != 0).sum()) and bool((idx.pdoc[1:] >= idx.pdoc[:-1])[(idx.toff[1:-1] - 1).clamp_min(0).unique()].numel() >= 0)
+    got = ops.sparse_dot(idx, *ops.sparse_rows(Qn, V))
+    assert torch.equal(got, ops.sparse_dot(idx, *ops.sparse_rows(Qn, V)))
+    dense = ops.dot_scores(Qn, Dn)
+    ref = (Qn.double() @ Dn.double().T)
+    assert (got.double() - ref).abs().max().item() <= 2e-6
+    assert (got - dense).abs().max().item() <= 2e-6
+    never = (ref == 0)
+    assert bool((got[never] == 0).all())
+    # the drop-in path: dense query vectors in, cosine scores out
+    assert torch.equal(ops.sparse_cos_scores(dev(Qm), idx), got)
+
+
+def test_ranker_scores_sparse_splade_through_the_index(ops, tmp_path):
+    """Ranker.single_vector_search with a SPLADE encoder whose vectors are sparse: inverted index (also through the on-disk cache) == the
+    dense cos_sim path, ranked lists and scores; a dense 'SPLADE' corpus falls back to the GEMM."""
+    from fusion_amd.retrievers.hybrid import Ranker
+    V = 997
+    rng = np.random.default_rng(11)
+
+    class FakeSplade:
+        dim = V
+        def __init__(self, dense): self.dense = dense
+        def encode(self, texts, batch_size=64, query_mode=False):
+            out = np.zeros((len(texts), V), dtype=np.float32)
+            for i, t in enumerate(texts):
+                r = np.random.default_rng(abs(hash(t)) % (1 << 31))
+                c = r.choice(V, size=V // 2 if self.dense else (12 if query_mode else 60), replace=False)
+                out[i, c] = np.log1p(r.random(c.size) * 3).astype(np.float32)
+            return torch.from_numpy(out).cuda()
+
+    corpus = {100 + i: f"doc {i} {rng.integers(0, 1 << 30)}" for i in range(400)}
+    queries = [f"query {i}" for i in range(7)]
+    for dense in (False, True):
+        enc = FakeSplade(dense)
+        a = Ranker.single_vector_search(queries, corpus, "splade-fake", encoder=enc, cache_dir=str(tmp_path / f"c{int(dense)}"))
+        b = Ranker.single_vector_search(queries, corpus, "splade-fake", encoder=enc, cache_dir=str(tmp_path / f"c{int(dense)}"))     # from the cache
+        De, Qe = enc.encode(list(corpus.values())), enc.encode(queries, query_mode=True)
+        ref = ops.cos_scores(Qe, De).cpu().numpy()
+        ids = np.array(list(corpus.keys()))
+        for lists in (a, b):
+            for q, lst in enumerate(lists):
+                assert len(lst) == len(corpus)
+                got = np.array([x["score"] for x in lst]); cid = np.array([x["corpus_id"] for x in lst])
+                exp = ref[q][np.searchsorted(ids, cid)]
+                assert np.abs(got - exp).max() <= 2e-6 and np.all(np.diff(got) <= 0)
+        assert [[x["corpus_id"] for x in l] for l in a] == [[x["corpus_id"] for x in l] for l in b]
