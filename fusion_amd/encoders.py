@@ -245,7 +245,7 @@ class PackedBertForward(FusedBertForward):
             return torch.nn.functional.linear(x, w, b)
         return torch.nn.functional.linear(x.to(self.amp_dtype), self._low(w), self._low(b)).float()
 
-    def _layers_f16(self, x, ctx, strips_d, H, mark):
+    def _layers_f16(self, x, ctx, strips_d, H, mark, T):
         """The encoder layers with float16 Linears end to end: every Linear takes a float16 operand written by the kernel in front of it
         (attention, residual + LayerNorm and GELU emit it next to / instead of their float32 result) and returns float16, as under
         autocast; the residual stream, the attention arithmetic and the normalisations are float32.  No conversion pass anywhere."""
@@ -254,8 +254,8 @@ class PackedBertForward(FusedBertForward):
         lo = self._low
         x16 = x.to(torch.float16)
         ctx16 = torch.empty(ctx.shape, dtype=torch.float16, device=x.device)
-        if ctx16.shape[0] != 0:
-            ctx16.copy_(ctx)                       # the pad rows' zeros
+        if T < ctx16.shape[0]:
+            ctx16[T:].zero_()                      # the pad rows (attention writes the real ones in every layer)
         for ly in self.layers:
             qkv16 = F.linear(x16, lo(ly["wqkv"]), lo(ly["bqkv"])); mark("encode_gemm")
             ops.attn_varlen_f16(qkv16, strips_d, H, ctx16); mark("encode_attn")
@@ -313,7 +313,7 @@ class PackedBertForward(FusedBertForward):
         mark = mark or (lambda name: None)
         mark("encode_embed")
         if self.amp_dtype == torch.float16 and self.word.shape[1] % 8 == 0 and self.layers[0]["w1"].shape[0] % 8 == 0:
-            return self._layers_f16(x, ctx, strips_d, H, mark)[:T], cu_d
+            return self._layers_f16(x, ctx, strips_d, H, mark, T)[:T], cu_d
         for ly in self.layers:
             qkv = self._linear(x, ly["wqkv"], ly["bqkv"]); mark("encode_gemm")
             ops.attn_varlen(qkv, strips_d, H, out=ctx); mark("encode_attn")
