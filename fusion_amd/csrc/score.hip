@@ -91,7 +91,8 @@ enum { EPI_STORE = 0, EPI_FILTER = 1, EPI_SPLADE = 2 };
 // ALL those tiles form one stream through the software pipeline: the operand loads of a tile's first two k-tiles are issued
 // during the last two k-tiles of the tile before it, and its score stores drain under the next tile's MFMAs -- a workgroup
 // pays the pipeline fill once per launch, not once per tile.
-template <int BN, int MI /* 32-row MFMA blocks per wave */, int WN /* waves along the corpus side: 2 (2 x 2 waves) or 4 (1 x 4) */, bool RAGGED /* d is not a whole number of k-tile pairs */, int EPI>
+template <int BN, int MI /* 32-row MFMA blocks per wave */, int WN /* waves along the corpus side: 2 (2 x 2 waves) or 4 (1 x 4) */, bool RAGGED /* d is not a whole number of k-tile pairs */, int EPI,
+          bool FLAT = false /* tile id b = corpus columns [b BN, (b + 1) BN) of the row band at row_origin (the 7-row-block cover) */>
 __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int first, const int end, const int step, const int qblocks, const int row_origin) {
     constexpr int WM = 4 / WN;           // waves along the query side
     constexpr int BMT = 32 * MI * WM;    // tile height: 128 (whole query blocks: 2 x 2 waves, MI = 2), 64 (MI = 1) or 32 (1 x 4 waves, MI = 1)
@@ -105,6 +106,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
 
     // tile id -> (query row, corpus column) of its corner; ids of the XCD padding decode to nothing
     auto decode = [&](int b, int& row0, int& col0) -> bool {
+        if constexpr (FLAT) { row0 = row_origin; col0 = b * BN; return col0 < g.N; }
         int half = 0;
         if (BN == 64) {   // workgroup i of the half-tile round: tile (i/16)*8 + i%8 (same XCD as i), half (i/8)%2
             const int h = b - g.full;
@@ -446,6 +448,19 @@ __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
     }
 }
 
+// 193..224 queries (the LLeQA test and dev batches: 195, 201) against a corpus that fits the chip in one round: 7 row blocks x ceil(N / 32) column
+// blocks of MFMA work -- 23.9 block pairs per CU at N = 27,942 -- which no single tile shape spreads evenly (128- and 96-row tiles of 128 columns:
+// 219 + 219 tiles on 256 CUs, the busiest CU holds two whole tiles).  Two shapes of 24 blocks each do: rows 0..127 as 128 x 192 tiles (2 x 2 waves,
+// 2 x 3 MFMA tiles each), rows 128.. as 96 x 256 tiles (1 x 4 waves, 3 x 2 each): 146 + 110 = 256 equal workgroups, one per CU (92 / 101 KB of LDS).
+// Same k-order fmaf chain per score as every other shape.
+template <bool RAGGED>
+__global__ __launch_bounds__(256, 1) void dot_scores_cover7_kernel(GemmArgs g, int nP) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = (int)blockIdx.x;
+    if (b < nP) gemm_stream<192, 2, 2, RAGGED, EPI_STORE, true>(g, lds, b, b + 1, 1, 1, 0);
+    else gemm_stream<256, 3, 4, RAGGED, EPI_STORE, true>(g, lds, b - nP, b - nP + 1, 1, 1, 128);
+}
+
 }  // namespace fz
 
 using namespace fz;
@@ -478,6 +493,25 @@ static int launch_gemm(GemmArgs& g, int epi, hipStream_t st) {
     FZ_HIP_TRY(hipGetDevice(&dev));
     if (dev >= 64) return FZ_ERR_UNSUPPORTED;
     if (!cus[dev]) FZ_HIP_TRY(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    // per-lane offsets are signed 32-bit byte offsets inside one operand tile (at most 256 rows)
+    if (256.0 * g.lda * 4 >= 2147483648.0 || 256.0 * g.ldb * 4 >= 2147483648.0) return FZ_ERR_UNSUPPORTED;
+    if (epi == EPI_STORE && g.Q > 192 && g.Q <= 224) {   // the 7-row-block cover, when its tiles fit the chip in one round
+        const long nP = (g.N + 191) / 192, nQ = (g.N + 255) / 256;
+        if (nP + nQ <= cus[dev]) {
+            constexpr size_t lds_c7 = 2 * (96 + 256) * LDT * sizeof(float);
+            static unsigned long long c7_set[2] = {0ull, 0ull};
+            const bool rg = g.d % (2 * BK) != 0;
+            if (rg) {
+                if (int rc = raise_lds_limit((const void*)dot_scores_cover7_kernel<true>, lds_c7, c7_set[1])) return rc;
+                dot_scores_cover7_kernel<true><<<(unsigned)(nP + nQ), 256, lds_c7, st>>>(g, (int)nP);
+            } else {
+                if (int rc = raise_lds_limit((const void*)dot_scores_cover7_kernel<false>, lds_c7, c7_set[0])) return rc;
+                dot_scores_cover7_kernel<false><<<(unsigned)(nP + nQ), 256, lds_c7, st>>>(g, (int)nP);
+            }
+            FZ_LAUNCH_CHECK();
+            return FZ_OK;
+        }
+    }
     const long slots = 2L * cus[dev] / 8 * 8;            // resident workgroups (two per CU), a multiple of the 8 XCDs
     if (slots <= 0 || B + Bt > 0x3fffffffL) return FZ_ERR_UNSUPPORTED;
     long R = B % slots;                                  // the partial last round ...
