@@ -517,3 +517,40 @@ def test_ranker_scores_sparse_splade_through_the_index(ops, tmp_path):
                 exp = ref[q][np.searchsorted(ids, cid)]
                 assert np.abs(got - exp).max() <= 2e-6 and np.all(np.diff(got) <= 0)
         assert [[x["corpus_id"] for x in l] for l in a] == [[x["corpus_id"] for x in l] for l in b]
+
+
+def test_mfma_kernels_are_bit_reproducible(ops):
+    """Reruns on one input give identical bits (attention, score GEMM at a 7-row-block and a many-tile batch, MaxSim, the fused SPLADE head).
+    Round 3: attn_varlen_kernel's tile maximum read the score registers of its MFMA chain too early -- results within tolerance, but different from
+    run to run; a reader of an MFMA result that hipcc leaves unpadded behind a branch shows up here (and in tools/check_mfma_hazards.py)."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    lens = np.array([442, 548, 389, 487, 516, 212, 127, 250, 242, 33, 1])
+    strips, _ = ops.attn_strips(lens)
+    sd = torch.from_numpy(strips).cuda()
+    qkv = torch.randn((int(lens.sum()), 3 * 12 * 64), generator=g, device="cuda")
+    ref = ops.attn_varlen(qkv, sd, 12).clone()
+    for _ in range(4):
+        assert torch.equal(ops.attn_varlen(qkv, sd, 12), ref)
+    q16 = qkv.half()
+    o16 = torch.empty((qkv.shape[0], 768), dtype=torch.float16, device="cuda")
+    ops.attn_varlen_f16(q16, sd, 12, o16)
+    assert torch.equal(o16, ops.attn_varlen(q16.float(), sd, 12).half())
+    D = ops.normalize_rows(torch.randn((27942, 768), generator=g, device="cuda"))
+    for Q in (195, 1024):
+        A = ops.normalize_rows(torch.randn((Q, 768), generator=g, device="cuda"))
+        r = ops.dot_scores(A, D).clone()
+        for _ in range(3):
+            assert torch.equal(ops.dot_scores(A, D), r)
+    lens = np.clip(np.random.default_rng(2).normal(300, 120, 1500), 16, 512).astype(np.int64)
+    Doff = np.zeros(lens.size + 1, dtype=np.int64); np.cumsum(lens, out=Doff[1:])
+    Dtok = torch.nn.functional.normalize(torch.randn((int(Doff[-1]), 128), generator=g, device="cuda"), dim=-1).half()
+    Qtok = torch.nn.functional.normalize(torch.randn((195, 64, 128), generator=g, device="cuda"), dim=-1).half()
+    r = ops.maxsim(Qtok, Dtok, dev(Doff), max_doc_len=512).clone()
+    for _ in range(3):
+        assert torch.equal(ops.maxsim(Qtok, Dtok, dev(Doff), max_doc_len=512), r)
+    x = torch.randn((3000, 768), generator=g, device="cuda")
+    cu = torch.tensor([0, 700, 701, 1800, 3000], dtype=torch.int32, device="cuda")
+    W, b = torch.randn((32005, 768), generator=g, device="cuda") * 0.05, torch.randn(32005, generator=g, device="cuda")
+    r = ops.splade_head_max(x, W, b, cu).clone()
+    for _ in range(2):
+        assert torch.equal(ops.splade_head_max(x, W, b, cu), r)
