@@ -869,6 +869,13 @@ class SparseIndex:
     def tensors(self):
         return self.toff, self.pdoc, self.pw
 
+    def to_dense(self) -> torch.Tensor:
+        """The [N, V rounded up to 4] float32 matrix the index was built from (normalised rows)."""
+        D = torch.zeros((self.N, round_up(max(self.V, 1), 4)), dtype=torch.float32, device=self.pw.device)
+        term = torch.repeat_interleave(torch.arange(self.V, device=self.pw.device), self.toff[1:] - self.toff[:-1])
+        D[self.pdoc.long(), term] = self.pw
+        return D
+
 
 def sparse_slice_offsets(toff: torch.Tensor, pdoc: torch.Tensor, V: int, N: int) -> torch.Tensor:
     _need(_dev(toff, torch.int64, "sparse_slice_offsets(toff)").is_contiguous() and toff.numel() == V + 1, f"sparse_slice_offsets: toff must hold {V + 1} offsets")
@@ -931,9 +938,14 @@ def sparse_dot(index: SparseIndex, qoff: torch.Tensor, qterms: torch.Tensor, qw:
     return out
 
 
-def sparse_cos_scores(Qe: torch.Tensor, index: SparseIndex) -> torch.Tensor:
-    """Cosine scores of dense query vectors Qe [Q, >= V] against a SparseIndex (whose rows were normalised before indexing)."""
-    return sparse_dot(index, *sparse_rows(normalize_rows(pad_dim(Qe)), index.V))
+def sparse_cos_scores(Qe: torch.Tensor, index: SparseIndex, max_query_density: float = 0.05) -> torch.Tensor:
+    """Cosine scores of dense query vectors Qe [Q, >= V] against a SparseIndex (whose rows were normalised before indexing).  Queries that are
+    not sparse themselves (an untrained head activates half the vocabulary: one barrier per term and query) take the dense GEMM against the
+    re-densified corpus instead -- same scores either way."""
+    Qn = normalize_rows(pad_dim(Qe))
+    if density(Qn[:, :index.V]) > max_query_density:
+        return dot_scores(Qn, index.to_dense())
+    return sparse_dot(index, *sparse_rows(Qn, index.V))
 
 
 def f64_to_f32(src: torch.Tensor) -> torch.Tensor:

@@ -479,8 +479,10 @@ def test_sparse_dot_equals_the_dense_contraction(ops, Q, N, V, dn, qn):
     assert (got - dense).abs().max().item() <= 2e-6
     never = (ref == 0)
     assert bool((got[never] == 0).all())
-    # the drop-in path: dense query vectors in, cosine scores out
-    assert torch.equal(ops.sparse_cos_scores(dev(Qm), idx), got)
+    # the drop-in path: dense query vectors in, cosine scores out; queries that are not sparse take the GEMM against the re-densified corpus
+    assert torch.equal(ops.sparse_cos_scores(dev(Qm), idx, max_query_density=1.0), got)
+    assert torch.equal(idx.to_dense()[:, :V], Dn[:, :V])
+    assert (ops.sparse_cos_scores(dev(Qm), idx, max_query_density=0.0) - got).abs().max().item() <= 2e-6
 
 
 def test_ranker_scores_sparse_splade_through_the_index(ops, tmp_path):
