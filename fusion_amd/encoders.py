@@ -226,6 +226,7 @@ class PackedBertForward(FusedBertForward):
     head_dim must be 64 (BERT-base family)."""
 
     ROW_GRANULE = 512
+    FULL_ROWS = 65536       # = _Base.packed_tokens: the corpus encode cuts its sub-batches at this many token rows
     # Mixed precision as torch.autocast applies it to a BERT forward (what colbert-ai's Checkpoint wraps every query() / doc() in):
     # the Linears take float16 operands (float32 accumulate on the matrix pipe); everything between them -- attention, GELU,
     # residual + LayerNorm -- stays in float32 here (autocast keeps LayerNorm and softmax in float32 and lets GELU follow its float16
@@ -301,6 +302,8 @@ class PackedBertForward(FusedBertForward):
         # while GEMM tuning is on, the row count is padded to a multiple of ROW_GRANULE (zero rows: every op between the GEMMs is
         # row-wise, so they never touch a real row) -- tuned solutions are keyed by the exact shape
         Tp = -(-T // self.ROW_GRANULE) * self.ROW_GRANULE if torch.cuda.tunable.is_enabled() else T
+        if torch.cuda.tunable.is_enabled() and self.FULL_ROWS * 7 // 8 < T <= self.FULL_ROWS:
+            Tp = self.FULL_ROWS                  # a (nearly) full sub-batch of the corpus encode: ONE row count, the one the recorded solutions are for
         x = None
         if Tp != T:                               # only the pad rows need zeros: the real ones are written by the kernel below
             x = torch.empty((Tp, self.word.shape[1]), dtype=torch.float32, device=dev)
