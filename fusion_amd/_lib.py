@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FUSION_AMD_LIB: another build of the same library (the host-sanitized one of `make -C fusion_amd/csrc hostasan`); same ABI check applies
 LIB_PATH = os.environ.get("FUSION_AMD_LIB") or os.path.join(_HERE, "libfusion_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 FZ_OK, FZ_ERR_ARG, FZ_ERR_UNSUPPORTED, FZ_ERR_HIP, FZ_ERR_WORKSPACE = 0, -1, -2, -3, -4
 NORMS = {"min-max": 1, "z-score": 2, "arctan": 3, "percentile-rank": 4, "normal-curve-equivalent": 5}
@@ -90,6 +90,7 @@ _PROTOS = {
     "fz_add_layernorm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, C.c_float, _i, _i, _vp, _i, _vp]),
     "fz_gelu_f32": (_i, [_vp, _vp, _sz, _vp]),
     "fz_attn_varlen_f16": (_i, [_vp, _i, _vp, _i, _i, _i, C.c_float, _vp, _i, _vp]),
+    "fz_attn_varlen_f16_amp": (_i, [_vp, _i, _vp, _i, _i, _i, C.c_float, _vp, _i, _vp]),
     "fz_add_layernorm_x16": (_i, [_vp, _i, _vp, _i, _vp, _vp, C.c_float, _i, _i, _vp, _i, _vp, _i, _vp]),
     "fz_gelu_f16": (_i, [_vp, _vp, _sz, _vp]),
     "fz_embed_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i, _i, _vp, _i, _vp]),

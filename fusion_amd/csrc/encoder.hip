@@ -209,6 +209,114 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 7
     }
 }
 
+// The attention of the MIXED-PRECISION forward with float16 matrix operands -- what torch.autocast does to a BERT layer (the reference's ColBERT:
+// colbert-ai's Checkpoint runs query() / doc() under autocast): q k^T and p v are float16 matmuls with float32 accumulation, the softmax between them
+// float32.  Same strips, same lane = query column softmax as attn_varlen_kernel, but on v_mfma_f32_16x16x32_f16 (S^T = K Q^T: two MFMAs per 16-key
+// tile instead of sixteen 16x16x4_f32) and v_mfma_f32_16x16x16_f16 (O^T = V^T P^T: four instead of sixteen), and with NO LDS at all:
+//   * the 16x16x32 operand layout -- lane l: row / column l % 16, k = 8 (l / 16) .. + 7 -- is a 16-byte piece of a head row: Q and K tiles are
+//     loaded straight into MFMA registers (dims 8 kg .. 8 kg + 7, and the same + 32 for the second MFMA; both operands permute the contraction
+//     index alike);
+//   * the C registers of S^T (lane (r, kg): keys 4 kg + i of query r) are, rounded to float16, the B operand of the 16x16x16 MFMA -- probabilities
+//     never move, as in the float32 kernel;
+//   * V: lane (r, kg) loads dims 4 r .. 4 r + 3 of keys 4 kg + i (8 bytes each, whole 128-byte head rows per instruction); output tile t takes the
+//     dims 4 r + t, so its A operand is element t of the four loads: a 4 x 4 transpose of halves inside the lane (8 v_perm per tile);
+//   * O^T comes out with lane (r, kg) holding dims 16 kg .. 16 kg + 15 of query r: two 16-byte stores per lane, no transpose.
+// Bounds-checked buffer loads as before (range = the sequence).  No branch between an MFMA and a reader of its result (tools/check_mfma_hazards.py).
+template <int NQ>
+__global__ __launch_bounds__(256) void attn_varlen_amp_kernel(AttnArgs a) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int grp = blockIdx.x / a.H;
+    const int h = blockIdx.x - grp * a.H;
+    const int strip = grp * 4 + wave;
+    if (strip >= a.n_strips) return;
+    const int4 st = a.strips[strip];
+    const int tok0 = st.x, L = st.y, q0 = st.z;
+    if (q0 >= L) return;
+    const int r = lane & 15, kg = lane >> 4;
+    const int hid = a.H * 64;
+    const int ldb = a.ld * 2;   // row pitch in bytes
+    const char* base = reinterpret_cast<const char*>(a.qkv) + ((size_t)tok0 * a.ld + h * 64) * 2;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (L * a.ld - h * 64) * 2, 0x00020000);
+    const int voff_qk = r * ldb + kg * 16;           // row r of the tile, dims 8 kg .. 8 kg + 7
+    const int voff_v = (4 * kg) * ldb + r * 8;       // key 4 kg (+ i), dims 4 r .. 4 r + 3
+
+    const bool second = NQ == 2 && q0 + 16 < L;      // wave-uniform: the strip's second 16 queries exist
+    h8v qf[NQ][2];
+    float m[NQ], l[NQ];
+    f32x4 o[NQ][4];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            qf[u][hf] = (u == 0 || second) ? __builtin_bit_cast(h8v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_qk, (q0 + 16 * u) * ldb + hf * 64, 0)) : h8v{};
+        m[u] = -INFINITY; l[u] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int j0 = 0; j0 < L; j0 += 16) {
+        h8v kf[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) kf[hf] = __builtin_bit_cast(h8v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_qk, j0 * ldb + hid * 2 + hf * 64, 0));
+        i32x2 vr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vr[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff_v, (j0 + i) * ldb + 2 * hid * 2, 0);
+        // A operands of the four output tiles: element t of the four keys' loads
+        h4v va[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t sel = (t & 1) ? 0x07060302u : 0x05040100u;
+            const int w = t >> 1;
+            const i32x2 x = {(int)__builtin_amdgcn_perm((uint32_t)vr[1][w], (uint32_t)vr[0][w], sel), (int)__builtin_amdgcn_perm((uint32_t)vr[3][w], (uint32_t)vr[2][w], sel)};
+            va[t] = __builtin_bit_cast(h4v, x);
+        }
+        const int left = L - (j0 + 4 * kg);
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            if (u == 1 && !second) break;
+            f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[u][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[u][1], s, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) s[g] = g < left ? s[g] : -INFINITY;     // keys past the sequence (read as zeros) drop out; a select, not a branch
+            float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            mx = xgroup_max(mx);
+            const float mnew = fmaxf(m[u], mx * a.scale_log2e);
+            const float alpha = __builtin_amdgcn_exp2f(m[u] - mnew);                // first tile: exp2(-inf) = 0, and o is 0
+            float psum = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                s[g] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[g], a.scale_log2e, -mnew));
+                psum += s[g];
+            }
+            psum = xgroup_sum(psum);
+            l[u] = l[u] * alpha + psum;
+            m[u] = mnew;
+            const h4v pb = {(_Float16)s[0], (_Float16)s[1], (_Float16)s[2], (_Float16)s[3]};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                o[u][t] *= alpha;
+                o[u][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pb, o[u][t], 0, 0, 0);
+            }
+        }
+    }
+    // o[u][t][g] = O[query 16 u + r][16 kg + 4 g + t]: 16 consecutive dims per lane
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        if (u == 1 && !second) break;
+        const float inv = 1.0f / l[u];
+        h8v lo, hi;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { lo[4 * g + t] = (_Float16)(o[u][t][g] * inv); hi[4 * g + t] = (_Float16)(o[u][t][g + 2] * inv); }
+        if (q0 + 16 * u + r < L) {
+            _Float16* op = a.out16 + (size_t)(tok0 + q0 + 16 * u + r) * a.ldo + h * 64 + 16 * kg;
+            *reinterpret_cast<h8v*>(op) = lo;
+            *reinterpret_cast<h8v*>(op + 8) = hi;
+        }
+    }
+}
+
 // LayerNorm(x + res) * gamma + beta; one wave per row, VPL float4 per lane (d <= 256 * VPL).  XH: x is float16 (a mixed-precision Linear's
 // output; the sum and the normalisation are float32 all the same); out16 non-null: the result is stored a second time as float16, the
 // operand of the next Linear (the float32 copy stays the residual stream).
@@ -421,6 +529,23 @@ extern "C" int fz_attn_varlen_f16(const void* qkv, int ld, const int32_t* strips
     const long long grid = (long long)((n_strips + 3) / 4) * H;
     if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
     attn_varlen_kernel<FZ_ATTN_NQ, true><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+extern "C" int fz_attn_varlen_f16_amp(const void* qkv, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
+                                     void* out, int ldo, void* stream) {
+    if (n_strips < 0 || H <= 0 || !(scale > 0.0f)) return FZ_ERR_ARG;
+    if (n_strips == 0) return FZ_OK;
+    if (!qkv || !strips || !out) return FZ_ERR_ARG;
+    if (head_dim != 64) return FZ_ERR_UNSUPPORTED;
+    if (ld < 3 * H * 64 || ldo < H * 64) return FZ_ERR_ARG;
+    if ((ld & 7) || (ldo & 7) || !aligned16(qkv) || !aligned16(out) || !aligned16(strips)) return FZ_ERR_UNSUPPORTED;   // 16-byte pieces of the rows
+    if ((long long)ld * 2 * 16384 > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
+    AttnArgs a{qkv, ld, reinterpret_cast<const int4*>(strips), n_strips, H, nullptr, ldo, scale * 1.4426950408889634f, reinterpret_cast<_Float16*>(out)};
+    const long long grid = (long long)((n_strips + 3) / 4) * H;
+    if (grid > 0x7fffffffLL) return FZ_ERR_UNSUPPORTED;
+    attn_varlen_amp_kernel<FZ_ATTN_NQ><<<(unsigned)grid, 256, 0, as_stream(stream)>>>(a);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

@@ -226,6 +226,7 @@ class PackedBertForward(FusedBertForward):
     head_dim must be 64 (BERT-base family)."""
 
     ROW_GRANULE = 512
+    AMP_ATTENTION = True    # the mixed-precision forward's attention on float16 MFMAs (autocast's matmuls); False: float32 arithmetic on the float16 rows
     FULL_ROWS = 65536       # = _Base.packed_tokens: the corpus encode cuts its sub-batches at this many token rows
     # Mixed precision as torch.autocast applies it to a BERT forward (what colbert-ai's Checkpoint wraps every query() / doc() in):
     # the Linears take float16 operands (float32 accumulate on the matrix pipe); everything between them -- attention, GELU,
@@ -259,7 +260,7 @@ class PackedBertForward(FusedBertForward):
             ctx16[T:].zero_()                      # the pad rows (attention writes the real ones in every layer)
         for ly in self.layers:
             qkv16 = F.linear(x16, lo(ly["wqkv"]), lo(ly["bqkv"])); mark("encode_gemm")
-            ops.attn_varlen_f16(qkv16, strips_d, H, ctx16); mark("encode_attn")
+            ops.attn_varlen_f16(qkv16, strips_d, H, ctx16, amp=self.AMP_ATTENTION); mark("encode_attn")
             y16 = F.linear(ctx16, lo(ly["wo"]), lo(ly["bo"])); mark("encode_gemm")
             x = ops.add_layernorm_x16(y16, x, *ly["ln1"], out16=x16); mark("encode_ln")
             h16 = F.linear(x16, lo(ly["w1"]), lo(ly["b1"])); mark("encode_gemm")

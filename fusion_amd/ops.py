@@ -1002,7 +1002,7 @@ def attn_varlen(qkv: torch.Tensor, strips: torch.Tensor, heads: int, scale: floa
     return out
 
 
-def attn_varlen_f16(qkv16: torch.Tensor, strips: torch.Tensor, heads: int, out: torch.Tensor) -> torch.Tensor:
+def attn_varlen_f16(qkv16: torch.Tensor, strips: torch.Tensor, heads: int, out: torch.Tensor, amp: bool = False) -> torch.Tensor:
     """attn_varlen on float16 fused-QKV rows with the context rows stored as float16 (`out` [T, heads*64] float16): the attention of the
     mixed-precision forward -- float32 scores, softmax and weighted sum between two float16 Linears."""
     _dev(qkv16, torch.float16, "attn_varlen_f16(qkv16)")
@@ -1014,8 +1014,9 @@ def attn_varlen_f16(qkv16: torch.Tensor, strips: torch.Tensor, heads: int, out: 
     if strips.dim() != 2 or strips.shape[1] != 4 or not strips.is_contiguous():
         raise ValueError("attn_varlen_f16: strips must be a contiguous [n_strips, 4] int32 tensor (ops.attn_strips)")
     _need(tuple(out.shape) == (T, heads * 64), f"attn_varlen_f16(out): expected shape {(T, heads * 64)}, got {tuple(out.shape)}")
-    check(_lib.lib().fz_attn_varlen_f16(_ptr(qkv16), qkv16.stride(0) if T > 1 else W, _ptr(strips), strips.shape[0], heads, 64, float(64 ** -0.5),
-                                        _ptr(out), out.stride(0) if T > 1 else heads * 64, _stream(qkv16)), "fz_attn_varlen_f16")
+    fn = _lib.lib().fz_attn_varlen_f16_amp if amp else _lib.lib().fz_attn_varlen_f16     # amp: float16 matmuls (autocast's arithmetic); else float32 throughout
+    check(fn(_ptr(qkv16), qkv16.stride(0) if T > 1 else W, _ptr(strips), strips.shape[0], heads, 64, float(64 ** -0.5),
+             _ptr(out), out.stride(0) if T > 1 else heads * 64, _stream(qkv16)), "fz_attn_varlen_f16_amp" if amp else "fz_attn_varlen_f16")
     return out
 
 

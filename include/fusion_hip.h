@@ -332,10 +332,15 @@ int fz_gelu_f32(const float* x, float* y, size_t count, void* stream);
  * colbert_ir.py:110,124): the Linears take and return float16, these kernels compute in float32 and hand the next Linear its float16 operand.
  *   fz_attn_varlen_f16:       as fz_attn_varlen_f32 with float16 fused-QKV rows in and float16 context rows out (8-byte aligned, ld / ldo in
  *                             elements); scores, softmax and the weighted sum are float32;
+ *   fz_attn_varlen_f16_amp:   the same rows in and out, but q k^T and p v as float16 matmuls with float32 accumulation (v_mfma_f32_16x16x32_f16 /
+ *                             16x16x16_f16) around a float32 softmax -- the arithmetic autocast gives the attention of a BERT layer; ld and ldo
+ *                             multiples of 8 elements, 16-byte aligned rows;
  *   fz_add_layernorm_x16:     x float16 (a Linear's output), res / out float32 (the residual stream), out16 nullable: a float16 copy of out;
  *   fz_gelu_f16:              float16 in and out (float32 arithmetic, as torch.nn.functional.gelu on a float16 tensor), count % 8 == 0. */
 int fz_attn_varlen_f16(const void* qkv /* float16 */, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
                        void* out /* float16 */, int ldo, void* stream);
+int fz_attn_varlen_f16_amp(const void* qkv /* float16 */, int ld, const int32_t* strips, int n_strips, int H, int head_dim, float scale,
+                           void* out /* float16 */, int ldo, void* stream);
 int fz_add_layernorm_x16(const void* x /* float16 */, int ldx, const float* res, int ldr, const float* gamma, const float* beta, float eps,
                          int rows, int d, float* out, int ldo, void* out16 /* float16, nullable */, int ldo16, void* stream);
 int fz_gelu_f16(const void* x /* float16 */, void* y /* float16 */, size_t count, void* stream);

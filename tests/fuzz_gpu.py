@@ -485,7 +485,11 @@ def case_f16_kernels(rng):
     sd = torch.from_numpy(strips).cuda()
     ctx16 = torch.empty((T, H * 64), dtype=torch.float16, device="cuda")
     ops.attn_varlen_f16(qkv16, sd, H, ctx16)
-    assert torch.equal(ctx16, ops.attn_varlen(qkv16.float(), sd, H).half())
+    exact = ops.attn_varlen(qkv16.float(), sd, H)
+    assert torch.equal(ctx16, exact.half())
+    amp = torch.empty_like(ctx16); ops.attn_varlen_f16(qkv16, sd, H, amp, amp=True)              # float16 MFMAs around the float32 softmax
+    again = torch.empty_like(ctx16); ops.attn_varlen_f16(qkv16, sd, H, again, amp=True)
+    assert torch.equal(amp, again) and (amp.float() - exact).abs().max().item() <= 3e-3 * max(1.0, exact.abs().max().item())
     return f"f16 kernels rows={rows} d={d} n={n} H={H} lens={lens.tolist()}"
 
 

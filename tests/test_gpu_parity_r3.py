@@ -556,3 +556,27 @@ def test_mfma_kernels_are_bit_reproducible(ops):
     r = ops.splade_head_max(x, W, b, cu).clone()
     for _ in range(2):
         assert torch.equal(ops.splade_head_max(x, W, b, cu), r)
+
+
+@pytest.mark.parametrize("H,lens", [(2, [5, 64, 1, 33, 17]), (12, [300, 512, 16, 129, 31, 250]), (1, [1]), (3, [16, 32, 48, 15, 47])])
+def test_amp_attention_matches_float64_and_the_float32_kernel(ops, H, lens):
+    """fz_attn_varlen_f16_amp (float16 MFMAs for q k^T and p v, float32 softmax: autocast's arithmetic) against a float64 softmax(q k^T / 8) v
+    of the same float16 inputs and against the float32-arithmetic kernel: within float16 rounding of the probabilities; reruns identical."""
+    g = torch.Generator(device="cuda").manual_seed(len(lens) * 10 + H)
+    lens = np.array(lens)
+    strips, cu = ops.attn_strips(lens)
+    sd = torch.from_numpy(strips).cuda()
+    T = int(cu[-1])
+    qkv16 = (torch.randn((T, 3 * H * 64), generator=g, device="cuda") * 1.5).half()
+    out = torch.empty((T, H * 64), dtype=torch.float16, device="cuda")
+    ops.attn_varlen_f16(qkv16, sd, H, out, amp=True)
+    again = torch.empty_like(out); ops.attn_varlen_f16(qkv16, sd, H, again, amp=True)
+    assert torch.equal(out, again)
+    exact = torch.empty_like(out); ops.attn_varlen_f16(qkv16, sd, H, exact, amp=False)
+    for b, L in enumerate(lens.tolist()):
+        blk = qkv16[cu[b]: cu[b] + L].double().view(L, 3, H, 64)
+        q, k, v = blk[:, 0].transpose(0, 1), blk[:, 1].transpose(0, 1), blk[:, 2].transpose(0, 1)
+        ref = (torch.softmax(q @ k.transpose(1, 2) / 8.0, -1) @ v).transpose(0, 1).reshape(L, H * 64)
+        scale = max(1.0, ref.abs().max().item())
+        assert (out[cu[b]: cu[b] + L].double() - ref).abs().max().item() <= 3e-3 * scale
+        assert (out[cu[b]: cu[b] + L].float() - exact[cu[b]: cu[b] + L].float()).abs().max().item() <= 3e-3 * scale

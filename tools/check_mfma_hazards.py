@@ -10,7 +10,8 @@ Usage: python tools/check_mfma_hazards.py file.s [...]      (hipcc -S --cuda-dev
 import re, sys
 
 # passes (4 cycles each) on gfx950: FLOPs of the instruction / (FLOPs per SIMD and cycle of its type) / 4
-PASSES = {"16x16x4_f32": 8, "32x32x2_f32": 16, "16x16x32_f16": 4, "16x16x32_bf16": 4, "32x32x16_f16": 8, "32x32x16_bf16": 8, "16x16x4_f64": 16}
+PASSES = {"16x16x4_f32": 8, "32x32x2_f32": 16, "16x16x32_f16": 4, "16x16x32_bf16": 4, "32x32x16_f16": 8, "32x32x16_bf16": 8, "16x16x4_f64": 16,
+          "16x16x16_f16": 8, "16x16x16_bf16": 8, "32x32x8_f16": 16, "32x32x8_bf16": 16}    # the K-halved forms: at most these (conservative)
 def need(op):
     for k, p in PASSES.items():
         if k in op:
