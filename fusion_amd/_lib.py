@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FUSION_AMD_LIB: another build of the same library (the host-sanitized one of `make -C fusion_amd/csrc hostasan`); same ABI check applies
 LIB_PATH = os.environ.get("FUSION_AMD_LIB") or os.path.join(_HERE, "libfusion_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 FZ_OK, FZ_ERR_ARG, FZ_ERR_UNSUPPORTED, FZ_ERR_HIP, FZ_ERR_WORKSPACE = 0, -1, -2, -3, -4
 NORMS = {"min-max": 1, "z-score": 2, "arctan": 3, "percentile-rank": 4, "normal-curve-equivalent": 5}
@@ -57,6 +57,10 @@ _PROTOS = {
     "fz_fuse_nsf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "fz_fuse_nsf_stats_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "fz_fuse_nsf_pstats_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "fz_nsf_tables_workspace_bytes": (_sz, [_i, _vp, _i]),
+    "fz_nsf_tables_prepare": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "fz_fuse_nsf_tables_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "fz_nsf_tables_path": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fz_zero_unlisted_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "fz_minmax_from_orders_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "fz_minmax_from_order_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -13,6 +13,7 @@
 // for the purely elementwise ones.  Compiled with -ffp-contract=off: the reference's
 // arithmetic is unfused and the oracle checks it bit for bit.
 #include "common.h"
+#include "nsf.h"
 
 namespace fz {
 
@@ -214,22 +215,6 @@ __global__ __launch_bounds__(THREADS) void row_stats_kernel(const float* __restr
 // registers and accumulated into the fused registers.  HBM traffic = (S+1)*N*4 B per query
 // (+ S*N*4 when rank planes carry validity).
 // -------------------------------------------------------------------------------------
-// cache-policy operand of global_load_lds on gfx940+: 2 = nt (the planes are streamed exactly once)
-#define FZ_CPOL_NT 2
-
-struct NsfArgs {
-    const float* planes[FZ_MAX_SYSTEMS];
-    const int32_t* ranks[FZ_MAX_SYSTEMS];
-    const uint32_t* vbits[FZ_MAX_SYSTEMS];   // validity of system s as a bitmap [Q][ldb] (bit j & 31 of word j >> 5), built once per system
-    int ldb;                                 //   (fz_rank_to_bitmap): 1/32 of the bytes of the rank plane it replaces in the fusion passes
-    const float* distr[FZ_MAX_SYSTEMS];
-    int P[FZ_MAX_SYSTEMS];
-    float w[FZ_MAX_SYSTEMS];
-    const float* sa[FZ_MAX_SYSTEMS];         // per-system row statistics [Q] (min | mean) and (max | unbiased std) for the flat passes: each system
-    const float* sb[FZ_MAX_SYSTEMS];         //   brings its own (a by-product of the sort that ranked it), nothing is concatenated per fusion call
-    int S, N, ld, Q;
-};
-
 // Combined block reduction of up to 3 doubles (one barrier pair for all statistics of a row).
 template <int THREADS, int NV>
 __device__ __forceinline__ void block_sum_n(double (&v)[NV], double* red /* NV*THREADS/64 */) {
@@ -251,10 +236,6 @@ __device__ __forceinline__ void block_sum_n(double (&v)[NV], double* red /* NV*T
         v[k] = s;
     }
 }
-
-// Barrier that does NOT drain pending LDS-DMA (a __syncthreads() would: hipcc emits vmcnt(0) in front of it while a
-// global_load_lds is in flight, which would serialise the prefetch below).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Single-barrier block reductions: the partial slots are double-buffered by `parity` (the caller alternates it per
 // use), so the write of round r+1 cannot overtake the reads of round r -- one s_barrier per reduction instead of two.
@@ -294,14 +275,6 @@ __device__ __forceinline__ void block_sum_n_nodrain(double (&v)[NV], double* red
         for (int i = 0; i < NW; ++i) s += r[k * NW + i];  // fixed order: deterministic
         v[k] = s;
     }
-}
-
-// validity of the 4 columns j0 .. j0+3 (j0 % 4 == 0) of row q as a nibble: from the bitmap when the system has one, else from its rank plane
-__device__ __forceinline__ uint32_t valid_nibble(const NsfArgs& a, int s, int q, size_t rowoff, int j0) {
-    if (a.vbits[s]) return (a.vbits[s][(size_t)q * a.ldb + (j0 >> 5)] >> (j0 & 31)) & 0xfu;
-    if (!a.ranks[s]) return 0xfu;
-    const int4 r = *reinterpret_cast<const int4*>(a.ranks[s] + rowoff + j0);
-    return (r.x >= 0 ? 1u : 0u) | (r.y >= 0 ? 2u : 0u) | (r.z >= 0 ? 4u : 0u) | (r.w >= 0 ? 8u : 0u);
 }
 
 // K4.  One workgroup of T threads per query; thread t owns columns {4*(t + T*i) .. +3}, i < E4.
@@ -765,15 +738,14 @@ __global__ __launch_bounds__(TPB) void fuse_nsf_table_kernel(NsfArgs a, TableArg
     }
 }
 
-// returns 1 when the LDS-table kernel cannot take the call (tables too long for LDS, planes not 16-B aligned)
-static int launch_nsf_tables(const NsfArgs& a, bool nce, int Q, float* fused, hipStream_t st) {
-    TableArgs t{};
+// layout of the LDS-resident tables; false when they cannot all live in LDS (tables too long, planes not 16-B aligned)
+static bool nsf_tables_plan(const NsfArgs& a, const float* fused, TableArgs& t, size_t& lds) {
     int total = 0;
     bool vec = (a.ld % 4 == 0) && ((uintptr_t)fused % 16 == 0);
     for (int s = 0; s < a.S; ++s) {
         t.off[s] = total;
         total += a.P[s];
-        if (a.P[s] > 65535) return 1;   // uint16 indices
+        if (a.P[s] > 65535) return false;   // uint16 indices
         vec = vec && ((uintptr_t)a.planes[s] % 16 == 0) && (!a.ranks[s] || (uintptr_t)a.ranks[s] % 16 == 0);
     }
     t.total = total;
@@ -781,8 +753,20 @@ static int launch_nsf_tables(const NsfArgs& a, bool nce, int Q, float* fused, hi
     for (int s = 0; s < a.S; ++s) { t.uoff[s] = utotal; utotal += ((a.P[s] + 3) & ~3) + 8; }
     t.uoff[a.S] = utotal;
     t.utotal = utotal;
-    const size_t lds = (size_t)(2 * utotal + 2 * total) * 4 + (size_t)((total + 1) & ~1) * 2 * 2 + (size_t)a.S * (2 * LUT_B + 1) * 2 + 16;
-    if (!vec || lds > 144 * 1024) return 1;
+    lds = (size_t)(2 * utotal + 2 * total) * 4 + (size_t)((total + 1) & ~1) * 2 * 2 + (size_t)a.S * (2 * LUT_B + 1) * 2 + 16;
+    return vec && lds <= 144 * 1024;
+}
+bool nsf_tables_fit_lds(const NsfArgs& a, const float* fused) {
+    TableArgs t{};
+    size_t lds = 0;
+    return nsf_tables_plan(a, fused, t, lds);
+}
+
+// returns 1 when the LDS-table kernel cannot take the call
+int launch_nsf_tables(const NsfArgs& a, bool nce, int Q, float* fused, hipStream_t st) {
+    TableArgs t{};
+    size_t lds = 0;
+    if (!nsf_tables_plan(a, fused, t, lds)) return 1;
     // one 1024-thread workgroup per CU: the tables, look-up tables and (NCE) per-index values are built once per workgroup and
     // serve 16 waves
     constexpr int tpb = 1024;
@@ -1061,17 +1045,10 @@ extern "C" int fz_rank_to_bitmap(const int32_t* rank, int rows, int N, int ld, u
     return FZ_OK;
 }
 
-extern "C" int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q,
-                               int N, int ld, int norm, const float* const* distr_h, const int32_t* P_h,
-                               const uint32_t* const* valid_bits_h, int ldb, float* fused, void* stream) {
-    if (!planes_h || !w_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
-    if (norm == FZ_NORM_NONE) return FZ_ERR_ARG;  // float64 passthrough lives in fz_fuse_none_f64
-    if (norm < FZ_NORM_MINMAX || norm > FZ_NORM_NCE) return FZ_ERR_ARG;
-    if (!fused && Q != 0 && N != 0) return FZ_ERR_ARG;   // empty tensors carry null pointers
-    const bool needs_distr = (norm == FZ_NORM_PERCENTILE || norm == FZ_NORM_NCE);
-    if (needs_distr && (!distr_h || !P_h)) return FZ_ERR_ARG;
-    if (Q == 0 || N == 0) return FZ_OK;
-    NsfArgs a{};
+namespace fz {
+int nsf_fill_args(NsfArgs& a, const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N, int ld,
+                  bool needs_distr, const float* const* distr_h, const int32_t* P_h, const uint32_t* const* valid_bits_h, int ldb) {
+    a = NsfArgs{};
     a.S = S; a.N = N; a.ld = ld; a.Q = Q;
     for (int s = 0; s < S; ++s) {
         if (!planes_h[s]) return FZ_ERR_ARG;
@@ -1085,6 +1062,22 @@ extern "C" int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* cons
     }
     a.ldb = ldb;
     if (valid_bits_h && ldb * 32 < N) return FZ_ERR_ARG;
+    return FZ_OK;
+}
+}  // namespace fz
+
+extern "C" int fz_fuse_nsf_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q,
+                               int N, int ld, int norm, const float* const* distr_h, const int32_t* P_h,
+                               const uint32_t* const* valid_bits_h, int ldb, float* fused, void* stream) {
+    if (!planes_h || !w_h || S <= 0 || S > FZ_MAX_SYSTEMS || Q < 0 || N < 0 || ld < N) return FZ_ERR_ARG;
+    if (norm == FZ_NORM_NONE) return FZ_ERR_ARG;  // float64 passthrough lives in fz_fuse_none_f64
+    if (norm < FZ_NORM_MINMAX || norm > FZ_NORM_NCE) return FZ_ERR_ARG;
+    if (!fused && Q != 0 && N != 0) return FZ_ERR_ARG;   // empty tensors carry null pointers
+    const bool needs_distr = (norm == FZ_NORM_PERCENTILE || norm == FZ_NORM_NCE);
+    if (needs_distr && (!distr_h || !P_h)) return FZ_ERR_ARG;
+    if (Q == 0 || N == 0) return FZ_OK;
+    NsfArgs a{};
+    if (int rc = nsf_fill_args(a, planes_h, ranks_h, w_h, S, Q, N, ld, needs_distr, distr_h, P_h, valid_bits_h, ldb)) return rc;
     hipStream_t st = as_stream(stream);
     int too_long = 1;
     switch (norm) {

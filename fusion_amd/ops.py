@@ -362,18 +362,56 @@ def minmax_from_order(scores: torch.Tensor, order: torch.Tensor, lens: torch.Ten
     return mn, mx
 
 
+TABLES_PATHS = {0: "lds-all", 1: "lds-swap", 2: "row"}
+
+
+class PreparedTables:
+    """Quantile tables of a percentile-rank / NCE fusion made ready for the kernel that keeps one system's table in LDS at a time
+    (fz_nsf_tables_prepare): aligned copies, bucket tables and -- NCE -- the value of every table index, in one workspace tensor.
+    Valid for any number of fuse_nsf calls with these tables and this norm (hybrid.py:412,451 read the tables once per process)."""
+
+    def __init__(self, distr: list[torch.Tensor], norm: str, workspace: torch.Tensor):
+        self.distr, self.norm, self.workspace = distr, norm, workspace
+
+    def matches(self, distr, norm) -> bool:
+        return norm == self.norm and len(distr) == len(self.distr) and all(
+            a.data_ptr() == b.data_ptr() and a.numel() == b.numel() for a, b in zip(distr, self.distr))
+
+
+def nsf_tables_prepare(distr: list[torch.Tensor], norm: str) -> PreparedTables | None:
+    """None when a table is too long for LDS (fuse_nsf then searches it in global memory)."""
+    _need(norm in ("percentile-rank", "normal-curve-equivalent"), f"nsf_tables_prepare: {norm!r} has no tables")
+    distr = [_dev(d, torch.float32, "distr").contiguous() for d in distr]
+    S = len(distr)
+    _need(all(d.dim() == 1 and d.numel() > 0 for d in distr), "nsf_tables_prepare: tables must be non-empty 1-d tensors")
+    P = (C.c_int32 * S)(*[int(d.numel()) for d in distr])
+    lib = _lib.lib()
+    nbytes = int(lib.fz_nsf_tables_workspace_bytes(S, P, NORMS[norm]))
+    if nbytes == 0:
+        return None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=distr[0].device)
+    check(lib.fz_nsf_tables_prepare(_ptr_array(distr), P, S, NORMS[norm], _ptr(ws), nbytes, _stream(distr[0])), "fz_nsf_tables_prepare")
+    return PreparedTables(distr, norm, ws)
+
+
+last_tables_path: str | None = None   # which kernel the last percentile-rank / NCE fuse_nsf call ran (tests pin it)
+
+
 def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None, weights, norm: str,
              distr: list[torch.Tensor] | None = None, out: torch.Tensor | None = None,
              orders: list[torch.Tensor] | None = None, lens: torch.Tensor | None = None,
              stats=None,
-             valid_bits: list[torch.Tensor | None] | None = None) -> torch.Tensor:
+             valid_bits: list[torch.Tensor | None] | None = None,
+             tables: PreparedTables | None | bool = None) -> torch.Tensor:
     """normalise -> weight -> sum in one HBM pass (hybrid.py:212-214,254-280,291,301-304).
     orders (+ lens [S, Q]): the systems' order planes, when they are ranked -- min-max then takes every list's minimum and
     maximum from its two ends and the fusion is one flat streaming pass (same bits as the reducing kernel).
     stats: the row statistics (min / max, or mean / unbiased std), when the caller has them -- the fusion is then one flat streaming
     pass.  Either (a, b) = two contiguous [S*Q] fp32 tensors, or a list of S pairs (a_s, b_s) of [Q] fp32 tensors, one per system:
     each ranked system keeps the statistics its ranking sort produced (sort_rows_desc(stats_out=...)), nothing is concatenated.
-    valid_bits[s] (optional): the validity of system s as a bitmap (rank_to_bitmap), read instead of its rank plane."""
+    valid_bits[s] (optional): the validity of system s as a bitmap (rank_to_bitmap), read instead of its rank plane.
+    tables (optional): nsf_tables_prepare(distr, norm) of these very tables, to prepare them once for many calls; False: stay on
+    fz_fuse_nsf_f32 whatever the table size (its all-tables-in-LDS kernel or its global-memory search: what tests compare against)."""
     for p in planes:
         _dev(p, torch.float32, "fuse_nsf(planes)")
     S = len(planes)
@@ -455,6 +493,22 @@ def fuse_nsf(planes: list[torch.Tensor], ranks: list[torch.Tensor | None] | None
         check(lib.fz_fuse_nsf_stats_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm],
                                         dptr, P, _ptr(sa), _ptr(sb), vb, ldb, _ptr(fused), _stream(planes[0])), "fz_fuse_nsf_stats_f32")
         return fused
+    if dptr is not None and Q > 0 and N > 0:
+        # quantile tables: all of them LDS-resident (small tables), one system's at a time (the sizes the reference reads:
+        # hybrid.py:412,451 -- 27,943 entries; :374 -- 10,001), or searched in global memory (longer still)
+        global last_tables_path
+        rp = None if ranks is None else _ptr_array(ranks)
+        path = lib.fz_nsf_tables_path(_ptr_array(planes), rp, S, Q, N, ld, NORMS[norm], P, _ptr(fused))
+        _need(path in TABLES_PATHS, f"fz_nsf_tables_path: status {path}")
+        last_tables_path = TABLES_PATHS[path]
+        if tables is False:
+            last_tables_path = TABLES_PATHS[0 if path == 0 else 2]
+        elif path == 1:
+            if tables is None or not tables.matches(distr, norm):
+                tables = nsf_tables_prepare(distr, norm)
+            check(lib.fz_fuse_nsf_tables_f32(_ptr_array(planes), rp, w, S, Q, N, ld, NORMS[norm], dptr, P, vb, ldb, _ptr(fused),
+                                             _ptr(tables.workspace), tables.workspace.numel(), _stream(planes[0])), "fz_fuse_nsf_tables_f32")
+            return fused
     rc = lib.fz_fuse_nsf_f32(_ptr_array(planes), None if ranks is None else _ptr_array(ranks), w, S, Q, N, ld, NORMS[norm], dptr, P,
                              vb, ldb, _ptr(fused), _stream(planes[0]))
     if rc == _lib.FZ_ERR_UNSUPPORTED:

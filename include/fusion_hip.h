@@ -173,6 +173,31 @@ int fz_fuse_nsf_stats_f32(const float* const* planes_h, const int32_t* const* ra
 int fz_fuse_nsf_pstats_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
                            int ld, int norm, const float* const* distr_h, const int32_t* P_h, const float* const* stat_a_h,
                            const float* const* stat_b_h, const uint32_t* const* valid_bits_h, int ldb, float* fused, void* stream);
+/* ---- percentile-rank / NCE at the table sizes the reference READS: hybrid.py:412,451 (score_distributions_raw_*_28k.csv: |corpus| + 1 =
+ * 27,943 quantiles per system) and :374 (_10k: 10,001).  fz_fuse_nsf_f32 keeps all S tables in LDS up to ~1.4 k entries per system at
+ * S = 4 and beyond that searches them in global memory (correct, slow).  These entries keep ONE system's table LDS-resident at a time
+ * (up to ~38 k entries) and need a prepared workspace: an aligned copy of every table, its bucket table and -- NCE -- the value of every
+ * table index.  Same results as fz_fuse_nsf_f32, bit for bit.
+ *   fz_nsf_tables_workspace_bytes: bytes for these table lengths (0: a table is too long for LDS or an argument is bad);
+ *   fz_nsf_tables_prepare: fills the workspace from the S ascending device tables (one small launch; the workspace stays valid for
+ *     any number of fusion calls with the same tables, lengths and norm);
+ *   fz_fuse_nsf_tables_f32: fz_fuse_nsf_f32's arguments + the prepared workspace.  FZ_ERR_UNSUPPORTED when a table does not fit LDS or
+ *     the planes are not 16-byte aligned with ld % 4 == 0: fz_fuse_nsf_f32 takes those.  Calls whose tables ALL fit LDS at once run
+ *     fz_fuse_nsf_f32's table kernel (the workspace is then not read);
+ *   fz_nsf_tables_path: which kernel the call above runs for these shapes and pointers (a fz_tables_path, or FZ_ERR_ARG). */
+typedef enum {
+    FZ_TABLES_PATH_LDS_ALL = 0,   /* every table LDS-resident for the whole launch (fuse_nsf_table_kernel) */
+    FZ_TABLES_PATH_LDS_SWAP = 1,  /* one system's table LDS-resident at a time (fuse_nsf_bigtab_kernel) */
+    FZ_TABLES_PATH_ROW = 2        /* not taken by fz_fuse_nsf_tables_f32: fz_fuse_nsf_f32's global-memory search */
+} fz_tables_path;
+size_t fz_nsf_tables_workspace_bytes(int S, const int32_t* P_h, int norm);
+int fz_nsf_tables_prepare(const float* const* distr_h, const int32_t* P_h, int S, int norm, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int fz_fuse_nsf_tables_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,
+                           int ld, int norm, const float* const* distr_h, const int32_t* P_h, const uint32_t* const* valid_bits_h,
+                           int ldb, float* fused, const void* workspace, size_t workspace_bytes, void* stream);
+int fz_nsf_tables_path(const float* const* planes_h, const int32_t* const* ranks_h, int S, int Q, int N, int ld, int norm,
+                       const int32_t* P_h, const float* fused);
 /* plane[q][j] = 0 where rank[q][j] < 0.  A system adds nothing for a document it does not list (hybrid.py:301-304); the
  * single-system planes of fz_fuse_nsf_f32 hold -inf there (see below), the weight sweep wants 0. */
 int fz_zero_unlisted_f32(float* plane, const int32_t* rank, int Q, int N, int ld, void* stream);

@@ -28,7 +28,7 @@ their arithmetic is not reproduced here ("parity unpinned" at those call sites,
 see DESIGN.md).
 
 Fixtures are data only: seeded synthetic inputs + the reference's outputs.
-Usage: python oracle/gen_golden.py  (rewrites tests/golden/*.npz|json)
+Usage: python oracle/gen_golden.py [generator ...]  (rewrites tests/golden/*.npz|json; no argument = all of them)
 """
 import json
 import os
@@ -563,25 +563,111 @@ def gen_unsorted(Aggregator):
         json.dump(out, f)
 
 
+def _reference_tables(rng, systems, n_draws, n, n_points):
+    """Quantile tables the way hybrid.py:389-397 makes them from the pooled scores of a run: zeros and each system's two smallest
+    distinct scores dropped, then `quantile(np.linspace(0, 1, n_points + 1))` -- n_points = len(corpus) gives the `_28k` table
+    hybrid.py:412,451 read (27,943 rows), 10,000 the `_10k` table of :374."""
+    import pandas as pd
+    out = {}
+    for s in systems:
+        pool = pd.Series(np.concatenate([synth_system_scores(rng, s, n, "plain") for _ in range(n_draws)]).astype(np.float64))
+        kept = pool[(pool != 0.0) & (~pool.isin(pool.drop_duplicates().nsmallest(2)))]
+        out[s] = kept.quantile(np.linspace(0, 1, n_points + 1)).to_numpy(dtype=np.float64)
+    return out
+
+
+def gen_pr28k(Aggregator):
+    """percentile-rank / normal-curve-equivalent at the table size the reference READS (hybrid.py:412,451: the `_28k` table has
+    len(corpus) + 1 = 27,943 rows per system): one full LLeQA row, S = 4, the ColBERT list cut to 60 %.  The reference's
+    [P, N] distance matrix is 3.1 GB per list here.  Planted: a run of duplicated quantiles, scores that ARE table entries,
+    scores exactly half-way between two entries, scores below and above the table."""
+    import copy
+    rng = np.random.default_rng(60)
+    S, Q, N = 4, 1, 27942
+    systems, ids, lists = make_case(rng, S, Q, N, "plain")
+    distr = _reference_tables(rng, systems, 3, N, N)
+    assert all(len(t) == N + 1 for t in distr.values())
+    distr["dpr"][5000:5032] = distr["dpr"][5000]               # duplicated quantiles: the FIRST of them is the argmin (hybrid.py:274)
+    distr["colbert"][20000:20003] = distr["colbert"][20000]
+    for s in systems:                                             # planted scores, as float32 values like every other score
+        t32 = distr[s].astype(np.float32)
+        l = lists[s][0]
+        for j, k in enumerate(range(100, 27000, 1500)):
+            l[40 + 3 * j]["score"] = float(t32[k])                                        # a table entry itself
+            l[41 + 3 * j]["score"] = float(np.float32((np.float64(t32[k]) + np.float64(t32[k + 1])) / 2))   # (rounded) midpoint
+        l[7]["score"] = float(np.float32(t32[-1] + np.float32(3.5)))                      # above the table
+        l[9]["score"] = float(np.float32(t32[0] - np.float32(1.25)))                      # below the table
+        if s == "dpr":
+            l[11]["score"] = float(t32[5010])                                             # inside the duplicated run
+    weights = {"bm25": 0.15, "dpr": 0.35, "splade": 0.3, "colbert": 0.2}
+    in_ids, in_sc, in_len = pack_lists(systems, lists, Q)
+    blob = {"systems": np.array(systems), "in_ids": in_ids.astype(np.int32), "in_scores": in_sc.astype(np.float32), "in_len": in_len,
+            "weights": np.array([weights[s] for s in systems], dtype=np.float64)}
+    assert np.array_equal(blob["in_scores"].astype(np.float64), in_sc)
+    for s in systems:
+        blob[f"distr_{s}"] = distr[s]
+    for norm in ["percentile-rank", "normal-curve-equivalent"]:
+        fused = Aggregator.fuse(copy.deepcopy(lists), method="nsf", normalization=norm, linear_weights=weights, percentile_distributions=distr)
+        o_ids, o_sc, o_len = pack_out(fused, Q)
+        blob[f"out_ids__nsf__{norm}"] = o_ids.astype(np.int32)
+        blob[f"out_scores__nsf__{norm}"] = o_sc.astype(np.float32)
+        assert np.array_equal(blob[f"out_scores__nsf__{norm}"].astype(np.float64), o_sc, equal_nan=True)
+        blob[f"out_len__nsf__{norm}"] = o_len
+    np.savez_compressed(os.path.join(OUT, f"pr28k_seed60_S{S}_Q{Q}_N{N}.npz"), **blob)
+
+
+def gen_tune10k(Aggregator):
+    """The weight-grid loop (hybrid.py:404-426) with 10,001-entry tables (the `_10k` size of hybrid.py:374), percentile-rank and NCE."""
+    import copy
+    from src.retrievers.hybrid import run_evaluation
+    seed, S, Q, N = 22, 2, 4, 257
+    rng = np.random.default_rng(seed)
+    systems, ids, lists = make_case(rng, S, Q, N, "plain")
+    labels = []
+    for q in range(Q):
+        pool = [x["corpus_id"] for s in systems for x in lists[s][q][:40]]
+        labels.append([int(x) for x in rng.choice(pool, size=int(rng.integers(1, 5)), replace=False).tolist()])
+    distr = _reference_tables(rng, systems, 60, N, 10000)
+    combos = _lattice(systems)
+    in_ids, in_sc, in_len = pack_lists(systems, lists, Q)
+    blob = {"systems": np.array(systems), "in_ids": in_ids, "in_scores": in_sc, "in_len": in_len,
+            "labels": np.array([",".join(str(x) for x in g) for g in labels]),
+            "weights": np.array([[w[s] for s in systems] for w in combos], dtype=np.float64)}
+    for s in systems:
+        blob[f"distr_{s}"] = distr[s]
+    names = None
+    for norm in ["percentile-rank", "normal-curve-equivalent"]:
+        rows = []
+        for w in combos:
+            fused = Aggregator.fuse(copy.deepcopy(lists), method="nsf", normalization=norm, percentile_distributions=distr, linear_weights=w)
+            perf = run_evaluation(predictions=[[x["corpus_id"] for x in r] for r in fused], labels=labels, print2console=False)
+            names = names or list(perf.keys())
+            assert list(perf.keys()) == names
+            rows.append([float(perf[k]) for k in names])
+        blob[f"metrics__{norm}"] = np.array(rows, dtype=np.float64)
+    blob["metric_names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, f"tune10k_seed{seed}_S{S}_Q{Q}_N{N}.npz"), **blob)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     # splade first: transformers' lazy imports probe optional packages with importlib.util.find_spec, which chokes on
     # the spec-less placeholder modules that load_reference() installs for hybrid.py / bm25.py
     BaseModel, SPLADE = load_reference_splade()
     Aggregator, BM25, Metrics = load_reference()
-    names = gen_fuse(Aggregator)
-    gen_kat(Aggregator)
-    gen_bm25(BM25)
-    gen_metrics(Metrics)
-    gen_similarity(BaseModel)
-    gen_search(BaseModel)
-    gen_splade_pool(SPLADE)
-    gen_tune(Aggregator)
-    gen_analysis(Aggregator)
-    gen_unsorted(Aggregator)
-    gen_fullrow(Aggregator)
+    only = set(sys.argv[1:])   # e.g. `python oracle/gen_golden.py pr28k tune10k`: those generators alone (default: all)
+    names = []
+    if not only or "fuse" in only:
+        names = gen_fuse(Aggregator)
+    for key, fn, arg in [("kat", gen_kat, Aggregator), ("bm25", gen_bm25, BM25), ("metrics", gen_metrics, Metrics),
+                         ("similarity", gen_similarity, BaseModel), ("search", gen_search, BaseModel),
+                         ("splade_pool", gen_splade_pool, SPLADE), ("tune", gen_tune, Aggregator), ("analysis", gen_analysis, Aggregator),
+                         ("unsorted", gen_unsorted, Aggregator), ("fullrow", gen_fullrow, Aggregator), ("pr28k", gen_pr28k, Aggregator),
+                         ("tune10k", gen_tune10k, Aggregator)]:
+        if not only or key in only:
+            fn(arg)
     print("wrote", len(names), "fuse fixtures + kat_fuse.json, bm25.json, metrics.json, sim_*.npz, search_*.npz, splade_pool_*.npz, "
-          "tune_*.npz, analysis_*.npz, unsorted_fuse.json, fuse_fullrow_*.npz ->", os.path.normpath(OUT))
+          "tune_*.npz, analysis_*.npz, unsorted_fuse.json, fuse_fullrow_*.npz, pr28k_*.npz, tune10k_*.npz ->", os.path.normpath(OUT))
 
 
 if __name__ == "__main__":

@@ -64,6 +64,49 @@ def bench_nsf(Q=1024, N=27942, S=4):
     emit("row_stats_kernel<z-score>", ms, Q * N * 4, HBM, "GB/s", Q=Q, N=N)
 
 
+def lleqa_planes(Q, N, g):
+    """Four systems shaped like SURVEY 8d/C4: bm25-like (>= 0, ~40 % zeros), cosine-like, SPLADE-like, ColBERT-like."""
+    def plane(t):
+        p = ops.alloc_plane(Q, N, torch.float32, "cuda"); p.copy_(t); return p
+    r = lambda: torch.randn((Q, N), generator=g, device="cuda")
+    return [plane(torch.clamp(3.0 * r() - 1.0, min=0.0)), plane(torch.tanh(0.3 * r())), plane(torch.log1p(torch.relu(r()))), plane(20.0 + 4.0 * r())]
+
+
+def quantile_table(p, P):
+    """hybrid.py:389-397: quantiles of a system's pooled non-zero scores, P = n_points + 1 entries."""
+    pool = p[:64].flatten()
+    pool = torch.sort(pool[pool != 0.0].double()).values
+    idx = torch.linspace(0, pool.numel() - 1, P, device="cuda", dtype=torch.float64)
+    lo = idx.floor().long(); hi = torch.clamp(lo + 1, max=pool.numel() - 1); f = idx - lo
+    return (pool[lo] + (pool[hi] - pool[lo]) * f).float().contiguous()
+
+
+def bench_tables(N=27942, S=4):
+    """percentile-rank / NCE at the table sizes the reference reads (hybrid.py:412,451: 27,943; :374: 10,001): the kernel that
+    keeps one system's table in LDS at a time (tables.hip) against fz_fuse_nsf_f32's global-memory search it replaces there."""
+    g = torch.Generator(device="cuda").manual_seed(7)
+    for Q in (1024, 195):
+        planes = lleqa_planes(Q, N, g)
+        out = ops.alloc_plane(Q, N, torch.float32, "cuda")
+        w = [0.25] * S
+        for P in (27943, 10001):
+            distr = [quantile_table(p, P) for p in planes]
+            for norm in ("percentile-rank", "normal-curve-equivalent"):
+                prep = ops.nsf_tables_prepare(distr, norm)
+                ms = timeit(lambda: ops.fuse_nsf(planes, None, w, norm, distr, out=out, tables=prep))
+                assert ops.last_tables_path == "lds-swap"
+                emit(f"fuse_nsf_bigtab_kernel<{norm}> S={S} P={P} (tables prepared once)", ms, (S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
+                ms = timeit(lambda: ops.fuse_nsf(planes, None, w, norm, distr, out=out))
+                emit(f"fz_nsf_tables_prepare + fuse_nsf_bigtab_kernel<{norm}> S={S} P={P}", ms, (S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
+                if Q == 1024 and P == 27943:
+                    ms1 = timeit(lambda: ops.fuse_nsf(planes[:1], None, [1.0], norm, distr[:1], out=out, tables=ops.nsf_tables_prepare(distr[:1], norm)))
+                    emit(f"fuse_nsf_bigtab_kernel<{norm}> S=1 P={P} (tune: one system per call)", ms1, 2 * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
+                    ref = ops.fuse_nsf(planes, None, w, norm, distr, tables=False)
+                    assert torch.equal(ref.view(torch.int32), ops.fuse_nsf(planes, None, w, norm, distr).view(torch.int32)), "swap kernel differs from the global-memory search"
+                    ms0 = timeit(lambda: ops.fuse_nsf(planes, None, w, norm, distr, out=out, tables=False), n=3, warm=1)
+                    emit(f"fuse_nsf_row_kernel<{norm}> S={S} P={P} (round-3 path: global-memory search)", ms0, (S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
+
+
 def bench_gemm(Q=1024, N=27942, d=768):
     g = torch.Generator(device="cuda").manual_seed(1)
     Qn = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
@@ -138,7 +181,7 @@ def bench_mmarco(Q=1024, N=8841823 // 8, d=768, k=1000):
     emit("mmarco shard: GEMM+topk chunks", ms, 2.0 * Q * N * d, F32, "TFLOP/s", Q=Q, N=N, k=k)
 
 
-ALL = dict(nsf=bench_nsf, gemm=bench_gemm, splade=bench_splade, maxsim=bench_maxsim, topk=bench_topk, mmarco=bench_mmarco)
+ALL = dict(nsf=bench_nsf, tables=bench_tables, gemm=bench_gemm, splade=bench_splade, maxsim=bench_maxsim, topk=bench_topk, mmarco=bench_mmarco)
 if __name__ == "__main__":
     for n in (sys.argv[1:] or list(ALL)):
         ALL[n]()
