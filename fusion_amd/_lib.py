@@ -58,6 +58,7 @@ _PROTOS = {
     "fz_fuse_nsf_stats_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "fz_fuse_nsf_pstats_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "fz_nsf_tables_workspace_bytes": (_sz, [_i, _vp, _i]),
+    "fz_nsf_tables_header_offset": (_sz, [_i, _vp, _i, _i]),
     "fz_nsf_tables_prepare": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "fz_fuse_nsf_tables_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "fz_nsf_tables_path": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -38,10 +38,12 @@
 
 namespace fz {
 
-constexpr int BT_T = 1024;                  // threads per workgroup
+constexpr int BT_T = 1024;                  // threads per workgroup: 16 waves, 128 VGPRs each
 constexpr int BT_E4 = 7;                    // float4 per thread: 28,672 columns per item
 constexpr int BT_COLS = BT_T * BT_E4 * 4;
 constexpr int BT_PIECE = 256;               // floats per LDS-DMA wave instruction (64 lanes x 16 B)
+constexpr int BT_LEAD = 4;                  // -inf entries in front of the table (index -1, -2 of the search; keeps the table 16-B aligned)
+constexpr int BT_TAIL = 8;                  // +inf entries behind it at least (probes past the table are clamped onto them)
 constexpr size_t BT_LDS_BUDGET = 160 * 1024 - 256;   // the CU's LDS minus the kernel's static variables
 constexpr size_t BT_HDR_BYTES = 256;
 
@@ -61,7 +63,7 @@ static BtPlan bt_plan(int S, const int32_t* P_h, bool nce) {
     int cap = 0;
     for (int s = 0; s < S; ++s) {
         if (P_h[s] <= 0 || P_h[s] > 65535) return p;          // uint16 bucket-table entries
-        p.Ppad[s] = (P_h[s] + 1 + BT_PIECE - 1) / BT_PIECE * BT_PIECE;   // at least one +inf entry behind the table
+        p.Ppad[s] = (BT_LEAD + P_h[s] + BT_TAIL + BT_PIECE - 1) / BT_PIECE * BT_PIECE;
         cap = p.Ppad[s] > cap ? p.Ppad[s] : cap;
     }
     p.tab_cap = cap;
@@ -85,9 +87,8 @@ static BtPlan bt_plan(int S, const int32_t* P_h, bool nce) {
 // for any lo / inv_w >= 0 (subtraction, multiplication by a non-negative constant, clamp and truncation all are; a NaN
 // intermediate -- inf * 0 -- lands in bucket 0 together with everything else when inv_w == 0).
 __device__ __forceinline__ int bt_bucket(float x, float lo_v, float inv_w, float top) {
-    float t = (x - lo_v) * inv_w;
-    t = fminf(fmaxf(t, 0.f), top);   // fmaxf(NaN, 0) = 0
-    return (int)t;
+    const float t = (x - lo_v) * inv_w;
+    return (int)__builtin_amdgcn_fmed3f(t, 0.f, top);   // clamp in one instruction; a NaN gives bucket 0 (med3 of a NaN = min3 of the rest; cvt(NaN) = 0 anyway)
 }
 
 struct BtPrepArgs {
@@ -97,7 +98,8 @@ struct BtPrepArgs {
     int lutb, lut_floats, nce;
 };
 
-// BT_PREP_SLICES workgroups per system: aligned +inf-padded copy of the table, header (lo, inv_w), bucket table, NCE values
+// BT_PREP_SLICES workgroups per system: aligned copy of the table between -inf / +inf sentinels, header (lo, inv_w), bucket
+// table, NCE values
 constexpr int BT_PREP_SLICES = 32;
 __global__ __launch_bounds__(256) void bt_prepare_kernel(BtPrepArgs a, unsigned char* __restrict__ ws) {
     const int s = blockIdx.x;
@@ -115,8 +117,8 @@ __global__ __launch_bounds__(256) void bt_prepare_kernel(BtPrepArgs a, unsigned 
         if (d > 0.f && d < INFINITY) inv_w = (float)a.lutb / d;
         if (!(inv_w < INFINITY)) inv_w = 0.f;   // a denormal range: everything in bucket 0, the search runs over the whole table
     }
-    if (tid == 0) { hdr[0] = lo_v; hdr[1] = inv_w; hdr[2] = 0.f; hdr[3] = 0.f; }
-    for (int k = tid; k < Ppad; k += nthr) wtab[k] = k < P ? tab[k] : INFINITY;
+    if (tid == 0) { hdr[0] = lo_v; hdr[1] = inv_w; }
+    for (int k = tid; k < Ppad; k += nthr) wtab[k] = k < BT_LEAD ? -INFINITY : (k - BT_LEAD < P ? tab[k - BT_LEAD] : INFINITY);
     const float top = (float)(a.lutb - 1);
     const int lut_n = a.lut_floats * 2;
     for (int b = tid; b < lut_n; b += nthr) {
@@ -142,19 +144,43 @@ __global__ __launch_bounds__(256) void bt_prepare_kernel(BtPrepArgs a, unsigned 
             val[k] = v;
         }
 }
+// second launch (the bucket table is complete): the number of halving probes that cover the fullest bucket
+__global__ __launch_bounds__(1024) void bt_prepare_steps_kernel(BtPrepArgs a, unsigned char* __restrict__ ws) {
+    const int s = blockIdx.x;
+    int* hdr = reinterpret_cast<int*>(ws + a.sys_off[s]);
+    const uint16_t* lut = reinterpret_cast<const uint16_t*>(ws + a.sys_off[s] + BT_HDR_BYTES + (size_t)a.Ppad[s] * 4);
+    __shared__ int red[16];
+    int m = 0;
+    for (int b = threadIdx.x; b < a.lutb; b += blockDim.x) m = max(m, (int)lut[b + 1] - (int)lut[b]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = max(m, red[i]);
+        // the search counts whole PAIRS of entries <= x from the pair of the bucket's first entry on: at most (m + 1) / 2 of them
+        const int pairs = (m + 1) / 2;
+        int steps = 0;
+        while ((1 << steps) - 1 < pairs) ++steps;
+        hdr[2] = steps; hdr[3] = m;
+    }
+}
 
 struct BtArgs {
-    const float* hdr[FZ_MAX_SYSTEMS];     // {lo, inv_w}
-    const float* tab[FZ_MAX_SYSTEMS];     // [Ppad] aligned copy, +inf padded
+    const float* hdr[FZ_MAX_SYSTEMS];     // {lo, inv_w, steps (int), fullest bucket (int)}
+    const float* tab[FZ_MAX_SYSTEMS];     // [Ppad] aligned copy: BT_LEAD x -inf, the table, +inf
     const float* lut[FZ_MAX_SYSTEMS];     // [lut_floats] floats = uint16 [lutb + 1 ...]
     const float* val[FZ_MAX_SYSTEMS];     // NCE: [Ppad]
     int Ppad[FZ_MAX_SYSTEMS];
     int lutb, tab_cap, lut_floats, val_in_lds;
+    float top;                             // (float)(lutb - 1)
 };
+
+typedef __attribute__((address_space(3))) float lds_f32;       // LDS-typed pointers: the searches must compile to ds_read, never to flat loads
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 // first index of the plateau of equal float32 distances that ends at k (|tab[k] - x| == dl, tab ascending, tab[k] <= x):
 // the distances fl(x - tab[j]) are non-increasing in j up to k, so "== dl" holds on a suffix of [0, k]
-__device__ __noinline__ int bt_plateau_start(const float* tab, float x, float dl, int k) {
+__device__ __forceinline__ int bt_plateau_start(const lds_f32* tab, float x, float dl, int k) {
     for (int i = 0; i < 4 && k > 0 && fabsf(tab[k - 1] - x) == dl; ++i) --k;
     if (k > 0 && fabsf(tab[k - 1] - x) == dl) {
         int a = -1, b = k - 1;   // tab[b] on the plateau, tab[a] not (or a = -1)
@@ -167,129 +193,250 @@ __device__ __noinline__ int bt_plateau_start(const float* tab, float x, float dl
     return k;
 }
 
-// nearest table entry (first minimum of the float32 distances) of the four scores of a float4; m = which of them are looked up
-__device__ __forceinline__ void bt_lookup4(const float* tab, const uint16_t* lut, float lo_v, float inv_w, float top, const float (&x)[4],
-                                           uint32_t m, int (&best)[4]) {
-    int lo[4], hi[4];
+// Nearest table entry (first minimum of the float32 distances) of W scores at once.  tab points at the table's entry 0 inside
+// LDS (tab[-4 .. -1] = -inf; tab[P ...] = +inf).  A score's bucket starts at entry lut[b]; everything before it is smaller,
+// everything behind the bucket larger.  The search runs over aligned PAIRS of entries -- a ds_read_b64 costs the LDS what a
+// ds_read_b32 does (2 x 32 lanes on 64 banks against 2 x 32 lanes on 32) and brings two entries: from the pair that holds the
+// bucket's first entry on, `steps` halving probes (2^steps - 1 >= the pairs the fullest bucket can fill) count the pairs whose
+// SECOND entry is <= x; probes that run past the bucket land on larger entries and fail by themselves: no bounds, no branches.
+// The last pair that passed and the first that failed are kept in registers as the probes go by -- they are the four entries
+// around x, (C D | A B) with D <= x < B -- so the decision between the neighbours needs no further read except for the side
+// no probe touched (a predicated read, about half of the lanes for the left pair, hardly ever for the right one).  Then the
+// reference's float32 distances decide; a distance equal to the one further left (duplicated quantiles, rounding plateaus) takes
+// the exact walk -- one rarely taken branch per group.
+template <int W>
+__device__ __forceinline__ void bt_lookup(const lds_f32* tab, const lds_u16* lut, float lo_v, float inv_w, float top, int steps, int last_pair,
+                                          const float (&x)[W], int (&best)[W]) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) f2v lds_f2;
+    const lds_f2* tab2 = (const lds_f2*)tab;
+    int p[W];                 // pairs before p are <= x throughout
+    float C[W], D[W], A[W], B[W];
+    uint32_t have = 0u;       // bit e: (C, D) known; bit W + e: (A, B) known
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const bool act = ((m >> e) & 1u) && fabsf(x[e]) < INFINITY;   // NaN: argmin of an all-NaN column; +-inf: every distance is inf -> index 0
-        const int b = bt_bucket(x[e], lo_v, inv_w, top);
-        const int l = (int)lut[b], h = (int)lut[b + 1];
-        lo[e] = act ? l - 1 : -1;
-        hi[e] = act ? h : 0;
-    }
-    while (max(max(hi[0] - lo[0], hi[1] - lo[1]), max(hi[2] - lo[2], hi[3] - lo[3])) > 1) {
+    for (int e = 0; e < W; ++e) p[e] = (int)lut[bt_bucket(x[e], lo_v, inv_w, top)] >> 1;
+    for (int st = steps - 1; st >= 0; --st) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool go = hi[e] - lo[e] > 1;
-            const int mid = go ? (lo[e] + hi[e]) >> 1 : 0;
-            const bool le = tab[mid] <= x[e];
-            lo[e] = (go && le) ? mid : lo[e];
-            hi[e] = (go && !le) ? mid : hi[e];
+        for (int e = 0; e < W; ++e) {
+            const int q = min(p[e] + (1 << st) - 1, last_pair);
+            const f2v ab = tab2[q];
+            const bool pass = ab.y <= x[e];
+            p[e] = pass ? q + 1 : p[e];
+            C[e] = pass ? ab.x : C[e]; D[e] = pass ? ab.y : D[e];
+            A[e] = pass ? A[e] : ab.x; B[e] = pass ? B[e] : ab.y;
+            have |= pass ? (1u << e) : (1u << (W + e));
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int l0 = max(lo[e], 0);
-        const float tl = tab[l0], th = tab[l0 + 1], tm = tab[max(l0 - 1, 0)];   // tab[P] = +inf
-        const float dl = fabsf(tl - x[e]), dh = fabsf(th - x[e]), dm = fabsf(tm - x[e]);
-        int k = lo[e] < 0 ? 0 : (dh < dl ? l0 + 1 : l0);
-        if (lo[e] > 0 && !(dh < dl) && dm == dl) k = bt_plateau_start(tab, x[e], dl, l0 - 1);
-        best[e] = k;
+    for (int e = 0; e < W; ++e) {
+        if (!((have >> e) & 1u)) { const f2v cd = tab2[p[e] - 1]; C[e] = cd.x; D[e] = cd.y; }
+        if (!((have >> (W + e)) & 1u)) { const f2v ab = tab2[min(p[e], last_pair)]; A[e] = ab.x; B[e] = ab.y; }
     }
+    uint32_t need = 0u;
+    float dls[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) {   // D <= x < B: the last entry <= x is A (index 2p) or D (2p - 1)
+        const bool a_in = A[e] <= x[e];
+        const float tl = a_in ? A[e] : D[e], th = a_in ? B[e] : A[e], tm = a_in ? D[e] : C[e];
+        const int lo = 2 * p[e] - (a_in ? 0 : 1);
+        const float dl = fabsf(tl - x[e]), dh = fabsf(th - x[e]), dm = fabsf(tm - x[e]);
+        const bool right = dh < dl;
+        best[e] = lo + (right ? 1 : 0);
+        dls[e] = dl;
+        need |= (!right && dm == dl) ? (1u << e) : 0u;
+    }
+    if (need) {   // rare.  Inlined (a call would force everything that lives across it -- the accumulators, both score sets -- into the
+                  // callee-saved half of the register file) and rolled: one copy of the walk per group, the lane's e-th score picked by selects
+#pragma unroll 1
+        for (int e = 0; e < W; ++e) {
+            if (!((need >> e) & 1u)) continue;
+            float xe = x[0], de = dls[0];
+            int be = best[0];
+#pragma unroll
+            for (int j = 1; j < W; ++j) { xe = e == j ? x[j] : xe; de = e == j ? dls[j] : de; be = e == j ? best[j] : be; }
+            const int k = bt_plateau_start(tab, xe, de, be - 1);
+#pragma unroll
+            for (int j = 0; j < W; ++j) best[j] = e == j ? k : best[j];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < W; ++e) best[e] = fabsf(x[e]) < INFINITY ? best[e] : 0;   // NaN: argmin of an all-NaN column; +-inf: every distance is inf -> index 0
 }
 
-template <bool NCE>
+// Persistent workgroups walk (query row, 28,672-column chunk) items x systems as one sequence of steps.  Per step: the
+// system's table comes into LDS if another one is there (barrier, LDS-DMA, barrier), the 56 scores per thread are searched ILV
+// float4s at a time -- each group's registers then take the NEXT step's scores, which cross HBM under this step's searches --
+// their values weighted and added into the item's accumulators; after the item's last system the fused row leaves.
+template <bool NCE, int ILV>
 __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs t, float* __restrict__ fused) {
     extern __shared__ __attribute__((aligned(16))) float bt_lds[];
-    float* tab = bt_lds;                                                    // [tab_cap]
+    float* tabr = bt_lds;                                                   // [tab_cap]: BT_LEAD sentinels, the table, +inf
     float* lutf = bt_lds + t.tab_cap;                                       // [lut_floats]
     float* valr = bt_lds + t.tab_cap + t.lut_floats;                        // [tab_cap] when val_in_lds
-    const uint16_t* lut = reinterpret_cast<const uint16_t*>(lutf);
+    const lds_f32* tab = (const lds_f32*)(tabr + BT_LEAD);
+    const lds_u16* lut = (const lds_u16*)(lutf);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float top = (float)(t.lutb - 1);
+    const float top = t.top;
+    const int toff = 4 * threadIdx.x;
     const int chunks = (a.N + BT_COLS - 1) / BT_COLS;
     const long long items = (long long)a.Q * chunks;
     typedef float f4v __attribute__((ext_vector_type(4)));
+    static_assert(BT_E4 % ILV == 0, "groups of ILV float4");
+    constexpr int W = 4 * ILV;
 
     // global -> LDS, one 1-KiB piece per wave instruction (LDS destination = wave-uniform base + lane * 16)
     auto dma = [&](const float* __restrict__ src, float* dst, int floats) {
         for (int p = wave * BT_PIECE; p < floats; p += (BT_T / 64) * BT_PIECE)
             __builtin_amdgcn_global_load_lds(src + p + lane * 4, (__attribute__((address_space(3))) void*)(dst + p), 16, 0, 0);
     };
+    // The thread's column offset, handed out through an empty asm so that the compiler recomputes the fourteen `offset + 2048 i`
+    // where they are used: hoisted out of the step loop they (and what hangs off them) stay live across the whole kernel, the
+    // register allocator spills them, and every reload is a `s_waitcnt vmcnt(0)` in front of the requests that should stay in flight.
+    auto my_off = [&]() { int o = toff; asm volatile("" : "+v"(o)); return o; };
+    // a step's scores: float4s past the row end re-read its last one (no branch, no mask: their columns are masked out of the sums)
+    auto load_one = [&](const float* __restrict__ base, int i, int lim) {
+        return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(base + min(my_off() + 4 * BT_T * i, lim)));   // streamed once
+    };
+    auto load_row = [&](f4v (&dst)[BT_E4], const float* __restrict__ base, int lim) {
+#pragma unroll
+        for (int i = 0; i < BT_E4; ++i) dst[i] = load_one(base, i, lim);
+    };
     int cur = -1;   // the system whose table is in LDS
+    f4v v[BT_E4];   // the current step's scores; a group's registers are refilled with the next step's as soon as it has been searched
+    const float* nxt = a.planes[0];   // the next step's row chunk (wave-uniform) and its last float4
+    int nlim = 0;
+    if ((long long)blockIdx.x < items) {   // the first step's scores
+        const int q = (int)(blockIdx.x / chunks), c = (int)(blockIdx.x - (long long)q * chunks);
+        load_row(v, a.planes[0] + (size_t)q * a.ld + c * BT_COLS, (min(a.N - c * BT_COLS, BT_COLS) - 1) & ~3);
+    }
     for (long long it = blockIdx.x; it < items; it += gridDim.x) {
         const int q = (int)(it / chunks), c = (int)(it - (long long)q * chunks);
         const size_t rowoff = (size_t)q * a.ld;
-        const int col0 = c * BT_COLS + 4 * threadIdx.x;
+        const int col0 = c * BT_COLS + my_off();
         float acc[BT_E4][4];
-        uint32_t present = 0u;
+        uint64_t present = 0ull, tail_ok = 0ull;   // tail_ok: the thread's columns that lie inside the row
 #pragma unroll
-        for (int i = 0; i < BT_E4; ++i)
+        for (int i = 0; i < BT_E4; ++i) {
+            const int rem = a.N - (col0 + 4 * BT_T * i);
+            tail_ok |= (uint64_t)(rem >= 4 ? 0xfu : (rem > 0 ? (1u << rem) - 1u : 0u)) << (4 * i);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+        }
         for (int s = 0; s < a.S; ++s) {
+            // Requests to HBM run one step ahead: a group's registers take the same group of the NEXT step right after it has been
+            // searched -- except the step's LAST group, whose request would be the youngest when the table swap waits for its LDS-DMA
+            // (vmcnt counts in order: waiting for the DMA means waiting for everything older).  That one is issued here, BEHIND the
+            // DMA, and the swap waits with vmcnt(ILV): the DMA and every older request have landed, the ILV youngest may still fly
+            // (on the very first step the wait may return with up to ILV DMA pieces in flight: it then uses vmcnt(0)).
             const bool swap = cur != s;
             if (swap) {
                 __syncthreads();                       // every wave is done with the table that is there
-                dma(t.tab[s], tab, t.Ppad[s]);
+                dma(t.tab[s], tabr, t.Ppad[s]);
                 dma(t.lut[s], lutf, t.lut_floats);
                 if (NCE && t.val_in_lds) dma(t.val[s], valr, t.Ppad[s]);
                 cur = s;
             }
-            // the item's scores of this system: loaded under the table's DMA
-            f4v v[BT_E4];
-            uint32_t ok = 0u;
+            if (it != (long long)blockIdx.x || s != 0) {   // (not the very first step, whose scores the prologue requested)
 #pragma unroll
-            for (int i = 0; i < BT_E4; ++i) {
-                const int j0 = col0 + 4 * BT_T * i;
-                v[i] = f4v{0.f, 0.f, 0.f, 0.f};
-                if (j0 < a.N) {
-                    v[i] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.planes[s] + rowoff + j0));   // streamed once
-                    const int rem = a.N - j0;
-                    const uint32_t mm = (rem >= 4 ? 0xfu : ((1u << rem) - 1u)) & valid_nibble(a, s, q, rowoff, j0);
-                    ok |= mm << (4 * i);
+                for (int i = BT_E4 - ILV; i < BT_E4; ++i) v[i] = load_one(nxt, i, nlim);
+            }
+            if (swap) {
+                if (it == (long long)blockIdx.x && s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (ILV == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // this wave's pieces have landed ...
+                __syncthreads();                                                                                                    // ... and everybody else's
+            }
+            // the next step: the next system of this item, or the first system of this workgroup's next item; after the very last step
+            // the requests re-read its own row (unconditional requests: no phi copies of the score registers, no second wait form)
+            if (s + 1 < a.S) { nxt = a.planes[s + 1] + rowoff + c * BT_COLS; nlim = (min(a.N - c * BT_COLS, BT_COLS) - 1) & ~3; }
+            else if (it + gridDim.x < items) {
+                const long long it2 = it + gridDim.x;
+                const int q2 = (int)(it2 / chunks), c2 = (int)(it2 - (long long)q2 * chunks);
+                nxt = a.planes[0] + (size_t)q2 * a.ld + c2 * BT_COLS;
+                nlim = (min(a.N - c2 * BT_COLS, BT_COLS) - 1) & ~3;
+            }
+            // which of the item's documents this system lists: wave-uniform bases + clamped per-thread offsets (no branches; what is
+            // read past the row end is masked by tail_ok)
+            uint64_t ok = tail_ok;
+            if (a.vbits[s]) {
+                const uint32_t* __restrict__ wb = a.vbits[s] + (size_t)q * a.ldb + ((c * BT_COLS) >> 5);
+                const int wlast = (min(a.N - c * BT_COLS, BT_COLS) - 1) >> 5, sh = toff & 31, wo = my_off() >> 5;
+                uint64_t m = 0ull;
+#pragma unroll
+                for (int i = 0; i < BT_E4; ++i) m |= (uint64_t)((wb[min(wo + (4 * BT_T / 32) * i, wlast)] >> sh) & 0xfu) << (4 * i);
+                ok &= m;
+            } else if (a.ranks[s]) {
+                const int32_t* __restrict__ rk = a.ranks[s] + rowoff + c * BT_COLS;
+                const int lim = (min(a.N - c * BT_COLS, BT_COLS) - 1) & ~3;
+                uint64_t m = 0ull;
+#pragma unroll
+                for (int i = 0; i < BT_E4; ++i) {
+                    const int4 r = *reinterpret_cast<const int4*>(rk + min(my_off() + 4 * BT_T * i, lim));
+                    uint32_t nib = (r.x >= 0 ? 1u : 0u) | (r.y >= 0 ? 2u : 0u) | (r.z >= 0 ? 4u : 0u) | (r.w >= 0 ? 8u : 0u);
+                    asm volatile("" : "+v"(nib));   // one rank quad at a time: all of them in flight at once would be the kernel's register peak
+                    m |= (uint64_t)nib << (4 * i);
                 }
+                ok &= m;
             }
             const float lo_v = t.hdr[s][0], inv_w = t.hdr[s][1];
-            if (swap) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces have landed ...
-                __syncthreads();                                   // ... and everybody else's
-            }
+            const int steps = reinterpret_cast<const int*>(t.hdr[s])[2];
+            const int last_pair = (t.Ppad[s] - BT_LEAD) / 2 - 1;
             const float w = a.w[s];
-            const float Pf = (float)a.P[s];
-            int idx[BT_E4][4];
+            const double invP = 1.0 / (double)a.P[s];
+            uint32_t idx[NCE ? BT_E4 : 1][2];
 #pragma unroll
-            for (int i = 0; i < BT_E4; ++i) {
-                const float x[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-                int best[4];
-                bt_lookup4(tab, lut, lo_v, inv_w, top, x, (ok >> (4 * i)) & 0xfu, best);
+            for (int g = 0; g < BT_E4; g += ILV) {
+                float x[W];
+                int best[W];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int j = 0; j < ILV; ++j) { x[4 * j] = v[g + j].x; x[4 * j + 1] = v[g + j].y; x[4 * j + 2] = v[g + j].z; x[4 * j + 3] = v[g + j].w; }
+                bt_lookup<W>(tab, lut, lo_v, inv_w, top, steps, last_pair, x, best);
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    const int i = g + (k >> 2), e = k & 3;
                     if (!NCE) {
-                        const float tr = (float)best[e] / Pf;                   // hybrid.py:275
+                        // (float)k / (float)P (hybrid.py:275), computed as fl32(fl64(k * fl64(1 / P))): k < P < 2^16, so the quotient is at
+                        // least 2^-41 (relative) away from every float32 rounding boundary and the 2^-52 error of the double product
+                        // cannot move it across one -- the correctly rounded quotient, in 3 instructions instead of the division's 12
+                        const float tr = (float)((double)best[k] * invP);
                         const float prod = tr * w;                              // fl32(t * fl32(w))      hybrid.py:291 under NumPy 2
-                        acc[i][e] = ((ok >> (4 * i + e)) & 1u) ? acc[i][e] + prod : acc[i][e];
-                    } else idx[i][e] = best[e];
+                        // a document the system does not list adds nothing: + (+0.0f) leaves every accumulator as it is (one is never
+                        // -0.0: the sums start from +0.0); as a bit mask, so that the compiler does not branch around the arithmetic
+                        const uint32_t keep = 0u - (uint32_t)((ok >> (4 * i + e)) & 1ull);
+                        acc[i][e] = acc[i][e] + __uint_as_float(__float_as_uint(prod) & keep);
+                    } else if (e & 1) idx[NCE ? i : 0][e >> 1] |= (uint32_t)best[k] << 16;   // two 16-bit indices per register (P <= 65535)
+                    else idx[NCE ? i : 0][e >> 1] = (uint32_t)best[k];
                 }
+#pragma unroll
+                for (int j = 0; j < ILV; ++j) {
+                    // pin the group's sums (or indices) HERE: left alone the compiler sinks every group's value arithmetic to the end of the
+                    // step, the 4 indices per group stay live until then, and what the register allocator then spills is the score registers
+                    if (!NCE) asm volatile("" : "+v"(acc[g + j][0]), "+v"(acc[g + j][1]), "+v"(acc[g + j][2]), "+v"(acc[g + j][3]));
+                    else asm volatile("" : "+v"(idx[NCE ? g + j : 0][0]), "+v"(idx[NCE ? g + j : 0][1]));
+                }
+                if (g + ILV < BT_E4) {
+#pragma unroll
+                    for (int j = 0; j < ILV; ++j) v[g + j] = load_one(nxt, g + j, nlim);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one group's searches at a time: scheduled across groups, their temporaries push the score registers out
             }
             if (NCE) {
-                const float* vt = valr;
+                const lds_f32* vt = (const lds_f32*)valr;
                 if (!t.val_in_lds) {   // the values take the table's place
                     __syncthreads();
-                    dma(t.val[s], tab, t.Ppad[s]);
+                    dma(t.val[s], tabr, t.Ppad[s]);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     cur = -1;
-                    vt = tab;
+                    vt = (const lds_f32*)tabr;
                 }
 #pragma unroll
                 for (int i = 0; i < BT_E4; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float prod = vt[idx[i][e]] * w;
-                        acc[i][e] = ((ok >> (4 * i + e)) & 1u) ? acc[i][e] + prod : acc[i][e];
+                        const float prod = vt[(idx[NCE ? i : 0][e >> 1] >> (16 * (e & 1))) & 0xffffu] * w;
+                        const uint32_t keep = 0u - (uint32_t)((ok >> (4 * i + e)) & 1ull);
+                        acc[i][e] = acc[i][e] + __uint_as_float(__float_as_uint(prod) & keep);
                     }
             }
             present |= ok;
@@ -300,7 +447,7 @@ __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs
             if (j0 < a.N) {   // columns [N, ld) of the last float4 are padding of the plane: written, never read
                 float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = ((present >> (4 * i + e)) & 1u) ? acc[i][e] : -INFINITY;
+                for (int e = 0; e < 4; ++e) o[e] = ((present >> (4 * i + e)) & 1ull) ? acc[i][e] : -INFINITY;
                 *reinterpret_cast<float4*>(fused + rowoff + j0) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
@@ -323,6 +470,12 @@ extern "C" size_t fz_nsf_tables_workspace_bytes(int S, const int32_t* P_h, int n
     return p.ok ? p.sys_off[S] : 0;
 }
 
+extern "C" size_t fz_nsf_tables_header_offset(int S, const int32_t* P_h, int norm, int s) {
+    if (S <= 0 || S > FZ_MAX_SYSTEMS || !P_h || s < 0 || s >= S || (norm != FZ_NORM_PERCENTILE && norm != FZ_NORM_NCE)) return (size_t)-1;
+    const BtPlan p = bt_plan(S, P_h, norm == FZ_NORM_NCE);
+    return p.ok ? p.sys_off[s] : (size_t)-1;
+}
+
 extern "C" int fz_nsf_tables_prepare(const float* const* distr_h, const int32_t* P_h, int S, int norm, void* workspace, size_t workspace_bytes,
                                      void* stream) {
     if (S <= 0 || S > FZ_MAX_SYSTEMS || !distr_h || !P_h || (norm != FZ_NORM_PERCENTILE && norm != FZ_NORM_NCE)) return FZ_ERR_ARG;
@@ -336,6 +489,7 @@ extern "C" int fz_nsf_tables_prepare(const float* const* distr_h, const int32_t*
     for (int s = 0; s < S; ++s) { a.distr[s] = distr_h[s]; a.P[s] = P_h[s]; a.Ppad[s] = p.Ppad[s]; a.sys_off[s] = p.sys_off[s]; }
     a.lutb = p.lutb; a.lut_floats = p.lut_floats; a.nce = norm == FZ_NORM_NCE;
     bt_prepare_kernel<<<dim3((unsigned)S, BT_PREP_SLICES), 256, 0, as_stream(stream)>>>(a, static_cast<unsigned char*>(workspace));
+    bt_prepare_steps_kernel<<<S, 1024, 0, as_stream(stream)>>>(a, static_cast<unsigned char*>(workspace));
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }
@@ -392,16 +546,17 @@ extern "C" int fz_fuse_nsf_tables_f32(const float* const* planes_h, const int32_
         t.val[s] = nce ? t.lut[s] + p.lut_floats : nullptr;
         t.Ppad[s] = p.Ppad[s];
     }
+    t.top = (float)(p.lutb - 1);
     t.lutb = p.lutb; t.tab_cap = p.tab_cap; t.lut_floats = p.lut_floats; t.val_in_lds = p.val_in_lds ? 1 : 0;
     const long long items = (long long)Q * ((N + BT_COLS - 1) / BT_COLS);
     const unsigned grid = (unsigned)(items < 256 ? items : 256);
     static unsigned long long set_pr = 0ull, set_nce = 0ull;
     if (nce) {
-        if (int rc = raise_lds_limit((const void*)fuse_nsf_bigtab_kernel<true>, p.lds_bytes, set_nce)) return rc;
-        fuse_nsf_bigtab_kernel<true><<<grid, BT_T, p.lds_bytes, st>>>(a, t, fused);
+        if (int rc = raise_lds_limit((const void*)fuse_nsf_bigtab_kernel<true, 1>, p.lds_bytes, set_nce)) return rc;
+        fuse_nsf_bigtab_kernel<true, 1><<<grid, BT_T, p.lds_bytes, st>>>(a, t, fused);
     } else {
-        if (int rc = raise_lds_limit((const void*)fuse_nsf_bigtab_kernel<false>, p.lds_bytes, set_pr)) return rc;
-        fuse_nsf_bigtab_kernel<false><<<grid, BT_T, p.lds_bytes, st>>>(a, t, fused);
+        if (int rc = raise_lds_limit((const void*)fuse_nsf_bigtab_kernel<false, 1>, p.lds_bytes, set_pr)) return rc;
+        fuse_nsf_bigtab_kernel<false, 1><<<grid, BT_T, p.lds_bytes, st>>>(a, t, fused);
     }
     FZ_LAUNCH_CHECK();
     return FZ_OK;

@@ -373,6 +373,17 @@ class PreparedTables:
     def __init__(self, distr: list[torch.Tensor], norm: str, workspace: torch.Tensor):
         self.distr, self.norm, self.workspace = distr, norm, workspace
 
+    def search_info(self) -> list[dict]:
+        """Per system: probes per search and entries in the fullest bucket (diagnostics; synchronises)."""
+        S = len(self.distr)
+        P = (C.c_int32 * S)(*[int(d.numel()) for d in self.distr])
+        out = []
+        for s in range(S):
+            off = int(_lib.lib().fz_nsf_tables_header_offset(S, P, NORMS[self.norm], s))
+            h = self.workspace[off:off + 16].cpu().numpy()
+            out.append(dict(probes=int(h[8:12].view(np.int32)[0]), fullest_bucket=int(h[12:16].view(np.int32)[0])))
+        return out
+
     def matches(self, distr, norm) -> bool:
         return norm == self.norm and len(distr) == len(self.distr) and all(
             a.data_ptr() == b.data_ptr() and a.numel() == b.numel() for a, b in zip(distr, self.distr))

@@ -191,6 +191,11 @@ typedef enum {
     FZ_TABLES_PATH_ROW = 2        /* not taken by fz_fuse_nsf_tables_f32: fz_fuse_nsf_f32's global-memory search */
 } fz_tables_path;
 size_t fz_nsf_tables_workspace_bytes(int S, const int32_t* P_h, int norm);
+/* byte offset, inside a prepared workspace, of system s's 16-byte header {float first entry; float buckets per unit; int32 probes per
+ * search; int32 entries in the fullest bucket} -- diagnostics: the search costs `probes` LDS reads per score (log2 of the fullest bucket of
+ * an equi-width bucket table; 3..6 for quantile tables of real score distributions, more for tables with long runs of equal entries).
+ * (size_t)-1 on a bad argument. */
+size_t fz_nsf_tables_header_offset(int S, const int32_t* P_h, int norm, int s);
 int fz_nsf_tables_prepare(const float* const* distr_h, const int32_t* P_h, int S, int norm, void* workspace, size_t workspace_bytes,
                           void* stream);
 int fz_fuse_nsf_tables_f32(const float* const* planes_h, const int32_t* const* ranks_h, const double* w_h, int S, int Q, int N,

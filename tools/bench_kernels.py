@@ -95,7 +95,8 @@ def bench_tables(N=27942, S=4):
                 prep = ops.nsf_tables_prepare(distr, norm)
                 ms = timeit(lambda: ops.fuse_nsf(planes, None, w, norm, distr, out=out, tables=prep))
                 assert ops.last_tables_path == "lds-swap"
-                emit(f"fuse_nsf_bigtab_kernel<{norm}> S={S} P={P} (tables prepared once)", ms, (S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
+                emit(f"fuse_nsf_bigtab_kernel<{norm}> S={S} P={P} (tables prepared once)", ms, (S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N,
+                     search=prep.search_info())
                 ms = timeit(lambda: ops.fuse_nsf(planes, None, w, norm, distr, out=out))
                 emit(f"fz_nsf_tables_prepare + fuse_nsf_bigtab_kernel<{norm}> S={S} P={P}", ms, (S + 1) * Q * N * 4, HBM, "GB/s", Q=Q, N=N)
                 if Q == 1024 and P == 27943:
