@@ -33,6 +33,8 @@
 // Same nearest entry, same float expressions as the per-score device function (fuse.hip percentile_rank): bit-identical
 // results -- tests/test_gpu_tables.py holds the three kernels against each other and against the reference's own outputs
 // (tests/golden/pr28k_*.npz: outputs of the reference itself).
+#include <type_traits>
+
 #include "common.h"
 #include "nsf.h"
 
@@ -43,7 +45,9 @@ constexpr int BT_E4 = 7;                    // float4 per thread: 28,672 columns
 constexpr int BT_COLS = BT_T * BT_E4 * 4;
 constexpr int BT_PIECE = 256;               // floats per LDS-DMA wave instruction (64 lanes x 16 B)
 constexpr int BT_LEAD = 4;                  // -inf entries in front of the table (index -1, -2 of the search; keeps the table 16-B aligned)
-constexpr int BT_TAIL = 8;                  // +inf entries behind it at least (probes past the table are clamped onto them)
+constexpr int BT_TAIL = 40;                 // +inf entries behind it at least: the unrolled search (<= 4 probes) reaches 15 pairs past its start, unclamped
+constexpr int BT_MAX_UNROLLED = 4;
+typedef std::conditional<(BT_E4 <= 8), uint32_t, uint64_t>::type mask_t;   // one bit per column of a thread
 constexpr size_t BT_LDS_BUDGET = 160 * 1024 - 256;   // the CU's LDS minus the kernel's static variables
 constexpr size_t BT_HDR_BYTES = 256;
 
@@ -197,70 +201,74 @@ __device__ __forceinline__ int bt_plateau_start(const lds_f32* tab, float x, flo
 // LDS (tab[-4 .. -1] = -inf; tab[P ...] = +inf).  A score's bucket starts at entry lut[b]; everything before it is smaller,
 // everything behind the bucket larger.  The search runs over aligned PAIRS of entries -- a ds_read_b64 costs the LDS what a
 // ds_read_b32 does (2 x 32 lanes on 64 banks against 2 x 32 lanes on 32) and brings two entries: from the pair that holds the
-// bucket's first entry on, `steps` halving probes (2^steps - 1 >= the pairs the fullest bucket can fill) count the pairs whose
-// SECOND entry is <= x; probes that run past the bucket land on larger entries and fail by themselves: no bounds, no branches.
-// The last pair that passed and the first that failed are kept in registers as the probes go by -- they are the four entries
-// around x, (C D | A B) with D <= x < B -- so the decision between the neighbours needs no further read except for the side
-// no probe touched (a predicated read, about half of the lanes for the left pair, hardly ever for the right one).  Then the
-// reference's float32 distances decide; a distance equal to the one further left (duplicated quantiles, rounding plateaus) takes
-// the exact walk -- one rarely taken branch per group.
-template <int W>
+// bucket's first entry on, STEPS halving probes (2^STEPS - 1 >= the pairs the fullest bucket can fill) count the pairs whose
+// SECOND entry is <= x; probes that run past the bucket land on larger entries and fail by themselves: no bounds, no branches,
+// a compare, a select and an add per probe (the probe's offset is an immediate).  One ds_read2_b64 then brings the four entries
+// around x, (C D | A B) with D <= x < B, and the reference's float32 distances decide between the neighbours; a distance equal
+// to the one further left (duplicated quantiles, rounding plateaus) takes the exact walk -- one rarely taken branch per group.
+// STEPS = 0: tables with fuller buckets (long runs of equal quantiles): `steps` probes in a loop, clamped to the table.
+template <int W, int STEPS>
 __device__ __forceinline__ void bt_lookup(const lds_f32* tab, const lds_u16* lut, float lo_v, float inv_w, float top, int steps, int last_pair,
                                           const float (&x)[W], int (&best)[W]) {
     typedef float f2v __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) f2v lds_f2;
     const lds_f2* tab2 = (const lds_f2*)tab;
     int p[W];                 // pairs before p are <= x throughout
-    float C[W], D[W], A[W], B[W];
-    uint32_t have = 0u;       // bit e: (C, D) known; bit W + e: (A, B) known
 #pragma unroll
     for (int e = 0; e < W; ++e) p[e] = (int)lut[bt_bucket(x[e], lo_v, inv_w, top)] >> 1;
-    for (int st = steps - 1; st >= 0; --st) {
+    if (STEPS > 0) {
 #pragma unroll
-        for (int e = 0; e < W; ++e) {
-            const int q = min(p[e] + (1 << st) - 1, last_pair);
-            const f2v ab = tab2[q];
-            const bool pass = ab.y <= x[e];
-            p[e] = pass ? q + 1 : p[e];
-            C[e] = pass ? ab.x : C[e]; D[e] = pass ? ab.y : D[e];
-            A[e] = pass ? A[e] : ab.x; B[e] = pass ? B[e] : ab.y;
-            have |= pass ? (1u << e) : (1u << (W + e));
-        }
-    }
+        for (int st = STEPS - 1; st >= 0; --st)
 #pragma unroll
-    for (int e = 0; e < W; ++e) {
-        if (!((have >> e) & 1u)) { const f2v cd = tab2[p[e] - 1]; C[e] = cd.x; D[e] = cd.y; }
-        if (!((have >> (W + e)) & 1u)) { const f2v ab = tab2[min(p[e], last_pair)]; A[e] = ab.x; B[e] = ab.y; }
+            for (int e = 0; e < W; ++e) p[e] += (tab2[p[e] + (1 << st) - 1].y <= x[e]) ? (1 << st) : 0;
+    } else {
+        for (int st = steps - 1; st >= 0; --st)
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const int q = min(p[e] + (1 << st) - 1, last_pair);
+                p[e] = (tab2[q].y <= x[e]) ? q + 1 : p[e];
+            }
+#pragma unroll
+        for (int e = 0; e < W; ++e) p[e] = min(p[e], last_pair);
     }
     uint32_t need = 0u;
-    float dls[W];
 #pragma unroll
     for (int e = 0; e < W; ++e) {   // D <= x < B: the last entry <= x is A (index 2p) or D (2p - 1)
-        const bool a_in = A[e] <= x[e];
-        const float tl = a_in ? A[e] : D[e], th = a_in ? B[e] : A[e], tm = a_in ? D[e] : C[e];
-        const int lo = 2 * p[e] - (a_in ? 0 : 1);
+        const f2v cd = tab2[p[e] - 1], ab = tab2[p[e]];
+        const bool a_in = ab.x <= x[e];
+        const float tl = a_in ? ab.x : cd.y, th = a_in ? ab.y : ab.x, tm = a_in ? cd.y : cd.x;
         const float dl = fabsf(tl - x[e]), dh = fabsf(th - x[e]), dm = fabsf(tm - x[e]);
         const bool right = dh < dl;
-        best[e] = lo + (right ? 1 : 0);
-        dls[e] = dl;
+        best[e] = 2 * p[e] - (a_in ? 0 : 1) + (right ? 1 : 0);
         need |= (!right && dm == dl) ? (1u << e) : 0u;
     }
-    if (need) {   // rare.  Inlined (a call would force everything that lives across it -- the accumulators, both score sets -- into the
+    if (need) {   // rare.  Inlined (a call would force everything that lives across it -- the accumulators, the score registers -- into the
                   // callee-saved half of the register file) and rolled: one copy of the walk per group, the lane's e-th score picked by selects
 #pragma unroll 1
         for (int e = 0; e < W; ++e) {
             if (!((need >> e) & 1u)) continue;
-            float xe = x[0], de = dls[0];
+            float xe = x[0];
             int be = best[0];
 #pragma unroll
-            for (int j = 1; j < W; ++j) { xe = e == j ? x[j] : xe; de = e == j ? dls[j] : de; be = e == j ? best[j] : be; }
-            const int k = bt_plateau_start(tab, xe, de, be - 1);
+            for (int j = 1; j < W; ++j) { xe = e == j ? x[j] : xe; be = e == j ? best[j] : be; }
+            const int k = bt_plateau_start(tab, xe, fabsf(tab[be] - xe), be - 1);
 #pragma unroll
             for (int j = 0; j < W; ++j) best[j] = e == j ? k : best[j];
         }
     }
 #pragma unroll
     for (int e = 0; e < W; ++e) best[e] = fabsf(x[e]) < INFINITY ? best[e] : 0;   // NaN: argmin of an all-NaN column; +-inf: every distance is inf -> index 0
+}
+
+// (float)k / (float)P (hybrid.py:275) without the division: q = k * fl(1/P) is within an ulp, r = fma(-q, P, k) is the exact
+// remainder (it fits 24 bits), and fma(r, fl(1/P), q) rounds k/P * (1 + 2^-46) once -- for k < P < 2^16 the quotient is at least
+// 2^-41 (relative) away from every float32 rounding boundary (a boundary is an odd multiple of half an ulp: its numerator has
+// 25 bits, k/P's at most 16), so that is the correctly rounded quotient.  4 full-rate instructions for the division's 12.
+__device__ __forceinline__ float bt_quot(int k, float Pf, float rP) {
+    const float kf = (float)k;
+    const float q = kf * rP;
+    const float r = __builtin_fmaf(-q, Pf, kf);
+    return __builtin_fmaf(r, rP, q);
 }
 
 // Persistent workgroups walk (query row, 28,672-column chunk) items x systems as one sequence of steps.  Per step: the
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs
     const float top = t.top;
     const int toff = 4 * threadIdx.x;
     const int chunks = (a.N + BT_COLS - 1) / BT_COLS;
-    const long long items = (long long)a.Q * chunks;
+    const int items = a.Q * chunks;   // (< 2^31: checked by the launcher)
     typedef float f4v __attribute__((ext_vector_type(4)));
     static_assert(BT_E4 % ILV == 0, "groups of ILV float4");
     constexpr int W = 4 * ILV;
@@ -305,20 +313,25 @@ __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs
     f4v v[BT_E4];   // the current step's scores; a group's registers are refilled with the next step's as soon as it has been searched
     const float* nxt = a.planes[0];   // the next step's row chunk (wave-uniform) and its last float4
     int nlim = 0;
-    if ((long long)blockIdx.x < items) {   // the first step's scores
-        const int q = (int)(blockIdx.x / chunks), c = (int)(blockIdx.x - (long long)q * chunks);
+    // items it = blockIdx.x, + gridDim.x, ...: (row q, chunk c) advanced by hand -- a division per item would be done on the vector ALU,
+    // in registers that live across the whole kernel
+    int q = (int)blockIdx.x / chunks, c = (int)blockIdx.x - q * chunks;
+    const int dq = (int)gridDim.x / chunks, dc = (int)gridDim.x - dq * chunks;
+    bool first = true;
+    if ((int)blockIdx.x < items) {   // the first step's scores
         load_row(v, a.planes[0] + (size_t)q * a.ld + c * BT_COLS, (min(a.N - c * BT_COLS, BT_COLS) - 1) & ~3);
     }
-    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
-        const int q = (int)(it / chunks), c = (int)(it - (long long)q * chunks);
+    for (int it = blockIdx.x; it < items; it += gridDim.x) {
+        int q2 = q + dq, c2 = c + dc;   // the workgroup's next item
+        if (c2 >= chunks) { c2 -= chunks; ++q2; }
         const size_t rowoff = (size_t)q * a.ld;
         const int col0 = c * BT_COLS + my_off();
         float acc[BT_E4][4];
-        uint64_t present = 0ull, tail_ok = 0ull;   // tail_ok: the thread's columns that lie inside the row
+        mask_t present = 0, tail_ok = 0;   // tail_ok: the thread's columns that lie inside the row
 #pragma unroll
         for (int i = 0; i < BT_E4; ++i) {
             const int rem = a.N - (col0 + 4 * BT_T * i);
-            tail_ok |= (uint64_t)(rem >= 4 ? 0xfu : (rem > 0 ? (1u << rem) - 1u : 0u)) << (4 * i);
+            tail_ok |= (mask_t)(rem >= 4 ? 0xfu : (rem > 0 ? (1u << rem) - 1u : 0u)) << (4 * i);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
         }
@@ -336,45 +349,44 @@ __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs
                 if (NCE && t.val_in_lds) dma(t.val[s], valr, t.Ppad[s]);
                 cur = s;
             }
-            if (it != (long long)blockIdx.x || s != 0) {   // (not the very first step, whose scores the prologue requested)
+            if (!first) {   // (not the very first step, whose scores the prologue requested)
 #pragma unroll
                 for (int i = BT_E4 - ILV; i < BT_E4; ++i) v[i] = load_one(nxt, i, nlim);
             }
             if (swap) {
-                if (it == (long long)blockIdx.x && s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (ILV == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // this wave's pieces have landed ...
                 __syncthreads();                                                                                                    // ... and everybody else's
             }
+            first = false;
             // the next step: the next system of this item, or the first system of this workgroup's next item; after the very last step
             // the requests re-read its own row (unconditional requests: no phi copies of the score registers, no second wait form)
             if (s + 1 < a.S) { nxt = a.planes[s + 1] + rowoff + c * BT_COLS; nlim = (min(a.N - c * BT_COLS, BT_COLS) - 1) & ~3; }
             else if (it + gridDim.x < items) {
-                const long long it2 = it + gridDim.x;
-                const int q2 = (int)(it2 / chunks), c2 = (int)(it2 - (long long)q2 * chunks);
                 nxt = a.planes[0] + (size_t)q2 * a.ld + c2 * BT_COLS;
                 nlim = (min(a.N - c2 * BT_COLS, BT_COLS) - 1) & ~3;
             }
             // which of the item's documents this system lists: wave-uniform bases + clamped per-thread offsets (no branches; what is
             // read past the row end is masked by tail_ok)
-            uint64_t ok = tail_ok;
+            mask_t ok = tail_ok;
             if (a.vbits[s]) {
                 const uint32_t* __restrict__ wb = a.vbits[s] + (size_t)q * a.ldb + ((c * BT_COLS) >> 5);
                 const int wlast = (min(a.N - c * BT_COLS, BT_COLS) - 1) >> 5, sh = toff & 31, wo = my_off() >> 5;
-                uint64_t m = 0ull;
+                mask_t m = 0;
 #pragma unroll
-                for (int i = 0; i < BT_E4; ++i) m |= (uint64_t)((wb[min(wo + (4 * BT_T / 32) * i, wlast)] >> sh) & 0xfu) << (4 * i);
+                for (int i = 0; i < BT_E4; ++i) m |= (mask_t)((wb[min(wo + (4 * BT_T / 32) * i, wlast)] >> sh) & 0xfu) << (4 * i);
                 ok &= m;
             } else if (a.ranks[s]) {
                 const int32_t* __restrict__ rk = a.ranks[s] + rowoff + c * BT_COLS;
                 const int lim = (min(a.N - c * BT_COLS, BT_COLS) - 1) & ~3;
-                uint64_t m = 0ull;
+                mask_t m = 0;
 #pragma unroll
                 for (int i = 0; i < BT_E4; ++i) {
                     const int4 r = *reinterpret_cast<const int4*>(rk + min(my_off() + 4 * BT_T * i, lim));
                     uint32_t nib = (r.x >= 0 ? 1u : 0u) | (r.y >= 0 ? 2u : 0u) | (r.z >= 0 ? 4u : 0u) | (r.w >= 0 ? 8u : 0u);
                     asm volatile("" : "+v"(nib));   // one rank quad at a time: all of them in flight at once would be the kernel's register peak
-                    m |= (uint64_t)nib << (4 * i);
+                    m |= (mask_t)nib << (4 * i);
                 }
                 ok &= m;
             }
@@ -382,43 +394,50 @@ __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs
             const int steps = reinterpret_cast<const int*>(t.hdr[s])[2];
             const int last_pair = (t.Ppad[s] - BT_LEAD) / 2 - 1;
             const float w = a.w[s];
-            const double invP = 1.0 / (double)a.P[s];
+            const float Pf = (float)a.P[s], rP = 1.0f / Pf;
             uint32_t idx[NCE ? BT_E4 : 1][2];
-#pragma unroll
-            for (int g = 0; g < BT_E4; g += ILV) {
-                float x[W];
-                int best[W];
-#pragma unroll
-                for (int j = 0; j < ILV; ++j) { x[4 * j] = v[g + j].x; x[4 * j + 1] = v[g + j].y; x[4 * j + 2] = v[g + j].z; x[4 * j + 3] = v[g + j].w; }
-                bt_lookup<W>(tab, lut, lo_v, inv_w, top, steps, last_pair, x, best);
-#pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    const int i = g + (k >> 2), e = k & 3;
-                    if (!NCE) {
-                        // (float)k / (float)P (hybrid.py:275), computed as fl32(fl64(k * fl64(1 / P))): k < P < 2^16, so the quotient is at
-                        // least 2^-41 (relative) away from every float32 rounding boundary and the 2^-52 error of the double product
-                        // cannot move it across one -- the correctly rounded quotient, in 3 instructions instead of the division's 12
-                        const float tr = (float)((double)best[k] * invP);
-                        const float prod = tr * w;                              // fl32(t * fl32(w))      hybrid.py:291 under NumPy 2
-                        // a document the system does not list adds nothing: + (+0.0f) leaves every accumulator as it is (one is never
-                        // -0.0: the sums start from +0.0); as a bit mask, so that the compiler does not branch around the arithmetic
-                        const uint32_t keep = 0u - (uint32_t)((ok >> (4 * i + e)) & 1ull);
-                        acc[i][e] = acc[i][e] + __uint_as_float(__float_as_uint(prod) & keep);
-                    } else if (e & 1) idx[NCE ? i : 0][e >> 1] |= (uint32_t)best[k] << 16;   // two 16-bit indices per register (P <= 65535)
-                    else idx[NCE ? i : 0][e >> 1] = (uint32_t)best[k];
+            auto groups = [&](auto steps_c) {
+                constexpr int STEPS = decltype(steps_c)::value;
+    #pragma unroll
+                for (int g = 0; g < BT_E4; g += ILV) {
+                    float x[W];
+                    int best[W];
+    #pragma unroll
+                    for (int j = 0; j < ILV; ++j) { x[4 * j] = v[g + j].x; x[4 * j + 1] = v[g + j].y; x[4 * j + 2] = v[g + j].z; x[4 * j + 3] = v[g + j].w; }
+                    bt_lookup<W, STEPS>(tab, lut, lo_v, inv_w, top, steps, last_pair, x, best);
+    #pragma unroll
+                    for (int k = 0; k < W; ++k) {
+                        const int i = g + (k >> 2), e = k & 3;
+                        if (!NCE) {
+                            const float tr = bt_quot(best[k], Pf, rP);               // hybrid.py:275
+                            const float prod = tr * w;                              // fl32(t * fl32(w))      hybrid.py:291 under NumPy 2
+                            // a document the system does not list adds nothing: + (+0.0f) leaves every accumulator as it is (one is never
+                            // -0.0: the sums start from +0.0); as a bit mask, so that the compiler does not branch around the arithmetic
+                            const uint32_t keep = 0u - (uint32_t)((ok >> (4 * i + e)) & 1);
+                            acc[i][e] = acc[i][e] + __uint_as_float(__float_as_uint(prod) & keep);
+                        } else if (e & 1) idx[NCE ? i : 0][e >> 1] |= (uint32_t)best[k] << 16;   // two 16-bit indices per register (P <= 65535)
+                        else idx[NCE ? i : 0][e >> 1] = (uint32_t)best[k];
+                    }
+    #pragma unroll
+                    for (int j = 0; j < ILV; ++j) {
+                        // pin the group's sums (or indices) HERE: left alone the compiler sinks every group's value arithmetic to the end of the
+                        // step, the 4 indices per group stay live until then, and what the register allocator then spills is the score registers
+                        if (!NCE) asm volatile("" : "+v"(acc[g + j][0]), "+v"(acc[g + j][1]), "+v"(acc[g + j][2]), "+v"(acc[g + j][3]));
+                        else asm volatile("" : "+v"(idx[NCE ? g + j : 0][0]), "+v"(idx[NCE ? g + j : 0][1]));
+                    }
+                    if (g + ILV < BT_E4) {
+    #pragma unroll
+                        for (int j = 0; j < ILV; ++j) v[g + j] = load_one(nxt, g + j, nlim);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one group's searches at a time: scheduled across groups, their temporaries push the score registers out
                 }
-#pragma unroll
-                for (int j = 0; j < ILV; ++j) {
-                    // pin the group's sums (or indices) HERE: left alone the compiler sinks every group's value arithmetic to the end of the
-                    // step, the 4 indices per group stay live until then, and what the register allocator then spills is the score registers
-                    if (!NCE) asm volatile("" : "+v"(acc[g + j][0]), "+v"(acc[g + j][1]), "+v"(acc[g + j][2]), "+v"(acc[g + j][3]));
-                    else asm volatile("" : "+v"(idx[NCE ? g + j : 0][0]), "+v"(idx[NCE ? g + j : 0][1]));
-                }
-                if (g + ILV < BT_E4) {
-#pragma unroll
-                    for (int j = 0; j < ILV; ++j) v[g + j] = load_one(nxt, g + j, nlim);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // one group's searches at a time: scheduled across groups, their temporaries push the score registers out
+            };
+            switch (steps <= BT_MAX_UNROLLED ? (steps < 1 ? 1 : steps) : 0) {   // (wave-uniform; fewer probes than the table needs would be wrong, more are not)
+                case 1: groups(std::integral_constant<int, 1>{}); break;
+                case 2: groups(std::integral_constant<int, 2>{}); break;
+                case 3: groups(std::integral_constant<int, 3>{}); break;
+                case 4: groups(std::integral_constant<int, 4>{}); break;
+                default: groups(std::integral_constant<int, 0>{}); break;
             }
             if (NCE) {
                 const lds_f32* vt = (const lds_f32*)valr;
@@ -435,7 +454,7 @@ __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float prod = vt[(idx[NCE ? i : 0][e >> 1] >> (16 * (e & 1))) & 0xffffu] * w;
-                        const uint32_t keep = 0u - (uint32_t)((ok >> (4 * i + e)) & 1ull);
+                        const uint32_t keep = 0u - (uint32_t)((ok >> (4 * i + e)) & 1);
                         acc[i][e] = acc[i][e] + __uint_as_float(__float_as_uint(prod) & keep);
                     }
             }
@@ -447,10 +466,11 @@ __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs
             if (j0 < a.N) {   // columns [N, ld) of the last float4 are padding of the plane: written, never read
                 float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = ((present >> (4 * i + e)) & 1ull) ? acc[i][e] : -INFINITY;
+                for (int e = 0; e < 4; ++e) o[e] = ((present >> (4 * i + e)) & 1) ? acc[i][e] : -INFINITY;
                 *reinterpret_cast<float4*>(fused + rowoff + j0) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
+        q = q2; c = c2;
     }
 }
 
@@ -549,6 +569,7 @@ extern "C" int fz_fuse_nsf_tables_f32(const float* const* planes_h, const int32_
     t.top = (float)(p.lutb - 1);
     t.lutb = p.lutb; t.tab_cap = p.tab_cap; t.lut_floats = p.lut_floats; t.val_in_lds = p.val_in_lds ? 1 : 0;
     const long long items = (long long)Q * ((N + BT_COLS - 1) / BT_COLS);
+    if (items >= (1ll << 31)) return FZ_ERR_UNSUPPORTED;
     const unsigned grid = (unsigned)(items < 256 ? items : 256);
     static unsigned long long set_pr = 0ull, set_nce = 0ull;
     if (nce) {

@@ -8,34 +8,16 @@ CSRC = os.path.join(ROOT, "fusion_amd", "csrc")
 SRC = open(os.path.join(CSRC, "tables.hip")).read()
 FLAGS = "-O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math".split()
 
+T1024 = "constexpr int BT_T = 1024;"
+E7 = "constexpr int BT_E4 = 7;"
 VARIANTS = {
-    # the value: one multiply instead of int -> double -> multiply -> float
-    "novalue": [("const float tr = (float)((double)best[e] * invP);", "const float tr = (float)best[e] * 3.5e-5f;")],
-    # no neighbour decision: the count alone
-    "nofinal": [("    float tl[4], th[4], tm[4];", "    for (int e = 0; e < 4; ++e) best[e] = pos[e];\n    return;\n    float tl[4], th[4], tm[4];")],
-    # no probes: the bucket start is the answer
-    "noprobe": [("        for (int st = STEPS - 1; st >= 0; --st)\n#pragma unroll\n            for (int e = 0; e < 4; ++e) pos[e] +=",
-                 "        for (int st = -1; st >= 0; --st)\n#pragma unroll\n            for (int e = 0; e < 4; ++e) pos[e] +=")],
-    # no LDS at all in the search: streaming, swaps and accumulation only
-    "nolookup": [("        bt_lookup4<STEPS>(tab, lut, lo_v, inv_w, top, gsteps, v[i], best);",
-                  "        for (int e = 0; e < 4; ++e) best[e] = (int)v[i][e];")],
+    # 8 waves x 256 VGPRs, two float4 (8 scores) searched in lockstep
+    "t512_ilv2": [(T1024, "constexpr int BT_T = 512;"), (E7, "constexpr int BT_E4 = 14;"), ("fuse_nsf_bigtab_kernel<false, 1>", "fuse_nsf_bigtab_kernel<false, 2>"),
+                  ("fuse_nsf_bigtab_kernel<true, 1>", "fuse_nsf_bigtab_kernel<true, 2>")],
+    "t512_ilv1": [(T1024, "constexpr int BT_T = 512;"), (E7, "constexpr int BT_E4 = 14;")],
     # no HBM reads of scores after the first step (lookups + swaps + stores only)
-    "nostream": [("            const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(nxt + min(toff + 4 * BT_T * i, nlim)));   // streamed once\n            v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;",
-                  "            v[i][0] += 1e-3f;")],
-    # the HBM reads are issued but their data is never used (no register dependence on them): is it the waits or the traffic?
-    "streamdiscard": [("            const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(nxt + min(toff + 4 * BT_T * i, nlim)));   // streamed once\n            v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;",
-                       "            { f4v f; asm volatile(\"global_load_dwordx4 %0, %1, off nt\" : \"=v\"(f) : \"v\"(nxt + min(toff + 4 * BT_T * i, nlim))); }\n            v[i][0] += 1e-3f;")],
-    # every prefetch reads row 0 of plane 0 (served by L2): same instructions, no HBM traffic
-    "streaml2": [("            const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(nxt + min(toff + 4 * BT_T * i, nlim)));",
-                  "            const f4v f = *reinterpret_cast<const f4v*>(x00 + min(toff + 4 * BT_T * i, nlim));"),
-                 ("                                          const float* __restrict__ nxt, int nlim, int toff) {", "                                          const float* __restrict__ nxt, int nlim, int toff, const float* x00) {"),
-                 ("idx, nxt, nlim, toff); break;", "idx, nxt, nlim, toff, a.planes[0]); break;")],
-    # regular (temporal) loads instead of nt
-    "streamtemporal": [("            const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(nxt + min(toff + 4 * BT_T * i, nlim)));",
-                        "            const f4v f = *reinterpret_cast<const f4v*>(nxt + min(toff + 4 * BT_T * i, nlim));")],
-    # neither swaps nor streaming: the lookups alone (+ stores)
-    "lookuponly": [("            const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(nxt + min(toff + 4 * BT_T * i, nlim)));   // streamed once\n            v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;",
-                    "            v[i][0] += 1e-3f;"), ("            const bool swap = cur != s;", "            const bool swap = cur < 0;")],
+    "nostream": [("        return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(base + min(my_off() + 4 * BT_T * i, lim)));   // streamed once",
+                  "        f4v r = {1.f, 2.f, 3.f, 4.f}; asm volatile(\"\" : \"+v\"(r)); return r;")],
     # no table swaps (the first system's table stays): what the LDS-DMA phases cost
     "noswap": [("            const bool swap = cur != s;", "            const bool swap = cur < 0;")],
 }
