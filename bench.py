@@ -450,8 +450,26 @@ def measure_configs(dev, N=27942):
                 st = [s.stats(norm) for s in systems.values()] if norm != "percentile-rank" else None
                 return ops.fuse_nsf(planes, ranks, w, norm, distr if norm == "percentile-rank" else None, out=fused, stats=st, valid_bits=vbits)
             ms = timeit_ms(call, n=10)
-            out.append(dict(config=f"4: nsf {norm} fusion, S=4, colbert 40% absent", shape=dict(Q=Q, N=N, S=4),
+            out.append(dict(config=f"4: nsf {norm} fusion, S=4, colbert 40% absent" + (", P=1001" if norm == "percentile-rank" else ""), shape=dict(Q=Q, N=N, S=4),
                             **roof("fuse_nsf kernels", ms, work, "hbm")))
+        # percentile-rank / NCE with the tables the reference READS (hybrid.py:412,451: the `_28k` table = len(corpus) + 1 quantiles per
+        # system): one system's table LDS-resident at a time (csrc/tables.hip); tables prepared inside the call, as fuse_device does
+        P28 = N + 1
+        distr28 = []
+        for p_ in planes:
+            pool = torch.sort(p_[:64, :N].flatten().double()).values
+            pos = torch.linspace(0, pool.numel() - 1, P28, device=dev, dtype=torch.float64)
+            lo_ = pos.floor().long(); hi_ = torch.clamp(lo_ + 1, max=pool.numel() - 1)
+            distr28.append((pool[lo_] + (pool[hi_] - pool[lo_]) * (pos - lo_)).float().contiguous())
+        for norm in ("percentile-rank", "normal-curve-equivalent"):
+            ms = timeit_ms(lambda: ops.fuse_nsf(planes, ranks, w, norm, distr28, out=fused, valid_bits=vbits), n=10)
+            assert ops.last_tables_path == "lds-swap"
+            row = dict(config=f"4: nsf {norm}, S=4, P={P28} (the table size hybrid.py:412,451 read), colbert 40% absent", shape=dict(Q=Q, N=N, S=4, P=P28),
+                       **roof("fuse_nsf_bigtab_kernel", ms, work, "hbm"))
+            if Q == 1024 and norm == "percentile-rank":   # what these sizes cost before round 4: fz_fuse_nsf_f32's global-memory search
+                row["ms_round3_path"] = timeit_ms(lambda: ops.fuse_nsf(planes, ranks, w, norm, distr28, out=fused, valid_bits=vbits, tables=False), n=3)
+            out.append(row)
+        del distr28
         ms = timeit_ms(lambda: Aggregator.fuse_device(systems, "nsf", "min-max", dict(zip(names, w)), {}), n=5)
         out.append(dict(config="4: Aggregator.fuse_device nsf min-max END TO END (stats + fuse + insertion order + final sort)", shape=dict(Q=Q, N=N, S=4),
                         ms=ms, queries_per_s=Q / (ms * 1e-3)))
@@ -472,6 +490,32 @@ def measure_configs(dev, N=27942):
                 torch.cuda.synchronize(); dt = time.perf_counter() - t0
                 out.append(dict(config=f"4: weight sweep nsf {norm}, {len(grid)} vectors (np.float64 lattice, float64 sweep)", shape=dict(Q=Q, N=N, S=4, W=len(grid)),
                                 ms=dt * 1e3, ms_per_weight_vector=dt * 1e3 / len(grid), note="wall clock incl. host-side metrics"))
+        if Q == 195:
+            # the drop-in boundary with the REFERENCE'S OWN TYPES in and out (hybrid.py:66-75,170-220: list[Q] of list[<= N] of
+            # {'corpus_id', 'score'} per system -> the fused lists in the same form): host packing (csrc/pyhost.c + numpy), upload, the
+            # device fusion, download, rebuilding the dicts.  The first 32 queries of the batch (3.4 M dicts in, 0.9 M out per call); the
+            # cost is per query.  Aggregator.fuse(..., as_device=True) callers -- main() -- pay the device part only.
+            from fusion_amd.retrievers.hybrid import pack_ranked_lists
+            Qb = 32
+            sub = {n: RankedSystem(scores=s.scores[:Qb], order=s.order[:Qb], rank=s.rank[:Qb], lens=s.lens[:Qb], ids=np.arange(N) + 1, full=s.full)
+                   for n, s in systems.items()}
+            as_lists = {n: s.to_lists() for n, s in sub.items()}
+            t0 = time.perf_counter(); pack_ranked_lists(as_lists); pack_ms = (time.perf_counter() - t0) * 1e3
+            for method, norm, lw in (("rrf", None, None), ("nsf", "min-max", dict(zip(names, w)))):
+                Aggregator.fuse(as_lists, method, norm, lw, {})                      # warm
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                res_lists = Aggregator.fuse(as_lists, method, norm, lw, {})
+                total_ms = (time.perf_counter() - t0) * 1e3
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                fd = Aggregator.fuse(as_lists, method, norm, lw, {}, as_device=True)
+                torch.cuda.synchronize(); to_dev_ms = (time.perf_counter() - t0) * 1e3   # pack + upload + device fusion
+                t0 = time.perf_counter(); fd.to_lists(); unpack_ms = (time.perf_counter() - t0) * 1e3
+                assert len(res_lists) == Qb and len(res_lists[0]) == N
+                out.append(dict(config=f"boundary: Aggregator.fuse {method}{' ' + norm if norm else ''}, reference types in and out", shape=dict(Q=Qb, N=N, S=4),
+                                ms_per_query=total_ms / Qb, queries_per_s=Qb / (total_ms * 1e-3), pack_ms_per_query=pack_ms / Qb,
+                                pack_upload_device_ms_per_query=to_dev_ms / Qb, download_unpack_ms_per_query=unpack_ms / Qb,
+                                note="host-bound by construction: 4 x 27,942 dicts in and 27,942 out per query; round 3: ~102 ms per query"))
+            del as_lists, sub, res_lists, fd
         del planes, systems, ranks, fused
 
     log("configs: fusion + sweep done")
@@ -590,11 +634,18 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
         splade_query_nnz = float(torch.count_nonzero(v_last).item()) / Q
         splade_diff = float((ops.dot_scores(ops.normalize_rows(v_last), Ds) - ops.sparse_cos_scores(v_last, Ds_index)).abs().max())
         del v_last
-        enc["colbert"].amp = False                 # the same query encode with float32 Linears, for the record (not part of the pipeline time)
+        enc["colbert"].amp = False                 # the same pipeline with a float32 ColBERT query encoder (both ways)
         colbert_fp32_ms = timeit_ms(lambda: enc["colbert"].encode_query_ids(cq_d), n=2, warm=1)
+        step(lambda n: None)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            step(lambda n: None)
+        torch.cuda.synchronize()
+        wall_fp32 = (time.perf_counter() - t0) / reps
         enc["colbert"].amp = True
         out.append(dict(config="4: BM25+DPR+SPLADE+ColBERT pipeline END TO END (query encode x3, score x4, full ranking x4, nsf min-max fusion, final order)",
-                        shape=dict(Q=Q, N=N, S=4), ms=wall * 1e3, queries_per_s=Q / wall, stages_ms=stages,
+                        shape=dict(Q=Q, N=N, S=4), ms=wall * 1e3, queries_per_s=Q / wall, ms_colbert_fp32=wall_fp32 * 1e3,
+                        queries_per_s_colbert_fp32=Q / wall_fp32, stages_ms=stages,
                         dtypes=dict(dpr="f32", splade="f32", bm25="f64",
                                     colbert="encoder Linears float16 (colbert-ai runs query() / doc() under autocast; multi_dense_biencoder.py:55 'amp': True), everything "
                                             "else of the forward float32; token vectors float16; MaxSim f16 MFMA, f32 accumulate"),
@@ -823,12 +874,48 @@ def e_sample(dev, n, d):
     return torch.randn((n, d), generator=g, device=dev)
 
 
+def launcher_argv(argv, n_gpus, port):
+    """`python bench.py --gpus N ...` outside torch.distributed.run: the command line of the N-rank job this process starts as a CHILD
+    (one rank per GPU, RCCL over xGMI; 127.0.0.1 rendezvous: the container hostname may not resolve) -- the driver's own form."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(args):
+    """Start the N ranks and relay rank 0's JSON line.  This parent makes NO GPU call (a process that has touched the GPU must not be
+    replaced or forked into workers on this pool): it only starts the child, streams its output through, and exits with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = launcher_argv(sys.argv[1:], args.gpus, port)
+    log(f"--gpus {args.gpus} without WORLD_SIZE: starting {' '.join(cmd[1:7])} ... as a child process")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.rstrip("\n")          # rank 0's one line: printed last, alone
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        rc = 1
+    sys.exit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                     # never returns
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     backend = os.environ.get("FUSION_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
@@ -944,6 +1031,18 @@ def main():
             torch.cuda.empty_cache()
             log("configs 2-5 done; config-4 pipeline ...")
             res["configs_measured"] += measure_pipeline4(dev, N)
+            # the figures the round's work moves, repeated inside `config` (the driver's parsed record keeps `config`, not the stdout tail)
+            for c in res["configs_measured"]:
+                name, Qc = c.get("config", ""), c.get("shape", {}).get("Q")
+                if name.startswith("4: BM25+DPR+SPLADE+ColBERT pipeline") and Qc in (1024, 195):
+                    res["config"][f"config4_ms_q{Qc}"] = round(c["ms"], 2)
+                    res["config"][f"config4_queries_per_s_q{Qc}"] = round(c["queries_per_s"], 1)
+                    res["config"][f"config4_ms_colbert_fp32_q{Qc}"] = round(c["ms_colbert_fp32"], 2)
+                elif name.startswith("4: nsf percentile-rank, S=4, P=") and Qc == 1024:
+                    res["config"]["config4_percentile_P27943_ms"] = round(c["ms"], 4)
+                    res["config"]["config4_percentile_P27943_hbm_frac"] = round(c["frac"], 4)
+                elif name.startswith("boundary: Aggregator.fuse rrf"):
+                    res["config"]["boundary_rrf_ms_per_query"] = round(c["ms_per_query"], 2)
         res["north_star_targets"] = north_star_targets(res)
         print(json.dumps(res))
     if dist:

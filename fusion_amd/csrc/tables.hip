@@ -12,23 +12,29 @@
 //   * persistent 1024-thread workgroups (one per CU) walk (query row, 28,672-column chunk) items; the fused accumulators of
 //     the item live in registers (7 float4 per thread) across the S systems, so every plane still crosses HBM exactly once
 //     and nothing is accumulated through memory;
-//   * per (item, system) the system's table and its bucket table are brought into LDS by LDS-DMA (global_load_lds, 16 B per
-//     lane, no VGPRs) from an aligned, +inf-padded copy in the workspace -- 144 KB from L2 per swap (the tables are read by
-//     every workgroup: L2-resident), ~1 us against ~28 k searches; the row's scores are loaded into registers under it.  With
-//     S = 1 (Aggregator.tune normalises system by system) the table is loaded once per workgroup;
+//   * per (item, system) step the system's table and its bucket table are brought into LDS by LDS-DMA (global_load_lds, 16 B
+//     per lane, no VGPRs) from an aligned, sentinel-padded copy in the workspace -- 144 KB from L2 per swap (the tables are read
+//     by every workgroup: L2-resident), ~2.5 us against ~28 k searches (measured: 0.03 of the 0.27 ms).  With S = 1
+//     (Aggregator.tune normalises system by system) the table is loaded once per workgroup;
+//   * the step's scores are requested from HBM one step AHEAD: a float4's registers take the same float4 of the next step as
+//     soon as it has been searched (measured: the stream costs 0.03 ms instead of its 0.09 standalone);
 //   * the search: an equi-width bucket table over [tab[0], tab[P-1]] with 16,384 buckets (uint16: 32 KB) is built ONCE per call
 //     by fz_nsf_tables_prepare with the SAME float expression the scores go through (bucket(x) = (int)clamp((x - lo) * inv_w)),
 //     lut[b] = #{k : bucket(tab[k]) < b}.  bucket() is monotone, so for a score in bucket b every entry before lut[b] is
-//     smaller and every entry from lut[b+1] on is larger: the bracket [lut[b] - 1, lut[b+1]) holds the answer BY CONSTRUCTION
-//     (no verification reads) and is a handful of entries wide where the table is densest (quantiles of a score distribution
-//     are dense exactly where the scores are: an equi-width table of 2,048 buckets, fuse.hip's, leaves ~60 entries there).
-//     Four scores of a float4 are searched in lockstep (independent LDS reads in flight), then three reads around the result
-//     decide between the two neighbours with the reference's float32 distances; equal distances to the left (duplicated
-//     quantiles, rounding plateaus) are resolved to the FIRST index by a short walk, then a binary search over the plateau;
-//   * percentile-rank's value is (float)k / (float)P in registers; NCE's value depends on the score only through k and costs
-//     a double-precision erfinv: tabulated once per call ([P] floats per system in the workspace, the expression of
-//     fuse.hip's transform<FZ_NORM_NCE>), it either sits next to the table in LDS (P <= ~16 k) or is swapped in over the
-//     table once the item's 28 indices per thread are known.
+//     smaller and every entry behind the bucket larger: the answer is found from lut[b] on BY CONSTRUCTION (no verification
+//     reads), and the buckets are a handful of entries full where the table is densest (quantiles of a score distribution
+//     are dense exactly where the scores are: an equi-width table of 2,048 buckets, fuse.hip's, leaves ~60 entries there;
+//     with 16,384 the fullest bucket of an LLeQA-shaped table holds 5-10).  The search itself probes PAIRS of entries
+//     (ds_read_b64: two entries for the LDS cycles of one) -- see bt_lookup;
+//   * percentile-rank's value is (float)k / (float)P, computed division-free and exactly (bt_quot); NCE's value depends on the
+//     score only through k and costs a double-precision erfinv: tabulated once per call ([P] floats per system in the
+//     workspace, the expression of fuse.hip's transform<FZ_NORM_NCE>), it either sits next to the table in LDS (P <= ~16 k) or
+//     is swapped in over the table once the item's 28 indices per thread are known.
+//
+// What bounds it (profiles/r04_pmc_tables.json, S = 4, Q = 1024, N = P - 1 = 27,942: 0.27 ms = 2.1 TB/s of the fusion's algorithmic
+// bytes): 51 vector instructions and 4.6 LDS instructions per score -- 0.15 ms of vector-ALU issue and 0.12 ms of LDS cycles (62 % of
+// them bank conflicts: the reads are random by nature) that overlap only in part; the round-3 path it replaces at these sizes
+// (fz_fuse_nsf_f32's global-memory search) takes 2.8 ms, NCE 9.4 ms.
 //
 // Same nearest entry, same float expressions as the per-score device function (fuse.hip percentile_rank): bit-identical
 // results -- tests/test_gpu_tables.py holds the three kernels against each other and against the reference's own outputs

@@ -117,8 +117,11 @@ class ShardedDenseIndex:
                 best_s, best_i = ops.topk_merge(torch.stack([best_s, s]), torch.stack([best_i, i])); mark("shard_topk_exact")
         self.last_overflow = 0
         if stream is not None:
-            best_s, best_i, _ = stream.result(); mark("shard_topk_stream")
-            self.last_overflow = stream.windows_redone
+            best_s, best_i, flag = stream.result(); mark("shard_topk_stream")
+            if int(flag.item()) != 0:   # a window of materialised scores overflowed (the stream holds no score plane: one chunk alive at a
+                res = self.local_topk(Qn, k, streaming=False, mark=mark)   # time): this shard again on the exact path
+                self.last_overflow = 1
+                return res
         return best_s, best_i
 
     def search(self, Qn: torch.Tensor, k: int = 1000, mark=None):

@@ -17,6 +17,7 @@ from __future__ import annotations
 import hashlib
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -369,6 +370,7 @@ class DenseEncoder(_Base):
     @torch.no_grad()
     def encode_ids_corpus(self, input_ids: torch.Tensor, lengths) -> torch.Tensor:
         """encode_ids_packed for more sequences than one forward should hold: sub-batches of at most `packed_tokens` token rows."""
+        lengths = np.asarray(lengths)     # (a Python list of token counts is as good as an array)
         out = torch.empty((input_ids.shape[0], self.dim), dtype=torch.float32, device=self._device)
         for idx in _id_batches(lengths, self.packed_tokens):
             sel = torch.from_numpy(idx).to(self._device)
@@ -470,6 +472,7 @@ class SpladeEncoder(_Base):
         fwd = self._packed_forward(getattr(self.mlm, self.mlm.base_model_prefix))
         if fwd is None:
             raise RuntimeError("SpladeEncoder.encode_ids_packed needs the padding-free forward (GPU, 64-wide heads)")
+        lengths = np.asarray(lengths)
         out = torch.empty((input_ids.shape[0], self.dim), dtype=torch.float32, device=self._device)
         for idx in _id_batches(lengths, self.HEAD_TOKENS):
             sel = torch.from_numpy(idx).to(self._device)
@@ -538,6 +541,13 @@ class ColbertEncoder(_Base):
         ids[:, 1] = marker_id
         return ids, mask
 
+    def _project(self, x: torch.Tensor) -> torch.Tensor:
+        """The 128-d projection of packed hidden rows, in the precision the HF route (_tokens) runs it: under colbert-ai's autocast
+        the Linear takes and returns float16 (float32 accumulate); the normalisation that follows is float32 either way."""
+        if self.amp:
+            return torch.nn.functional.linear(x.half(), self.linear.weight.half()).float()
+        return self.linear(x)
+
     @torch.no_grad()
     def _tokens(self, ids, mask):
         with torch.autocast(self._device.type, dtype=torch.float16, enabled=self.amp):      # the HF module as colbert-ai runs it
@@ -560,7 +570,7 @@ class ColbertEncoder(_Base):
             ids = torch.where(mask.bool(), ids, torch.full_like(ids, self.tokenizer.mask_token_id)).to(self._device, non_blocking=True)
             if fwd is not None:
                 x, _ = fwd.hidden(ids, np.full(len(part), Lq))
-                out[s0: s0 + len(part)] = ops.normalize_rows(self.linear(x)).view(len(part), Lq, self.dim).half()
+                out[s0: s0 + len(part)] = ops.normalize_rows(self._project(x)).view(len(part), Lq, self.dim).half()
             else:
                 # colbert-ai multiplies Q by (ids != pad), all ones once the padding is the mask token: every row is kept
                 att = torch.ones_like(ids) if self.attend_to_mask_tokens else mask.to(self._device)
@@ -577,7 +587,7 @@ class ColbertEncoder(_Base):
             raise RuntimeError("ColbertEncoder.encode_query_ids needs the padding-free forward (GPU, 64-wide heads)")
         Q, Lq = ids.shape
         x, _ = fwd.hidden(ids, np.full(Q, Lq), mark)
-        out = ops.normalize_rows(self.linear(x)).view(Q, Lq, self.dim).half()
+        out = ops.normalize_rows(self._project(x)).view(Q, Lq, self.dim).half()
         if mark: mark("colbert_project")
         return out
 
@@ -597,7 +607,7 @@ class ColbertEncoder(_Base):
         for idx in _id_batches(lengths, self.packed_tokens):
             sel = torch.from_numpy(idx).to(self._device)
             x, _ = fwd.hidden(input_ids.index_select(0, sel), lengths[idx])
-            v = ops.normalize_rows(self.linear(x)).half()
+            v = ops.normalize_rows(self._project(x)).half()
             rows = np.concatenate([np.arange(off[i], off[i + 1]) for i in idx]) if len(idx) else np.zeros(0, dtype=np.int64)
             tok[torch.from_numpy(rows).to(self._device)] = v
         return tok, torch.from_numpy(off).to(self._device)
@@ -639,7 +649,7 @@ class ColbertEncoder(_Base):
         for idx, ids, lens in _token_batches(self, docs, self.max_doc_length, batch_size,
                                              tokenize=lambda texts, L: self._marked(texts, L, self.d_marker_id, False)):
             x, _ = fwd.hidden(ids.to(self._device, non_blocking=True), lens)
-            v = ops.normalize_rows(self.linear(x)).half()                               # [T, 128], rows in sub-batch order
+            v = ops.normalize_rows(self._project(x)).half()                               # [T, 128], rows in sub-batch order
             ids_np = ids.numpy()
             keep_rows, starts = [], np.zeros(len(idx) + 1, dtype=np.int64)
             np.cumsum(lens, out=starts[1:])

@@ -750,7 +750,9 @@ class TopkStream:
     flag is read at every fold (one small device -> host read per window: 4 per 1.1 M-document shard) and an overflowed WINDOW is redone
     exactly -- per-piece top-k (fz_topk_rows_f32) merged into the list as it stood before the window -- so a corpus ordered by relevance
     (every window overflows) costs the exact search once, not a wasted streaming pass plus the exact search of the whole shard;
-    `windows_redone` counts them.  Without it the flag stays set and the caller redoes the search."""
+    `windows_redone` counts them.  That needs what the window was fed with: feed_gemm's pieces are views of Qn / Dn (kept: no copies);
+    feed()'s score buffers are kept only on request (hold=True) -- otherwise, and without exact_on_overflow, the flag stays set and
+    the caller redoes the search."""
 
     def __init__(self, run_scores: torch.Tensor, run_ids: torch.Tensor, seen: int, cap: int = 7168, exact_on_overflow: bool = True):
         _dev(run_scores, torch.float32, "TopkStream(run_scores)"); _dev(run_ids, torch.int64, "TopkStream(run_ids)")
@@ -773,6 +775,7 @@ class TopkStream:
         self.exact_on_overflow = bool(exact_on_overflow)
         self.windows_redone = 0
         self._pieces = []                # what the current window was fed with: ("scores", piece, id_base) | ("gemm", Qn, Dpiece, id_base)
+        self._unheld = False             # ... and whether some of it was fed without being held (feed(hold=False))
         wsb = int(_lib.lib().fz_topk_fold_workspace_bytes(rows, k, cap))
         self._ws, self._wsb = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev), wsb
 
@@ -780,8 +783,12 @@ class TopkStream:
         """documents one threshold may serve: expected candidates k * window / seen <= cap / 2"""
         return max(64, (self.cap // 2) * self.seen // self.k // 64 * 64)
 
-    def feed(self, scores: torch.Tensor, id_base: int):
-        """scores [rows, n] of documents id_base .. id_base + n - 1"""
+    def feed(self, scores: torch.Tensor, id_base: int, hold: bool = False):
+        """scores [rows, n] of documents id_base .. id_base + n - 1.
+        hold=False (default): nothing of `scores` is kept -- the caller may overwrite or free the buffer as soon as the call returns; a
+        window fed this way cannot be redone, so if it overflows the `overflow` flag STAYS SET and the caller redoes the search
+        (ShardedDenseIndex.local_topk does).  hold=True: the stream keeps a view of the piece until the window is folded and redoes an
+        overflowed window exactly from it -- only for callers that leave the buffer untouched (and can afford it alive) until then."""
         _dev(scores, torch.float32, "TopkStream.feed(scores)")
         _need(scores.shape[0] == self.rows, "TopkStream.feed: one row per running list")
         lib = _lib.lib()
@@ -792,7 +799,10 @@ class TopkStream:
             check(lib.fz_topk_filter_append_f32(_ptr(piece), self.rows, hi - lo, _ld(scores), int(id_base) + lo, _ptr(self.tau), _ptr(self.cand_s),
                                                 _ptr(self.cand_i), _ptr(self.cand_len), self.cap, _ptr(self.overflow), _stream(scores)),
                   "fz_topk_filter_append_f32")
-            self._pieces.append(("scores", piece, int(id_base) + lo))
+            if hold:
+                self._pieces.append(("scores", piece, int(id_base) + lo))
+            else:
+                self._unheld = True          # this window saw scores the stream does not hold: no exact redo for it
             self.pending += hi - lo
             lo = hi
             if self.pending >= self._window():
@@ -829,7 +839,7 @@ class TopkStream:
         check(_lib.lib().fz_topk_fold_f32(_ptr(self.best_s), _ptr(self.best_i), self.rows, self.k, _ptr(self.cand_s), _ptr(self.cand_i),
                                           _ptr(self.cand_len), self.cap, 1 if self.unordered else 0, _ptr(ns), _ptr(ni), _ptr(self.tau),
                                           _ptr(self.overflow), _ptr(self._ws), self._wsb, _stream(self.best_s)), "fz_topk_fold_f32")
-        if self.exact_on_overflow and int(self.overflow.item()) != 0:
+        if self.exact_on_overflow and not self._unheld and int(self.overflow.item()) != 0:
             # a candidate list was cut short (or a tie run was too long to order): this window again, exactly, on top of the list as it
             # stood before it -- per piece: scores -> fz_topk_rows_f32 -> merge (ties by ascending id, as everywhere)
             ns, ni = self.best_s, self.best_i
@@ -848,6 +858,7 @@ class TopkStream:
             self.overflow.zero_()
             self.windows_redone += 1
         self._pieces.clear()
+        self._unheld = False                 # (an overflow of that window has left the flag set: it is never cleared again)
         self.best_s, self.best_i = ns, ni
         self.seen += self.pending
         self.pending = 0
@@ -1009,7 +1020,11 @@ def sparse_cos_scores(Qe: torch.Tensor, index: SparseIndex, max_query_density: f
     re-densified corpus instead -- same scores either way."""
     Qn = normalize_rows(pad_dim(Qe))
     if density(Qn[:, :index.V]) > max_query_density:
-        return dot_scores(Qn, index.to_dense())
+        # re-densified ONCE per index and kept (N x V float32: 3.6 GB at LLeQA size -- a fresh allocation + scatter per query batch would
+        # cost more than the GEMM it feeds); a query encoder that is not sparse stays on this path for every batch
+        if getattr(index, "_dense", None) is None:
+            index._dense = pad_dim(index.to_dense())
+        return dot_scores(Qn, index._dense)
     return sparse_dot(index, *sparse_rows(Qn, index.V))
 
 

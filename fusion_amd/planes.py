@@ -14,6 +14,28 @@ import numpy as np
 import torch
 
 
+class _gc_paused:
+    """Building Q x N small dicts trips the cyclic collector's generation thresholds again and again, and every full collection walks
+    all the dicts made so far (they are containers): paused for the duration, the lists cost their allocations only."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+
+
+def _dict_list(cids: list, scores: list) -> list[dict]:
+    """[{'corpus_id': c, 'score': s}, ...] -- the reference's list entry (hybrid.py:75,307); ids arrive as Python objects
+    (ndarray.tolist(): ints for integer tables, the original objects for an object table)."""
+    from . import _pyhost
+    return _pyhost.build(cids, scores)
+
+
 @dataclass
 class RankedSystem:
     scores: torch.Tensor          # [Q, N] float32 plane: score of doc j for query q (undefined where rank < 0)
@@ -78,10 +100,10 @@ class RankedSystem:
             sc = self.scores.cpu().numpy()
             ss = np.take_along_axis(sc, np.maximum(order, 0).astype(np.int64), axis=1)
         out = []
-        for q in range(self.Q):
-            n = int(lens[q]) if topk is None else min(int(lens[q]), topk)
-            cid = self.ids[order[q, :n]]
-            out.append([{"corpus_id": c.item() if hasattr(c, "item") else c, "score": float(s)} for c, s in zip(cid, ss[q, :n])])
+        with _gc_paused():
+            for q in range(self.Q):
+                n = int(lens[q]) if topk is None else min(int(lens[q]), topk)
+                out.append(_dict_list(self.ids[order[q, :n]].tolist(), ss[q, :n].astype(np.float64).tolist()))   # Python floats (float(s))
         return out
 
 
@@ -99,11 +121,12 @@ class FusedResult:
         lens = self.lens.cpu().numpy()
         f32 = sc.dtype == np.float32
         out = []
-        for q in range(order.shape[0]):
+        with _gc_paused():
+          for q in range(order.shape[0]):
             n = int(lens[q])
-            cid = self.ids[order[q, :n]]
-            out.append([{"corpus_id": c.item() if hasattr(c, "item") else c, "score": (np.float32(s) if f32 else float(s))}
-                        for c, s in zip(cid, sc[q, :n])])
+            # nsf scores leave the reference as np.float32 scalars (hybrid.py:258 ... zip(keys, scores.cpu().numpy())), rrf / bcf / 'none'
+            # as Python floats: iterating a float32 array yields exactly those scalars, .tolist() the Python floats -- one C loop each
+            out.append(_dict_list(self.ids[order[q, :n]].tolist(), list(sc[q, :n]) if f32 else sc[q, :n].tolist()))
         return out
 
     def predictions(self, topk: int | None = None) -> list[list]:

@@ -154,7 +154,10 @@ class Ranker:
         model = encoder if encoder is not None else encoders.from_pretrained(model_name_or_path, "colbert", device=_device())
         # the reference reuses its on-disk PLAID index when it exists (hybrid.py:126-130); the analogue here is the
         # cached exact token matrix
-        key = encoders.corpus_cache_key(model_name_or_path, documents, "colbert") if cache_dir else ""
+        # ... keyed by the encoder's precision too: token matrices of a float32 forward and of the mixed-precision one differ by a few
+        # float16 steps, and a cache filled by one must not be scored against queries encoded by the other
+        precision = "colbert-amp16" if getattr(model, "amp", False) else "colbert-fp32"
+        key = encoders.corpus_cache_key(model_name_or_path, documents, precision) if cache_dir else ""
         Dtok, Doff = encoders.cached_tensors(cache_dir, key, ["tok", "off"], lambda: model.encode_docs(documents, batch_size=64))
         Dtok, Doff = Dtok.to(_device()), Doff.to(_device())
         Qtok = model.encode_queries(queries, batch_size=64)
@@ -194,6 +197,134 @@ class Ranker:
         return ranked_lists
 
 
+def _pack_by_dicts(ranked_lists: dict):
+    """The reference's own data flow, entry by entry (any hashable id): corpus position = first-seen order of the ids."""
+    names = list(ranked_lists.keys())
+    Q = len(next(iter(ranked_lists.values())))
+    pos: dict = {}
+    for n in names:
+        for lst in ranked_lists[n]:
+            for x in lst:
+                if x["corpus_id"] not in pos:
+                    pos[x["corpus_id"]] = len(pos)
+    N = max(len(pos), 1)
+    ids = np.empty(N, dtype=object)
+    for k, v in pos.items():
+        ids[v] = k
+    try:
+        if all(type(k) is int for k in pos):     # (a bool or a float id stays what it is: astype would turn True into 1)
+            ids = ids.astype(np.int64)
+    except (TypeError, ValueError, OverflowError):
+        pass
+    ld = ops.round_up(N, 64)
+    packed = {}
+    for n in names:
+        sc64 = np.zeros((Q, ld), dtype=np.float64)
+        rk = np.full((Q, ld), -1, dtype=np.int32)
+        od = np.full((Q, ld), -1, dtype=np.int32)
+        ln = np.zeros(Q, dtype=np.int32)
+        is_sorted = True
+        for q, lst in enumerate(ranked_lists[n]):
+            d = {}
+            for x in lst:            # convert2dict (hybrid.py:231): first position kept, last score wins
+                d[x["corpus_id"]] = x["score"]
+            if d:
+                j = np.fromiter((pos[c] for c in d.keys()), dtype=np.int64, count=len(d))
+                v = np.fromiter(d.values(), dtype=np.float64, count=len(d))
+                sc64[q, j] = v
+                rk[q, j] = np.arange(len(d), dtype=np.int32)
+                od[q, : len(d)] = j
+                v32 = v.astype(np.float32)
+                is_sorted = is_sorted and bool(np.all(v32[:-1] >= v32[1:]))   # False for NaN as well
+            ln[q] = len(d)
+        packed[n] = (sc64, rk, od, ln, is_sorted)
+    return ids, N, packed
+
+
+def pack_ranked_lists(ranked_lists: dict):
+    """The reference's RankedLists (hybrid.py:66-75: system -> list[Q] of list[<= N] of {'corpus_id', 'score'}) -> per system the host
+    planes a RankedSystem is made of: (scores64 [Q, ld], rank [Q, ld], order [Q, ld], lens [Q], every list sorted by score?), plus the
+    corpus position -> id table.  Pure host work, no device involved (bench.py times it as the boundary's packing cost).
+
+    Integer ids (the reference's: dataset article ids, hybrid.py:66) take a vectorised route: ids and scores of a list are pulled out by
+    one C loop over the dicts (csrc/pyhost.c), positions come from a direct table over the id range (any bijection id <-> position
+    serves: ties are broken by list order, never by position), duplicates inside a list -- convert2dict keeps the FIRST position and the
+    LAST score, hybrid.py:231 -- are detected by a scatter/gather round trip and sent, list by list, through the dict.  Everything else
+    (string ids, ids that do not fit int64, booleans ...) goes the reference's own entry-by-entry way."""
+    from .. import _pyhost
+    names = list(ranked_lists.keys())
+    Q = len(next(iter(ranked_lists.values())))
+    raw = {}
+    for n in names:
+        per_q = []
+        for lst in ranked_lists[n]:
+            got = _pyhost.extract(lst) if type(lst) is list else None
+            if got is None:
+                return _pack_by_dicts(ranked_lists)
+            per_q.append(got)
+        raw[n] = per_q
+    # the id table: the union of all lists' ids, sorted; position of an id = its index there.  Ids in a modest range (dataset article
+    # ids are) map through a direct table -- one gather per list; a sparse id space falls back to searchsorted
+    lo = min((int(c.min()) for n in names for c, _ in raw[n] if c.size), default=0)
+    hi = max((int(c.max()) for n in names for c, _ in raw[n] if c.size), default=0)
+    direct = hi - lo < (1 << 26)
+    if direct:
+        seen = np.zeros(hi - lo + 1, dtype=bool)
+        for n in names:
+            for cid, _ in raw[n]:
+                seen[cid - lo] = True
+        table = np.flatnonzero(seen).astype(np.int64) + lo
+        where = np.cumsum(seen, dtype=np.int32) - 1          # id - lo -> position
+        locate = lambda cid: where[cid - lo]
+    else:
+        table = np.empty(0, dtype=np.int64)
+        for n in names:
+            for cid, _ in raw[n]:
+                if cid.size == 0:
+                    continue
+                if table.size:
+                    j = np.minimum(np.searchsorted(table, cid), table.size - 1)
+                    if np.array_equal(table[j], cid):
+                        continue
+                table = np.union1d(table, cid)
+        locate = lambda cid: np.searchsorted(table, cid)
+    N = max(int(table.size), 1)
+    ids = table if table.size else np.zeros(1, dtype=np.int64)
+    ld = ops.round_up(N, 64)
+    packed = {}
+    for n in names:
+        sc64 = np.zeros((Q, ld), dtype=np.float64)
+        rk = np.full((Q, ld), -1, dtype=np.int32)
+        od = np.full((Q, ld), -1, dtype=np.int32)
+        ln = np.zeros(Q, dtype=np.int32)
+        is_sorted = True
+        for q, (cid, val) in enumerate(raw[n]):
+            m = cid.size
+            if m == 0:
+                continue
+            j = locate(cid)
+            ar = np.arange(m, dtype=np.int32)
+            rk[q, j] = ar
+            if not np.array_equal(rk[q, j], ar):     # an id occurs twice: first position kept, last score wins (hybrid.py:231)
+                d = {}
+                for c, v_ in zip(cid.tolist(), val.tolist()):
+                    d[c] = v_
+                cid = np.fromiter(d.keys(), dtype=np.int64, count=len(d))
+                val = np.fromiter(d.values(), dtype=np.float64, count=len(d))
+                m = cid.size
+                rk[q, j] = -1
+                j = locate(cid)
+                ar = np.arange(m, dtype=np.int32)
+                rk[q, j] = ar
+            sc64[q, j] = val
+            od[q, :m] = j
+            ln[q] = m
+            v32 = val.astype(np.float32)
+            is_sorted = is_sorted and bool(np.all(v32[:-1] >= v32[1:]))   # False for NaN as well
+        packed[n] = (sc64, rk, od, ln, is_sorted)
+    return ids, N, packed
+
+
 class Aggregator:
     """Normalise + fuse ranked lists (hybrid.py:166-307)."""
 
@@ -203,6 +334,10 @@ class Aggregator:
     # based promotion, the reference's own pinned environment (torch 2.1.2 / pandas 2.1.4 era): EVERY nsf product and sum is float64.
     # Scores differ by ~1e-8 relative; near-tied documents can swap.  Also switched on by FUSION_AMD_NUMPY1_PROMOTION=1.
     NUMPY1_PROMOTION = os.environ.get("FUSION_AMD_NUMPY1_PROMOTION", "0") == "1"
+    # fuse_device(topk=k): from this many queries on, float64 fused rows over full lists are SELECTED (ops.select_topk) instead of sorted
+    # and cut; below it the selection's extra launches and its flag read cost more than the sort (bench.py: 0.26 vs 0.14 ms at Q = 195)
+    SELECT_MIN_Q = 512
+    last_topk_path = None     # "select" | "sort": which of the two the last fuse_device(topk=...) took (tests pin it)
 
     @classmethod
     def _wide(cls, w) -> bool:
@@ -264,12 +399,14 @@ class Aggregator:
         # topk: float64 fused rows (rrf / bcf / 'none' / np.float64 weights) over full lists are selected, not sorted -- two thirds of the
         # full float64 sort's time at N = 27,942.  float32 rows (the selection costs what their four-pass sort costs) and partial lists
         # (the inverse insertion order costs more than the selection saves) are sorted and cut
-        select = topk is not None and topk < N and fused.dtype == torch.float64 and all_full and Q >= 512   # (small batches: launch- and sync-bound, the sort wins)
+        select = topk is not None and topk < N and fused.dtype == torch.float64 and all_full and Q >= cls.SELECT_MIN_Q   # (small batches: launch- and sync-bound, the sort wins)
+        cls.last_topk_path = "sort"
         if all_full:
             # first-insertion order == system 0's ranking: its rank plane places every doc (coalesced, no gather)
             if select:
                 sel = ops.select_topk(fused, S[0].rank, topk)
                 if sel is not None:
+                    cls.last_topk_path = "select"
                     return FusedResult(order=sel[0], scores=sel[1], lens=sel[2], ids=S[0].ids)
             lens_out = torch.full((Q,), N, dtype=torch.int32, device=dev)
             order, sk, _ = ops.sort_rows_desc(fused, init_rank=S[0].rank, covers_all=True)   # every list is full: every slot gets written
@@ -389,48 +526,14 @@ class Aggregator:
         if isinstance(first, RankedSystem):
             return ranked_lists
         dev = _device()
-        names = list(ranked_lists.keys())
         Q = len(first)
         assert all(len(v) == Q for v in ranked_lists.values()), (
             "Ranked results from different retrieval systems have varying lenghts across systems (i.e., some systems have been run on more queries).")
-        # corpus position = first-seen order of the ids (any bijection works: ties are broken by list order, not position)
-        pos: dict = {}
-        for n in names:
-            for lst in ranked_lists[n]:
-                for x in lst:
-                    if x["corpus_id"] not in pos:
-                        pos[x["corpus_id"]] = len(pos)
-        N = max(len(pos), 1)
-        ids = np.empty(N, dtype=object)
-        for k, v in pos.items():
-            ids[v] = k
-        try:
-            ids = ids.astype(np.int64)
-        except (TypeError, ValueError):
-            pass
-        ld = ops.round_up(N, 64)
+        ids, N, packed = pack_ranked_lists(ranked_lists)
         out = {}
-        for n in names:
-            sc64 = np.zeros((Q, ld), dtype=np.float64)
-            rk = np.full((Q, ld), -1, dtype=np.int32)
-            od = np.full((Q, ld), -1, dtype=np.int32)
-            ln = np.zeros(Q, dtype=np.int32)
-            is_sorted = True
-            for q, lst in enumerate(ranked_lists[n]):
-                d = {}
-                for x in lst:            # convert2dict (hybrid.py:231): first position kept, last score wins
-                    d[x["corpus_id"]] = x["score"]
-                if d:
-                    j = np.fromiter((pos[c] for c in d.keys()), dtype=np.int64, count=len(d))
-                    v = np.fromiter(d.values(), dtype=np.float64, count=len(d))
-                    sc64[q, j] = v
-                    rk[q, j] = np.arange(len(d), dtype=np.int32)
-                    od[q, : len(d)] = j
-                    v32 = v.astype(np.float32)
-                    is_sorted = is_sorted and bool(np.all(v32[:-1] >= v32[1:]))   # False for NaN as well
-                ln[q] = len(d)
+        t = lambda a: torch.from_numpy(a).to(dev)[:, :N]
+        for n, (sc64, rk, od, ln, is_sorted) in packed.items():
             sc = sc64.astype(np.float32)     # torch.tensor(list(values), dtype=float32) of the normalisations (hybrid.py:255)
-            t = lambda a: torch.from_numpy(a).to(dev)[:, :N]
             exact32 = bool(np.array_equal(sc.astype(np.float64), sc64, equal_nan=True))
             out[n] = RankedSystem(scores=t(sc), order=t(od), rank=t(rk), lens=torch.from_numpy(ln).to(dev), ids=ids,
                                   full=bool((ln == N).all()), scores64=None if exact32 else t(sc64), score_sorted=is_sorted)

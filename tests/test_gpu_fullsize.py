@@ -108,7 +108,9 @@ def test_config5_fused_search_survives_a_relevance_sorted_corpus(ops, oracle):
     for fused in (True, False):
         idx.FUSED = fused
         s, i = idx.local_topk(Qn, k)
-        assert idx.last_overflow >= 2                                # every window behind the head
+        # fused: every window behind the head is redone exactly from the GEMM's operands; materialised scores are not held by the
+        # stream (one chunk alive at a time), so that path flags the overflow and searches the shard again on the exact path
+        assert idx.last_overflow >= (2 if fused else 1)
         es, ei = oracle.topk_rows(ops.dot_scores(Qn, Dn).cpu().numpy(), k)
         np.testing.assert_array_equal(s.cpu().numpy(), es)
         np.testing.assert_array_equal(i.cpu().numpy(), ei)

@@ -625,11 +625,23 @@ def test_topk_stream_flags_candidate_overflow(ops):
     assert int(st.result()[2].item()) == 1
     # default: every overflowed window is redone exactly as it is folded -- the lists are the exact top-k, the flag is clear again
     st = ops.TopkStream(bs, bi, seen=4096, cap=500)
-    st.feed(S[:, 4096:], 4096)
+    st.feed(S[:, 4096:], 4096, hold=True)          # the stream keeps views of S until each window is folded: S stays as it is
     rs, ri, flag = st.result()
     es, ei = ops.topk_rows(S, k)
     assert st.windows_redone >= 1 and int(flag.item()) == 0
     assert torch.equal(rs, es) and torch.equal(ri, ei)
+    # ONE score buffer reused for every chunk (what a chunked caller does): the stream must not rank overwritten data -- scores fed
+    # without hold are never redone, the flag stays set, and the caller's exact fall-back gives the right lists
+    st = ops.TopkStream(bs, bi, seen=4096, cap=500)
+    buf = ops.alloc_plane(rows, 4096, torch.float32, "cuda")
+    for lo in range(4096, n, 4096):
+        hi = min(n, lo + 4096)
+        buf[:, : hi - lo].copy_(S[:, lo:hi])
+        st.feed(buf[:, : hi - lo], lo)
+        buf.fill_(float("nan"))                     # the caller's buffer is the caller's again
+    rs, ri, flag = st.result()
+    assert int(flag.item()) == 1 and st.windows_redone == 0
+    assert not torch.isnan(rs).any()
 
 
 # ---- percentile-rank / NCE: the windowed nearest-entry look-up against the plain first-argmin ------------------------------------------

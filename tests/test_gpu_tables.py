@@ -275,3 +275,97 @@ def test_config4_percentile_weight_grid_at_28k_tables(ops):
     assert ops.last_tables_path == "lds-swap"
     r = run_evaluation(f.predictions(1000), labels, print2console=False)
     assert 0.0 < r["recall@500"] <= 1.0
+
+
+# ---- the top-k SELECTION path of fuse_device through the Aggregator (main() takes it from 512 queries up) -------------------
+@pytest.mark.parametrize("method,norm", [("rrf", None), ("bcf", None), ("nsf", "none")])
+def test_fuse_device_topk_selection_path_equals_the_head_of_the_full_lists(ops, method, norm, monkeypatch):
+    """Aggregator.SELECT_MIN_Q = 1 puts a 7-query batch on the path large batches take: select_topk -> FusedResult(order = [Q, k] columns,
+    lens clamped) -> predictions(1000).  Order, scores, lens and predictions equal the head of the full lists; a tie run at the k-th
+    place that the candidate buffer cannot hold falls back to the full sort."""
+    from fusion_amd.retrievers.hybrid import Aggregator, _rank_scores
+    monkeypatch.setattr(Aggregator, "SELECT_MIN_Q", 1)
+    rng = np.random.default_rng(11)
+    Q, N, k = 7, 27942, 1000
+    ids = np.arange(N) + 5
+    hidden = rng.normal(0, 1, (Q, N))
+    mk = lambda s: (hidden + s * rng.normal(0, 1, (Q, N))).astype(np.float32)
+    systems = {"a": _rank_scores(plane_of(ops, np.maximum(mk(1.0), 0.0)), ids, None), "b": _rank_scores(plane_of(ops, mk(0.5)), ids, None)}
+    w = {"a": 0.4, "b": 0.6}
+    full = Aggregator.fuse_device(systems, method, norm, w, {})
+    head = Aggregator.fuse_device(systems, method, norm, w, {}, topk=k)
+    assert Aggregator.last_topk_path == "select"
+    assert head.order.shape == (Q, k) and head.scores.dtype == full.scores.dtype == torch.float64
+    np.testing.assert_array_equal(head.order.cpu().numpy(), full.order.cpu().numpy()[:, :k])
+    np.testing.assert_array_equal(head.scores.cpu().numpy(), full.scores.cpu().numpy()[:, :k])
+    np.testing.assert_array_equal(head.lens.cpu().numpy(), np.full(Q, k))
+    assert head.predictions(1000) == full.predictions(1000)
+    # two systems that rank every document alike below the head: thousands of equal fused scores at the k-th place -> no selection
+    flat = np.zeros((Q, N), dtype=np.float32)
+    flat[:, :50] = np.arange(50, 0, -1)
+    tied = {"a": _rank_scores(plane_of(ops, flat), ids, None), "b": _rank_scores(plane_of(ops, flat), ids, None)}
+    if method == "nsf":      # raw sums: 27,892 documents tie at 0.0
+        full = Aggregator.fuse_device(tied, method, norm, w, {})
+        head = Aggregator.fuse_device(tied, method, norm, w, {}, topk=k)
+        assert Aggregator.last_topk_path == "sort"
+        np.testing.assert_array_equal(head.order.cpu().numpy(), full.order.cpu().numpy()[:, :k])
+        np.testing.assert_array_equal(head.scores.cpu().numpy(), full.scores.cpu().numpy()[:, :k])
+
+
+# ---- VERDICT r3 item 5: the acceptance metric under the mixed-precision ColBERT encoder ---------------------------------------------------
+def test_colbert_mixed_precision_leaves_fused_recall_where_it_was(ops):
+    """config-4-shaped pipeline (BM25-like, DPR-like, SPLADE-like planes + REAL ColBERT MaxSim from a CamemBERT-base-shaped random-init
+    encoder over a synthetic corpus whose gold documents share the query's tokens) with ColbertEncoder(amp=True) -- colbert-ai's autocast,
+    the GPU default -- and with amp=False: the MaxSim rankings' top-500 overlap, and recall@10 / recall@500 of the nsf min-max fused lists
+    (north_star's acceptance metric).  Token vectors move by a few float16 steps, scores by ~1e-4 relative: the fused recall must not."""
+    from fusion_amd import encoders
+    from fusion_amd.retrievers.hybrid import Aggregator, _rank_scores, run_evaluation
+    rng = np.random.default_rng(17)
+    N, Q, Lq, Ld = 3000, 96, 64, 96
+    enc = encoders.random_init("colbert", device="cuda", size="base", seed=5)
+    V = 32000
+    doc_ids = rng.integers(7, V - 1, size=(N, Ld))
+    lens = rng.integers(24, Ld + 1, N)
+    gold = [rng.choice(N, size=int(rng.integers(1, 4)), replace=False).tolist() for _ in range(Q)]
+    q_ids = rng.integers(7, V - 1, size=(Q, Lq))
+    for q, gl in enumerate(gold):                                       # a query repeats tokens of its gold documents
+        for j, g in enumerate(gl):
+            take = rng.choice(int(lens[g]), size=12, replace=False)
+            q_ids[q, 2 + 12 * j: 14 + 12 * j] = doc_ids[g, take]
+    dids, qids = torch.from_numpy(doc_ids).cuda(), torch.from_numpy(q_ids).cuda()
+    ids = np.arange(N) + 1
+    hidden = torch.zeros((Q, N), device="cuda")
+    for q, gl in enumerate(gold):
+        hidden[q, gl] = 3.0
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    noisy = lambda s: hidden + s * torch.randn((Q, N), generator=gen, device="cuda")
+    others = {"bm25": torch.clamp(noisy(1.5), min=0.0), "dpr": torch.tanh(0.3 * noisy(1.2)), "splade": torch.log1p(torch.relu(noisy(1.8)))}
+    labels = [[int(ids[g]) for g in gl] for gl in gold]
+
+    def plane(t):
+        p = ops.alloc_plane(Q, N, torch.float32, "cuda"); p.copy_(t); return p
+    fused, maxsim = {}, {}
+    for amp in (True, False):
+        enc.amp = amp
+        Dtok, Doff = enc.encode_doc_ids(dids, lens)
+        Qtok = enc.encode_query_ids(qids)
+        S = ops.maxsim(Qtok, Dtok, Doff, max_doc_len=Ld)
+        maxsim[amp] = S
+        systems = {n: _rank_scores(plane(t), ids, None) for n, t in others.items()}
+        systems["colbert"] = _rank_scores(S, ids, None)
+        f = Aggregator.fuse_device(systems, "nsf", "min-max", {n: 0.25 for n in systems}, {})
+        fused[amp] = run_evaluation(f.predictions(1000), labels, print2console=False)
+    o16 = torch.argsort(maxsim[True], dim=1, descending=True, stable=True)[:, :500].cpu().numpy()
+    o32 = torch.argsort(maxsim[False], dim=1, descending=True, stable=True)[:, :500].cpu().numpy()
+    overlap = float(np.mean([len(set(a.tolist()) & set(b.tolist())) / 500 for a, b in zip(o16, o32)]))
+    rel = float(((maxsim[True] - maxsim[False]).abs() / maxsim[False].abs().clamp_min(1e-6)).max())
+    solo = {amp: run_evaluation(torch.argsort(maxsim[amp], dim=1, descending=True, stable=True)[:, :1000].add(1).cpu().numpy().tolist(), labels,
+                                print2console=False) for amp in (True, False)}
+    print(f"ColBERT amp vs fp32: MaxSim rel diff {rel:.1e}, top-500 overlap {overlap:.4f}; MaxSim-only recall@10 {solo[True]['recall@10']:.4f} / "
+          f"{solo[False]['recall@10']:.4f}; fused recall@10 {fused[True]['recall@10']:.4f} / {fused[False]['recall@10']:.4f}, "
+          f"recall@500 {fused[True]['recall@500']:.4f} / {fused[False]['recall@500']:.4f}")
+    assert rel <= 2e-3 and overlap >= 0.97
+    assert solo[False]["recall@10"] > 0.3                                # the synthetic task is one the encoder can do at all
+    for m in ("recall@10", "recall@500", "recall@100"):
+        assert abs(fused[True][m] - fused[False][m]) <= 1.0 / Q, (m, fused[True][m], fused[False][m])   # at most one (query, document) of the batch moves
+    assert fused[True]["recall@500"] == fused[False]["recall@500"]
