@@ -347,6 +347,29 @@ __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs
             // (vmcnt counts in order: waiting for the DMA means waiting for everything older).  That one is issued here, BEHIND the
             // DMA, and the swap waits with vmcnt(ILV): the DMA and every older request have landed, the ILV youngest may still fly
             // (on the very first step the wait may return with up to ILV DMA pieces in flight: it then uses vmcnt(0)).
+            // which of the item's documents this system lists: wave-uniform bases + clamped per-thread offsets (no branches; what is
+            // read past the row end is masked by tail_ok).  Requested BEFORE the table swap: the words arrive under its barrier and DMA
+            mask_t ok = tail_ok;
+            if (a.vbits[s]) {
+                const uint32_t* __restrict__ wb = a.vbits[s] + (size_t)q * a.ldb + ((c * BT_COLS) >> 5);
+                const int wlast = (min(a.N - c * BT_COLS, BT_COLS) - 1) >> 5, sh = toff & 31, wo = my_off() >> 5;
+                mask_t m = 0;
+#pragma unroll
+                for (int i = 0; i < BT_E4; ++i) m |= (mask_t)((wb[min(wo + (4 * BT_T / 32) * i, wlast)] >> sh) & 0xfu) << (4 * i);
+                ok &= m;
+            } else if (a.ranks[s]) {
+                const int32_t* __restrict__ rk = a.ranks[s] + rowoff + c * BT_COLS;
+                const int lim = (min(a.N - c * BT_COLS, BT_COLS) - 1) & ~3;
+                mask_t m = 0;
+#pragma unroll
+                for (int i = 0; i < BT_E4; ++i) {
+                    const int4 r = *reinterpret_cast<const int4*>(rk + min(my_off() + 4 * BT_T * i, lim));
+                    uint32_t nib = (r.x >= 0 ? 1u : 0u) | (r.y >= 0 ? 2u : 0u) | (r.z >= 0 ? 4u : 0u) | (r.w >= 0 ? 8u : 0u);
+                    asm volatile("" : "+v"(nib));   // one rank quad at a time: all of them in flight at once would be the kernel's register peak
+                    m |= (mask_t)nib << (4 * i);
+                }
+                ok &= m;
+            }
             const bool swap = cur != s;
             if (swap) {
                 __syncthreads();                       // every wave is done with the table that is there
@@ -372,29 +395,6 @@ __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs
             else if (it + gridDim.x < items) {
                 nxt = a.planes[0] + (size_t)q2 * a.ld + c2 * BT_COLS;
                 nlim = (min(a.N - c2 * BT_COLS, BT_COLS) - 1) & ~3;
-            }
-            // which of the item's documents this system lists: wave-uniform bases + clamped per-thread offsets (no branches; what is
-            // read past the row end is masked by tail_ok)
-            mask_t ok = tail_ok;
-            if (a.vbits[s]) {
-                const uint32_t* __restrict__ wb = a.vbits[s] + (size_t)q * a.ldb + ((c * BT_COLS) >> 5);
-                const int wlast = (min(a.N - c * BT_COLS, BT_COLS) - 1) >> 5, sh = toff & 31, wo = my_off() >> 5;
-                mask_t m = 0;
-#pragma unroll
-                for (int i = 0; i < BT_E4; ++i) m |= (mask_t)((wb[min(wo + (4 * BT_T / 32) * i, wlast)] >> sh) & 0xfu) << (4 * i);
-                ok &= m;
-            } else if (a.ranks[s]) {
-                const int32_t* __restrict__ rk = a.ranks[s] + rowoff + c * BT_COLS;
-                const int lim = (min(a.N - c * BT_COLS, BT_COLS) - 1) & ~3;
-                mask_t m = 0;
-#pragma unroll
-                for (int i = 0; i < BT_E4; ++i) {
-                    const int4 r = *reinterpret_cast<const int4*>(rk + min(my_off() + 4 * BT_T * i, lim));
-                    uint32_t nib = (r.x >= 0 ? 1u : 0u) | (r.y >= 0 ? 2u : 0u) | (r.z >= 0 ? 4u : 0u) | (r.w >= 0 ? 8u : 0u);
-                    asm volatile("" : "+v"(nib));   // one rank quad at a time: all of them in flight at once would be the kernel's register peak
-                    m |= (mask_t)nib << (4 * i);
-                }
-                ok &= m;
             }
             const float lo_v = t.hdr[s][0], inv_w = t.hdr[s][1];
             const int steps = reinterpret_cast<const int*>(t.hdr[s])[2];

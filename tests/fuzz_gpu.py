@@ -575,6 +575,51 @@ def case_sparse(rng):
     return f"sparse Q={Q} N={N} V={V} nnz={idx.nnz}"
 
 
+def case_tables(rng):
+    """percentile-rank / NCE against long quantile tables (csrc/tables.hip: one system's table LDS-resident at a time) == fz_fuse_nsf_f32's
+    search bit for bit, and the oracle's O(N P) scan where that is affordable; tables of every awkward shape."""
+    S, Q = int(rng.integers(1, 5)), int(rng.integers(1, 40))
+    N = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 33000)]))
+    P = int(rng.choice([rng.integers(1500, 4000), rng.integers(4000, 20000), rng.integers(20000, 38000)]))
+    kind = rng.choice(["quantile", "quantile", "dups", "const", "tiny", "huge", "two"])
+    partial = rng.random() < 0.5
+    planes, ranks, orders, lens = systems(rng, S, Q, N, partial)
+    tabs = []
+    for s in range(S):
+        if kind == "quantile":
+            t = np.quantile(planes[s].astype(np.float64), np.linspace(0, 1, P)).astype(np.float32)
+        elif kind == "dups":
+            t = np.sort(rng.integers(0, max(2, P // int(rng.integers(2, 400))), P)).astype(np.float32) * np.float32(0.125) - np.float32(3.0)
+        elif kind == "const":
+            t = np.full(P, np.float32(rng.normal()), dtype=np.float32)
+        elif kind == "tiny":
+            t = np.sort(np.float32(1.0) + rng.integers(0, 8, P).astype(np.float32) * np.float32(2.0 ** -23))
+        elif kind == "huge":
+            t = np.sort(np.float32(3.0e7) + rng.integers(0, 64, P).astype(np.float32) * np.float32(2.0))
+        else:   # two clusters far apart: one bucket holds half the table
+            t = np.sort(np.concatenate([rng.normal(-1e4, 1e-3, P // 2), rng.normal(1e4, 1e-3, P - P // 2)])).astype(np.float32)
+        tabs.append(np.ascontiguousarray(t))
+        k = rng.integers(0, P, max(1, N // 5))
+        planes[s][int(rng.integers(0, Q)), rng.integers(0, N, len(k))] = t[k]     # scores that ARE table entries
+    what = str(rng.choice(["percentile-rank", "normal-curve-equivalent"]))
+    w = rng.dirichlet(np.ones(S))
+    rk = None if not partial else [plane(r) for r in ranks]
+    pl, td = [plane(p) for p in planes], [dev(t) for t in tabs]
+    got = ops.fuse_nsf(pl, rk, w, what, td)
+    path = ops.last_tables_path
+    old = ops.fuse_nsf(pl, rk, w, what, td, tables=False)
+    assert torch.equal(got.view(torch.int32), old.view(torch.int32)), (what, kind, path)
+    if Q * N * P * S <= 2e9:
+        exp = oracle.fuse_nsf(planes, ranks if partial else None, w, what, tabs)
+        g = got.cpu().numpy()
+        fin = np.isfinite(exp)
+        np.testing.assert_array_equal(np.isfinite(g), fin)
+        np.testing.assert_array_equal(g[~fin], exp[~fin])
+        tol = 0.0 if what == "percentile-rank" else NSF_TOL[what] * max(1.0, np.max(np.abs(exp[fin]), initial=0.0))
+        assert np.max(np.abs(g[fin] - exp[fin]), initial=0.0) <= tol
+    return f"tables {what} {kind} S={S} Q={Q} N={N} P={P} partial={partial} path={path}"
+
+
 def case_empty(rng):
     """Zero-sized batches: every op returns an empty (or all-default) result without touching a pointer."""
     n = int(rng.integers(1, 500))
@@ -597,7 +642,7 @@ def case_empty(rng):
 
 
 CASES = [case_encoder, case_lists, case_empty, case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
-         case_topk_stream, case_segments, case_fused_search, case_sort_stats, case_select, case_splade_head, case_fuse_ranked, case_maxsim, case_f16_kernels, case_encoder_amp, case_rerun, case_rerun, case_sparse]
+         case_topk_stream, case_segments, case_fused_search, case_sort_stats, case_select, case_splade_head, case_fuse_ranked, case_maxsim, case_f16_kernels, case_encoder_amp, case_rerun, case_rerun, case_sparse, case_tables, case_tables]
 
 
 def main():

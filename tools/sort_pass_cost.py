@@ -29,4 +29,4 @@ if __name__ == "__main__":
     for p in libs:
         _lib._lib = None
         _lib.LIB_PATH = os.path.abspath(p)
-        run(os.path.basename(p), only64="abl" in p)
+        run(os.path.basename(p), only64="only64" in p)
