@@ -4,24 +4,27 @@
 // PLAID approximates is   s(q,d) = sum_{i<Lq} max_{t in d} <Q[q][i], D[t]>    on 128-d
 // L2-normalised token vectors (run_colbert.sh:26-27), query padded to 64 tokens (hybrid.py:129).
 //
-// Mapping: v_mfma_f32_32x32x16_f16 with A = 32 DOCUMENT tokens (rows), B = 32 QUERY tokens (cols), K = dim.
-// The C layout puts the query token on the lane (col = lane&31) and the 32 document tokens in the 16
-// accumulator registers x 2 lane halves, so
-//     max over document tokens = in-lane max of 16 registers (+ one exchange between lane l and l^32),
-//     sum over query tokens    = a wave reduction over 32 lanes, once per (query, document).
-// A workgroup = 8 waves; every wave keeps the B fragments of 4 query blocks (2 queries x 64 tokens)
-// in 128 VGPRs for the whole kernel, and all 8 waves consume the same document tile, which goes
-// global -> LDS once per workgroup by LDS-DMA (16-B chunks XOR-swizzled by row so that ds_read_b128 of
-// 32 rows is conflict-free), a group of four tiles ahead.  Tiles are aligned to document starts (rows past the end are masked
-// to -inf).  Workgroups that share a 32-document range run back-to-back on one XCD, so the range (about
-// 2.4 MB) is fetched from HBM once and served from that XCD's L2 to the other query groups.
+// Mapping: v_mfma_f32_16x16x32_f16 with A = 16 DOCUMENT tokens (rows) x 32 dims, B = 32 dims x 16 QUERY tokens (cols), four
+// k-steps for the 128 dims.  The C layout puts the query token on the lane (col = lane & 15) and the 16 document tokens in the
+// 4 accumulator registers x 4 lane groups (row = 4 (lane >> 4) + r), so
+//     max over document tokens = in-lane max of 4 registers per row block (v_max3), the four lane groups combined ONCE per
+//                                document by permlane32 / permlane16 swaps that transpose 8 partial-max registers into 2,
+//     sum over query tokens    = one 16-lane DPP sum per register + two swap-and-add steps, once per (query, document).
+// A workgroup = 8 waves; every wave keeps the B fragments of 8 column blocks (2 queries x 64 tokens) in 128 VGPRs for the
+// whole kernel, and all 8 waves consume the same 32-token document tile (two row blocks whose MFMA chains interleave), which
+// goes global -> LDS once per workgroup by LDS-DMA (16-B chunks XOR-swizzled by row so that ds_read_b128 of 16 rows is
+// conflict-free), a group of four tiles ahead in an 8-slot ring, one barrier per group.  Tiles are aligned to document starts
+// (rows past the end are masked to -inf); a document's last tile with at most 16 tokens left runs its first row block only.
+// Workgroups that share a 32-document range run back-to-back on one XCD, so the range (about 2.4 MB) is fetched from HBM once
+// and served from that XCD's L2 to the other query groups.
 //
-// Where it stands (profiles/r02_pmc_maxsim.json, Q = 195): 9.1e8 MFMAs per launch (0.89 useful: query-block and tile
-// padding), SQ_VALU_MFMA_BUSY_CYCLES = 64 % of the SIMD cycles at an effective clock of 1.99 GHz (GRBM_GUI_ACTIVE / 8 /
-// time) -- 1.12-1.21 PFLOP/s = 45-48 % of the 2.5 PF nominal peak, 90-97 % of the 1,247 TFLOP/s MI355X_MICROARCH.md
-// measures for a dense bf16 MFMA loop on random data (same busy fraction, same clock: the chip holds its clock down under
-// matrix load).  Measured and without effect on the time: barrier every 2 / 4 / 8 tiles, register staging vs LDS-DMA,
-// A fragments refilled in place under the last MFMA chain (slower: 0.39), waves 4-7 staggered by s_sleep 4..24.
+// Where it stands (profiles/r03_pmc_maxsim.json, r03_maxsim_ab.jsonl): 1.42-1.46 PFLOP/s of exact
+// sum-of-lengths FLOPs at Q = 1024 = 0.57-0.58 of the 2.5 PF nominal peak, matrix pipe busy 62 % of the SIMD cycles, 1.3 other
+// vector instructions per 16-cycle MFMA, LDS conflicts 0.06 % -- what MI355X_MICROARCH.md measures for an LDS-fed 16x16x32 loop
+// on random data (1.40-1.43 PF: the chip holds its clock down under matrix load).  What alignment to document starts costs: with
+// the LLeQA-shaped lengths of the bench 2.5 % of the row-block slots are padding (7.5 of ~300 rows per document), so tiles
+// packed across document boundaries could add at most that much -- 1.43 -> <= 1.47 PF -- for a piece-wise epilogue in every
+// tile; not built (round 4, DESIGN.md 'Tried').  The round-2 32x32x16 form is kept as tools/ablate/maxsim_32x32x16.hip.
 #include <hip/hip_fp16.h>
 
 #include <type_traits>

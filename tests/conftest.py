@@ -13,8 +13,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the HIP library is built in-tree and git-ignored: a fresh clone builds it here (hipcc cross-compiles without a GPU)
-    from fusion_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
+    from fusion_amd import _lib, _pyhost
+    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(_pyhost.LIB_PATH):
         _lib.build()
 
 

@@ -18,6 +18,9 @@ VARIANTS = {
     # no HBM reads of scores after the first step (lookups + swaps + stores only)
     "nostream": [("        return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(base + min(my_off() + 4 * BT_T * i, lim)));   // streamed once",
                   "        f4v r = {1.f, 2.f, 3.f, 4.f}; asm volatile(\"\" : \"+v\"(r)); return r;")],
+    # no searches at all: streaming, swaps and accumulation only
+    "nolookup": [("                bt_lookup<W, STEPS>(tab, lut, lo_v, inv_w, top, steps, last_pair, x, best);",
+                  "                for (int e = 0; e < W; ++e) best[e] = (int)x[e] & 1023;")],
     # no table swaps (the first system's table stays): what the LDS-DMA phases cost
     "noswap": [("            const bool swap = cur != s;", "            const bool swap = cur < 0;")],
 }

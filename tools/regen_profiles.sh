@@ -13,7 +13,10 @@ step "colbert amp"     200 python tools/bench_colbert_amp.py 1024 > $O/colbert_a
 step "colbert amp 195" 200 python tools/bench_colbert_amp.py 195 >> $O/colbert_amp.jsonl 2>> $O/colbert_amp.err
 step "profile bench"   600 bash tools/profile_bench.sh > $O/profile_bench.log 2>&1
 step "pmc sort"        300 bash tools/pmc_sort.sh > $O/pmc_sort.log 2>&1
+step "pmc tables"      300 bash tools/pmc_tables.sh > $O/pmc_tables.log 2>&1
+step "tables a/b"      300 python tools/run_tables_ab.py 2 > $O/tables_ab.jsonl 2>&1
+step "boundary"        300 python tools/bench_boundary.py 32 > $O/boundary.json 2>&1
 cp gpurun_out/hbm_traffic.json $O/ 2>/dev/null
-cp gpurun_out/pmc_sort.json $O/ 2>/dev/null
+cp gpurun_out/pmc_sort.json gpurun_out/pmc_tables.json $O/ 2>/dev/null
 find gpurun_out/prof_stats -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
 ls -la $O >&2
