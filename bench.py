@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32, dense
 MFMA_F16_PEAK_TF = 2500.0      # v_mfma_f32_32x32x16_f16, dense
 METRIC = "queries/sec end-to-end (encode+score+fuse), LLeQA test; recall@500 parity"
-TRAFFIC_PROFILES = ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
+TRAFFIC_PROFILES = ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
 # the stages of the step that ARE the path's kernels (scoring, ranking, fusion behind the C ABI).  The bench line's
 # `roofline` names the one of THESE that takes the most time per step; the encoder's kernels (HIP and vendor) stay in `roofline_all`.
 PATH_STAGES = ("dpr_score", "dpr_rank", "bm25_score", "bm25_rank", "fuse_rrf", "final_order")
