@@ -577,13 +577,13 @@ __device__ __forceinline__ int nearest_entry_lut(const TableSys& y, float s) {
     if (y.use_lut) {
         const float t = (s - y.lo_v) * y.inv_w;
         if (t < 0.f) return 0;                       // below the first entry: it is the nearest
-        if (t < (float)LUT_B) {
-            const int b = (int)t;
-            lo = (int)y.lut[b > 0 ? b - 1 : 0] - 1;
-            hi = (int)y.lut[b + 2 < LUT_B ? b + 2 : LUT_B];
-            if (lo >= 0 && !(y.tab[lo] <= s)) lo = -1;   // rounding broke the bracket: widen (never seen, kept for exactness)
-            if (hi < P && !(y.tab[hi] > s)) hi = P;
-        } else lo = P - 1;                                // at or above the last entry
+        // t >= LUT_B does NOT mean "at or above the last entry": a score a rounding below the table's maximum lands there too, with other
+        // entries between it and the maximum (round 4, found by the soak on a table of two far-apart clusters) -- it takes the last bucket's bracket
+        const int b = t < (float)LUT_B ? (int)t : LUT_B - 1;
+        lo = (int)y.lut[b > 0 ? b - 1 : 0] - 1;
+        hi = (int)y.lut[b + 2 < LUT_B ? b + 2 : LUT_B];
+        if (lo >= 0 && !(y.tab[lo] <= s)) lo = -1;   // rounding broke the bracket: widen (never seen, kept for exactness)
+        if (hi < P && !(y.tab[hi] > s)) hi = P;
     }
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;

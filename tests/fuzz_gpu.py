@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from fusion_amd import ops
 from oracle import oracle
+from helpers import quantile_table
 
 NSF_TOL = {"min-max": 0.0, "z-score": 2e-6, "arctan": 1e-6, "percentile-rank": 0.0, "normal-curve-equivalent": 1e-4}
 
@@ -587,7 +588,7 @@ def case_tables(rng):
     tabs = []
     for s in range(S):
         if kind == "quantile":
-            t = np.quantile(planes[s].astype(np.float64), np.linspace(0, 1, P)).astype(np.float32)
+            t = quantile_table(planes[s], P).astype(np.float32)
         elif kind == "dups":
             t = np.sort(rng.integers(0, max(2, P // int(rng.integers(2, 400))), P)).astype(np.float32) * np.float32(0.125) - np.float32(3.0)
         elif kind == "const":

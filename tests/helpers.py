@@ -52,3 +52,13 @@ def integration_snippet(root):
     assert len(code) == 1, "INTEGRATION.md must hold exactly one binding snippet that defines rrf()"
     from fusion_amd import _lib
     return code[0].replace('"libfusion_hip.so"', repr(_lib.LIB_PATH))
+
+
+def quantile_table(pool, P):
+    """np.quantile(pool, np.linspace(0, 1, P)) (linear interpolation) by one sort: numpy's own takes ~40 s for 38,000 quantiles
+    (one partition step per quantile)."""
+    s = np.sort(np.asarray(pool, dtype=np.float64).ravel())
+    pos = np.linspace(0.0, len(s) - 1.0, P)
+    lo = np.floor(pos).astype(np.int64)
+    hi = np.minimum(lo + 1, len(s) - 1)
+    return s[lo] + (s[hi] - s[lo]) * (pos - lo)

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN
-from helpers import load_lists
+from helpers import load_lists, quantile_table
 
 pytestmark = pytest.mark.gpu
 
@@ -100,7 +100,7 @@ def _tables(rng, S, P, kind="quantile"):
             pool = [np.maximum(0.0, rng.gamma(0.5, 4.0, 4 * P) - 2.0), rng.uniform(-0.2, 0.9, 4 * P), rng.normal(20.0, 4.0, 4 * P),
                     np.log1p(np.maximum(rng.normal(0, 1, 4 * P), 0))][s % 4]
             pool = pool[pool != 0.0]
-            t = np.quantile(pool, np.linspace(0, 1, P)).astype(np.float32)
+            t = quantile_table(pool, P).astype(np.float32)
         elif kind == "dups":     # long runs of equal quantiles (a discrete-valued system)
             t = np.sort(rng.integers(0, max(2, P // 50), P)).astype(np.float32) * np.float32(0.125)
         elif kind == "const":
@@ -369,3 +369,28 @@ def test_colbert_mixed_precision_leaves_fused_recall_where_it_was(ops):
     for m in ("recall@10", "recall@500", "recall@100"):
         assert abs(fused[True][m] - fused[False][m]) <= 1.0 / Q, (m, fused[True][m], fused[False][m])   # at most one (query, document) of the batch moves
     assert fused[True]["recall@500"] == fused[False]["recall@500"]
+
+
+@pytest.mark.parametrize("P", [2898, 27943])
+def test_scores_a_rounding_below_the_table_maximum(ops, oracle, P):
+    """Two far-apart clusters of quantiles (float32 spacing ~1e-3 at 1e4: long runs of equal entries) and scores that ARE entries of the
+    upper cluster, a rounding below the table's maximum: the equi-width bucket of such a score rounds up to the bucket count.  Found by the
+    soak in round 4 in the round-3 kernel (all tables in LDS), whose exact search took that for 'at or above the last entry' and skipped the
+    entries in between; both table sizes -- both kernels -- against the oracle's first-argmin scan."""
+    rng = np.random.default_rng(P)
+    tabs = [np.sort(np.concatenate([rng.normal(-1e4, 1e-3, P // 2), rng.normal(1e4, 1e-3, P - P // 2)])).astype(np.float32) for _ in range(2)]
+    Q, N = 3, 4000
+    xs = []
+    for t in tabs:
+        x = t[rng.integers(P - 40, P, (Q, N))].copy()                  # entries of the topmost 40: most of them below the maximum
+        x[:, ::7] = t[rng.integers(0, P, (Q, len(range(0, N, 7))))]
+        xs.append(np.ascontiguousarray(x))
+    for norm in NORMS:
+        got = ops.fuse_nsf([plane_of(ops, x) for x in xs], None, [0.4, 0.6], norm, [dev(t) for t in tabs]).cpu().numpy()
+        assert ops.last_tables_path == ("lds-all" if P < 5000 else "lds-swap")
+        exp = oracle.fuse_nsf(xs, None, [0.4, 0.6], norm, tabs)
+        if norm == "percentile-rank":
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+        else:
+            fin = np.isfinite(exp)
+            assert np.array_equal(np.isfinite(got), fin) and np.max(np.abs(got[fin] - exp[fin])) <= 1e-4
