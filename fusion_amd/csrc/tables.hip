@@ -53,6 +53,7 @@ constexpr int BT_PIECE = 256;               // floats per LDS-DMA wave instructi
 constexpr int BT_LEAD = 4;                  // -inf entries in front of the table (index -1, -2 of the search; keeps the table 16-B aligned)
 constexpr int BT_TAIL = 40;                 // +inf entries behind it at least: the unrolled search (<= 4 probes) reaches 15 pairs past its start, unclamped
 constexpr int BT_MAX_UNROLLED = 4;
+constexpr int BT_R = 1;                    // items per table residency (accumulator sets per thread); 2 needs the 256 VGPRs of a 512-thread workgroup
 typedef std::conditional<(BT_E4 <= 8), uint32_t, uint64_t>::type mask_t;   // one bit per column of a thread
 constexpr size_t BT_LDS_BUDGET = 160 * 1024 - 256;   // the CU's LDS minus the kernel's static variables
 constexpr size_t BT_HDR_BYTES = 256;
@@ -281,7 +282,7 @@ __device__ __forceinline__ float bt_quot(int k, float Pf, float rP) {
 // system's table comes into LDS if another one is there (barrier, LDS-DMA, barrier), the 56 scores per thread are searched ILV
 // float4s at a time -- each group's registers then take the NEXT step's scores, which cross HBM under this step's searches --
 // their values weighted and added into the item's accumulators; after the item's last system the fused row leaves.
-template <bool NCE, int ILV>
+template <bool NCE, int ILV, int R>
 __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs t, float* __restrict__ fused) {
     extern __shared__ __attribute__((aligned(16))) float bt_lds[];
     float* tabr = bt_lds;                                                   // [tab_cap]: BT_LEAD sentinels, the table, +inf
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs
     const int items = a.Q * chunks;   // (< 2^31: checked by the launcher)
     typedef float f4v __attribute__((ext_vector_type(4)));
     static_assert(BT_E4 % ILV == 0, "groups of ILV float4");
+    static_assert(R == 1 || R == 2, "one or two items per table residency");
     constexpr int W = 4 * ILV;
 
     // global -> LDS, one 1-KiB piece per wave instruction (LDS destination = wave-uniform base + lane * 16)
@@ -320,163 +322,192 @@ __global__ __launch_bounds__(BT_T) void fuse_nsf_bigtab_kernel(NsfArgs a, BtArgs
     const float* nxt = a.planes[0];   // the next step's row chunk (wave-uniform) and its last float4
     int nlim = 0;
     // items it = blockIdx.x, + gridDim.x, ...: (row q, chunk c) advanced by hand -- a division per item would be done on the vector ALU,
-    // in registers that live across the whole kernel
+    // in registers that live across the whole kernel.  A workgroup takes R of its items per ROUND and runs them system by system --
+    // (item 0, s), (item 1, s), (item 0, s + 1) ... -- so that a table swap serves R items; R accumulator sets live in registers.
     int q = (int)blockIdx.x / chunks, c = (int)blockIdx.x - q * chunks;
     const int dq = (int)gridDim.x / chunks, dc = (int)gridDim.x - dq * chunks;
+    auto advance = [&](int& qq, int& cc) { qq += dq; cc += dc; if (cc >= chunks) { cc -= chunks; ++qq; } };
+    auto chunk_lim = [&](int cc) { return (min(a.N - cc * BT_COLS, BT_COLS) - 1) & ~3; };   // the chunk's last float4
     bool first = true;
-    if ((int)blockIdx.x < items) {   // the first step's scores
-        load_row(v, a.planes[0] + (size_t)q * a.ld + c * BT_COLS, (min(a.N - c * BT_COLS, BT_COLS) - 1) & ~3);
-    }
-    for (int it = blockIdx.x; it < items; it += gridDim.x) {
-        int q2 = q + dq, c2 = c + dc;   // the workgroup's next item
-        if (c2 >= chunks) { c2 -= chunks; ++q2; }
-        const size_t rowoff = (size_t)q * a.ld;
-        const int col0 = c * BT_COLS + my_off();
-        float acc[BT_E4][4];
-        mask_t present = 0, tail_ok = 0;   // tail_ok: the thread's columns that lie inside the row
+    if ((int)blockIdx.x < items) load_row(v, a.planes[0] + (size_t)q * a.ld + c * BT_COLS, chunk_lim(c));   // the first step's scores
+    for (int it = blockIdx.x; it < items; it += R * gridDim.x) {
+        int qr[R], cr[R];
+        bool live[R];
+        qr[0] = q; cr[0] = c; live[0] = true;
 #pragma unroll
-        for (int i = 0; i < BT_E4; ++i) {
-            const int rem = a.N - (col0 + 4 * BT_T * i);
-            tail_ok |= (mask_t)(rem >= 4 ? 0xfu : (rem > 0 ? (1u << rem) - 1u : 0u)) << (4 * i);
+        for (int r = 1; r < R; ++r) { qr[r] = qr[r - 1]; cr[r] = cr[r - 1]; advance(qr[r], cr[r]); live[r] = it + r * (int)gridDim.x < items; }
+        int qn = qr[R - 1], cn = cr[R - 1];   // the next round's first item
+        advance(qn, cn);
+        const bool more = it + R * (int)gridDim.x < items;
+        float acc[R][BT_E4][4];
+        mask_t present[R], tail_ok[R];   // tail_ok: the thread's columns that lie inside the row
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+        for (int r = 0; r < R; ++r) {
+            present[r] = 0; tail_ok[r] = 0;
+            const int col0 = cr[r] * BT_COLS + my_off();
+#pragma unroll
+            for (int i = 0; i < BT_E4; ++i) {
+                const int rem = a.N - (col0 + 4 * BT_T * i);
+                tail_ok[r] |= (mask_t)(rem >= 4 ? 0xfu : (rem > 0 ? (1u << rem) - 1u : 0u)) << (4 * i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[r][i][e] = 0.f;
+            }
         }
         for (int s = 0; s < a.S; ++s) {
-            // Requests to HBM run one step ahead: a group's registers take the same group of the NEXT step right after it has been
-            // searched -- except the step's LAST group, whose request would be the youngest when the table swap waits for its LDS-DMA
-            // (vmcnt counts in order: waiting for the DMA means waiting for everything older).  That one is issued here, BEHIND the
-            // DMA, and the swap waits with vmcnt(ILV): the DMA and every older request have landed, the ILV youngest may still fly
-            // (on the very first step the wait may return with up to ILV DMA pieces in flight: it then uses vmcnt(0)).
-            // which of the item's documents this system lists: wave-uniform bases + clamped per-thread offsets (no branches; what is
-            // read past the row end is masked by tail_ok).  Requested BEFORE the table swap: the words arrive under its barrier and DMA
-            mask_t ok = tail_ok;
-            if (a.vbits[s]) {
-                const uint32_t* __restrict__ wb = a.vbits[s] + (size_t)q * a.ldb + ((c * BT_COLS) >> 5);
-                const int wlast = (min(a.N - c * BT_COLS, BT_COLS) - 1) >> 5, sh = toff & 31, wo = my_off() >> 5;
-                mask_t m = 0;
-#pragma unroll
-                for (int i = 0; i < BT_E4; ++i) m |= (mask_t)((wb[min(wo + (4 * BT_T / 32) * i, wlast)] >> sh) & 0xfu) << (4 * i);
-                ok &= m;
-            } else if (a.ranks[s]) {
-                const int32_t* __restrict__ rk = a.ranks[s] + rowoff + c * BT_COLS;
-                const int lim = (min(a.N - c * BT_COLS, BT_COLS) - 1) & ~3;
-                mask_t m = 0;
-#pragma unroll
-                for (int i = 0; i < BT_E4; ++i) {
-                    const int4 r = *reinterpret_cast<const int4*>(rk + min(my_off() + 4 * BT_T * i, lim));
-                    uint32_t nib = (r.x >= 0 ? 1u : 0u) | (r.y >= 0 ? 2u : 0u) | (r.z >= 0 ? 4u : 0u) | (r.w >= 0 ? 8u : 0u);
-                    asm volatile("" : "+v"(nib));   // one rank quad at a time: all of them in flight at once would be the kernel's register peak
-                    m |= (mask_t)nib << (4 * i);
-                }
-                ok &= m;
-            }
-            const bool swap = cur != s;
-            if (swap) {
-                __syncthreads();                       // every wave is done with the table that is there
-                dma(t.tab[s], tabr, t.Ppad[s]);
-                dma(t.lut[s], lutf, t.lut_floats);
-                if (NCE && t.val_in_lds) dma(t.val[s], valr, t.Ppad[s]);
-                cur = s;
-            }
-            if (!first) {   // (not the very first step, whose scores the prologue requested)
-#pragma unroll
-                for (int i = BT_E4 - ILV; i < BT_E4; ++i) v[i] = load_one(nxt, i, nlim);
-            }
-            if (swap) {
-                if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (ILV == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // this wave's pieces have landed ...
-                __syncthreads();                                                                                                    // ... and everybody else's
-            }
-            first = false;
-            // the next step: the next system of this item, or the first system of this workgroup's next item; after the very last step
-            // the requests re-read its own row (unconditional requests: no phi copies of the score registers, no second wait form)
-            if (s + 1 < a.S) { nxt = a.planes[s + 1] + rowoff + c * BT_COLS; nlim = (min(a.N - c * BT_COLS, BT_COLS) - 1) & ~3; }
-            else if (it + gridDim.x < items) {
-                nxt = a.planes[0] + (size_t)q2 * a.ld + c2 * BT_COLS;
-                nlim = (min(a.N - c2 * BT_COLS, BT_COLS) - 1) & ~3;
-            }
             const float lo_v = t.hdr[s][0], inv_w = t.hdr[s][1];
             const int steps = reinterpret_cast<const int*>(t.hdr[s])[2];
             const int last_pair = (t.Ppad[s] - BT_LEAD) / 2 - 1;
             const float w = a.w[s];
             const float Pf = (float)a.P[s], rP = 1.0f / Pf;
-            uint32_t idx[NCE ? BT_E4 : 1][2];
-            auto groups = [&](auto steps_c) {
-                constexpr int STEPS = decltype(steps_c)::value;
-    #pragma unroll
-                for (int g = 0; g < BT_E4; g += ILV) {
-                    float x[W];
-                    int best[W];
-    #pragma unroll
-                    for (int j = 0; j < ILV; ++j) { x[4 * j] = v[g + j].x; x[4 * j + 1] = v[g + j].y; x[4 * j + 2] = v[g + j].z; x[4 * j + 3] = v[g + j].w; }
-                    bt_lookup<W, STEPS>(tab, lut, lo_v, inv_w, top, steps, last_pair, x, best);
-    #pragma unroll
-                    for (int k = 0; k < W; ++k) {
-                        const int i = g + (k >> 2), e = k & 3;
-                        if (!NCE) {
-                            const float tr = bt_quot(best[k], Pf, rP);               // hybrid.py:275
-                            const float prod = tr * w;                              // fl32(t * fl32(w))      hybrid.py:291 under NumPy 2
-                            // a document the system does not list adds nothing: + (+0.0f) leaves every accumulator as it is (one is never
-                            // -0.0: the sums start from +0.0); as a bit mask, so that the compiler does not branch around the arithmetic
+            auto step = [&](auto r_c) {
+                constexpr int r = decltype(r_c)::value;
+                const int q = qr[r], c = cr[r];
+                const size_t rowoff = (size_t)q * a.ld;
+                // which of the item's documents this system lists: wave-uniform bases + clamped per-thread offsets (no branches; what is
+                // read past the row end is masked by tail_ok).  Requested BEFORE the table swap: the words arrive under its barrier and DMA
+                mask_t ok = tail_ok[r];
+                if (a.vbits[s]) {
+                    const uint32_t* __restrict__ wb = a.vbits[s] + (size_t)q * a.ldb + ((c * BT_COLS) >> 5);
+                    const int wlast = (min(a.N - c * BT_COLS, BT_COLS) - 1) >> 5, sh = toff & 31, wo = my_off() >> 5;
+                    mask_t m = 0;
+#pragma unroll
+                    for (int i = 0; i < BT_E4; ++i) m |= (mask_t)((wb[min(wo + (4 * BT_T / 32) * i, wlast)] >> sh) & 0xfu) << (4 * i);
+                    ok &= m;
+                } else if (a.ranks[s]) {
+                    const int32_t* __restrict__ rk = a.ranks[s] + rowoff + c * BT_COLS;
+                    const int lim = chunk_lim(c);
+                    mask_t m = 0;
+#pragma unroll
+                    for (int i = 0; i < BT_E4; ++i) {
+                        const int4 rr = *reinterpret_cast<const int4*>(rk + min(my_off() + 4 * BT_T * i, lim));
+                        uint32_t nib = (rr.x >= 0 ? 1u : 0u) | (rr.y >= 0 ? 2u : 0u) | (rr.z >= 0 ? 4u : 0u) | (rr.w >= 0 ? 8u : 0u);
+                        asm volatile("" : "+v"(nib));   // one rank quad at a time: all of them in flight at once would be the kernel's register peak
+                        m |= (mask_t)nib << (4 * i);
+                    }
+                    ok &= m;
+                }
+                // Requests to HBM run one step ahead: a group's registers take the same group of the NEXT step right after it has been
+                // searched -- except the step's LAST group, whose request would be the youngest when the table swap waits for its LDS-DMA
+                // (vmcnt counts in order: waiting for the DMA means waiting for everything older).  That one is issued here, BEHIND the
+                // DMA, and the swap waits with vmcnt(ILV): the DMA and every older request have landed, the ILV youngest may still fly
+                // (on the very first step the wait could return with DMA pieces in flight: it uses vmcnt(0)).
+                const bool swap = cur != s;
+                if (swap) {
+                    __syncthreads();                       // every wave is done with the table that is there
+                    dma(t.tab[s], tabr, t.Ppad[s]);
+                    dma(t.lut[s], lutf, t.lut_floats);
+                    if (NCE && t.val_in_lds) dma(t.val[s], valr, t.Ppad[s]);
+                    cur = s;
+                }
+                if (!first) {   // (not the very first step, whose scores the prologue requested)
+#pragma unroll
+                    for (int i = BT_E4 - ILV; i < BT_E4; ++i) v[i] = load_one(nxt, i, nlim);
+                }
+                if (swap) {
+                    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (ILV == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // this wave's pieces have landed ...
+                    __syncthreads();                                        // ... and everybody else's
+                }
+                first = false;
+                // the next step: the round's next live item under this system, else its first item under the next system, else the next
+                // round's first item; after the very last step the requests re-read this step's own row (unconditional requests: no
+                // phi copies of the score registers, no second wait form)
+                {
+                    bool found = false;
+#pragma unroll
+                    for (int r2 = r + 1; r2 < R; ++r2)
+                        if (!found && live[r2]) { nxt = a.planes[s] + (size_t)qr[r2] * a.ld + cr[r2] * BT_COLS; nlim = chunk_lim(cr[r2]); found = true; }
+                    if (!found) {
+                        if (s + 1 < a.S) { nxt = a.planes[s + 1] + (size_t)qr[0] * a.ld + cr[0] * BT_COLS; nlim = chunk_lim(cr[0]); }
+                        else if (more) { nxt = a.planes[0] + (size_t)qn * a.ld + cn * BT_COLS; nlim = chunk_lim(cn); }
+                    }
+                }
+                uint32_t idx[NCE ? BT_E4 : 1][2];
+                auto groups = [&](auto steps_c) {
+                    constexpr int STEPS = decltype(steps_c)::value;
+#pragma unroll
+                    for (int g = 0; g < BT_E4; g += ILV) {
+                        float x[W];
+                        int best[W];
+#pragma unroll
+                        for (int j = 0; j < ILV; ++j) { x[4 * j] = v[g + j].x; x[4 * j + 1] = v[g + j].y; x[4 * j + 2] = v[g + j].z; x[4 * j + 3] = v[g + j].w; }
+                        bt_lookup<W, STEPS>(tab, lut, lo_v, inv_w, top, steps, last_pair, x, best);
+#pragma unroll
+                        for (int k = 0; k < W; ++k) {
+                            const int i = g + (k >> 2), e = k & 3;
+                            if (!NCE) {
+                                const float tr = bt_quot(best[k], Pf, rP);               // hybrid.py:275
+                                const float prod = tr * w;                              // fl32(t * fl32(w))      hybrid.py:291 under NumPy 2
+                                // a document the system does not list adds nothing: + (+0.0f) leaves every accumulator as it is (one is never
+                                // -0.0: the sums start from +0.0); as a bit mask, so that the compiler does not branch around the arithmetic
+                                const uint32_t keep = 0u - (uint32_t)((ok >> (4 * i + e)) & 1);
+                                acc[r][i][e] = acc[r][i][e] + __uint_as_float(__float_as_uint(prod) & keep);
+                            } else if (e & 1) idx[NCE ? i : 0][e >> 1] |= (uint32_t)best[k] << 16;   // two 16-bit indices per register (P <= 65535)
+                            else idx[NCE ? i : 0][e >> 1] = (uint32_t)best[k];
+                        }
+#pragma unroll
+                        for (int j = 0; j < ILV; ++j) {
+                            // pin the group's sums (or indices) HERE: left alone the compiler sinks every group's value arithmetic to the end of the
+                            // step, the 4 indices per group stay live until then, and what the register allocator then spills is the score registers
+                            if (!NCE) asm volatile("" : "+v"(acc[r][g + j][0]), "+v"(acc[r][g + j][1]), "+v"(acc[r][g + j][2]), "+v"(acc[r][g + j][3]));
+                            else asm volatile("" : "+v"(idx[NCE ? g + j : 0][0]), "+v"(idx[NCE ? g + j : 0][1]));
+                        }
+                        if (g + ILV < BT_E4) {
+#pragma unroll
+                            for (int j = 0; j < ILV; ++j) v[g + j] = load_one(nxt, g + j, nlim);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // one group's searches at a time: scheduled across groups, their temporaries push the score registers out
+                    }
+                };
+                switch (steps <= BT_MAX_UNROLLED ? (steps < 1 ? 1 : steps) : 0) {   // (wave-uniform; fewer probes than the table needs would be wrong, more are not)
+                    case 1: groups(std::integral_constant<int, 1>{}); break;
+                    case 2: groups(std::integral_constant<int, 2>{}); break;
+                    case 3: groups(std::integral_constant<int, 3>{}); break;
+                    case 4: groups(std::integral_constant<int, 4>{}); break;
+                    default: groups(std::integral_constant<int, 0>{}); break;
+                }
+                if (NCE) {
+                    const lds_f32* vt = (const lds_f32*)valr;
+                    if (!t.val_in_lds) {   // the values take the table's place
+                        __syncthreads();
+                        dma(t.val[s], tabr, t.Ppad[s]);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        cur = -1;
+                        vt = (const lds_f32*)tabr;
+                    }
+#pragma unroll
+                    for (int i = 0; i < BT_E4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float prod = vt[(idx[NCE ? i : 0][e >> 1] >> (16 * (e & 1))) & 0xffffu] * w;
                             const uint32_t keep = 0u - (uint32_t)((ok >> (4 * i + e)) & 1);
-                            acc[i][e] = acc[i][e] + __uint_as_float(__float_as_uint(prod) & keep);
-                        } else if (e & 1) idx[NCE ? i : 0][e >> 1] |= (uint32_t)best[k] << 16;   // two 16-bit indices per register (P <= 65535)
-                        else idx[NCE ? i : 0][e >> 1] = (uint32_t)best[k];
-                    }
-    #pragma unroll
-                    for (int j = 0; j < ILV; ++j) {
-                        // pin the group's sums (or indices) HERE: left alone the compiler sinks every group's value arithmetic to the end of the
-                        // step, the 4 indices per group stay live until then, and what the register allocator then spills is the score registers
-                        if (!NCE) asm volatile("" : "+v"(acc[g + j][0]), "+v"(acc[g + j][1]), "+v"(acc[g + j][2]), "+v"(acc[g + j][3]));
-                        else asm volatile("" : "+v"(idx[NCE ? g + j : 0][0]), "+v"(idx[NCE ? g + j : 0][1]));
-                    }
-                    if (g + ILV < BT_E4) {
-    #pragma unroll
-                        for (int j = 0; j < ILV; ++j) v[g + j] = load_one(nxt, g + j, nlim);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // one group's searches at a time: scheduled across groups, their temporaries push the score registers out
+                            acc[r][i][e] = acc[r][i][e] + __uint_as_float(__float_as_uint(prod) & keep);
+                        }
                 }
+                present[r] |= ok;
             };
-            switch (steps <= BT_MAX_UNROLLED ? (steps < 1 ? 1 : steps) : 0) {   // (wave-uniform; fewer probes than the table needs would be wrong, more are not)
-                case 1: groups(std::integral_constant<int, 1>{}); break;
-                case 2: groups(std::integral_constant<int, 2>{}); break;
-                case 3: groups(std::integral_constant<int, 3>{}); break;
-                case 4: groups(std::integral_constant<int, 4>{}); break;
-                default: groups(std::integral_constant<int, 0>{}); break;
-            }
-            if (NCE) {
-                const lds_f32* vt = (const lds_f32*)valr;
-                if (!t.val_in_lds) {   // the values take the table's place
-                    __syncthreads();
-                    dma(t.val[s], tabr, t.Ppad[s]);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    cur = -1;
-                    vt = (const lds_f32*)tabr;
+            step(std::integral_constant<int, 0>{});
+            if constexpr (R > 1) { if (live[R - 1]) step(std::integral_constant<int, R - 1>{}); }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!live[r]) continue;
+            const size_t rowoff = (size_t)qr[r] * a.ld;
+            const int col0 = cr[r] * BT_COLS + my_off();
+#pragma unroll
+            for (int i = 0; i < BT_E4; ++i) {
+                const int j0 = col0 + 4 * BT_T * i;
+                if (j0 < a.N) {   // columns [N, ld) of the last float4 are padding of the plane: written, never read
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = ((present[r] >> (4 * i + e)) & 1) ? acc[r][i][e] : -INFINITY;
+                    *reinterpret_cast<float4*>(fused + rowoff + j0) = make_float4(o[0], o[1], o[2], o[3]);
                 }
-#pragma unroll
-                for (int i = 0; i < BT_E4; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float prod = vt[(idx[NCE ? i : 0][e >> 1] >> (16 * (e & 1))) & 0xffffu] * w;
-                        const uint32_t keep = 0u - (uint32_t)((ok >> (4 * i + e)) & 1);
-                        acc[i][e] = acc[i][e] + __uint_as_float(__float_as_uint(prod) & keep);
-                    }
-            }
-            present |= ok;
-        }
-#pragma unroll
-        for (int i = 0; i < BT_E4; ++i) {
-            const int j0 = col0 + 4 * BT_T * i;
-            if (j0 < a.N) {   // columns [N, ld) of the last float4 are padding of the plane: written, never read
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = ((present >> (4 * i + e)) & 1) ? acc[i][e] : -INFINITY;
-                *reinterpret_cast<float4*>(fused + rowoff + j0) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
-        q = q2; c = c2;
+        q = qn; c = cn;
     }
 }
 
@@ -579,11 +610,11 @@ extern "C" int fz_fuse_nsf_tables_f32(const float* const* planes_h, const int32_
     const unsigned grid = (unsigned)(items < 256 ? items : 256);
     static unsigned long long set_pr = 0ull, set_nce = 0ull;
     if (nce) {
-        if (int rc = raise_lds_limit((const void*)fuse_nsf_bigtab_kernel<true, 1>, p.lds_bytes, set_nce)) return rc;
-        fuse_nsf_bigtab_kernel<true, 1><<<grid, BT_T, p.lds_bytes, st>>>(a, t, fused);
+        if (int rc = raise_lds_limit((const void*)fuse_nsf_bigtab_kernel<true, 1, BT_R>, p.lds_bytes, set_nce)) return rc;
+        fuse_nsf_bigtab_kernel<true, 1, BT_R><<<grid, BT_T, p.lds_bytes, st>>>(a, t, fused);
     } else {
-        if (int rc = raise_lds_limit((const void*)fuse_nsf_bigtab_kernel<false, 1>, p.lds_bytes, set_pr)) return rc;
-        fuse_nsf_bigtab_kernel<false, 1><<<grid, BT_T, p.lds_bytes, st>>>(a, t, fused);
+        if (int rc = raise_lds_limit((const void*)fuse_nsf_bigtab_kernel<false, 1, BT_R>, p.lds_bytes, set_pr)) return rc;
+        fuse_nsf_bigtab_kernel<false, 1, BT_R><<<grid, BT_T, p.lds_bytes, st>>>(a, t, fused);
     }
     FZ_LAUNCH_CHECK();
     return FZ_OK;

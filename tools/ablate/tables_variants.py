@@ -10,10 +10,13 @@ FLAGS = "-O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -fno-fast-
 
 T1024 = "constexpr int BT_T = 1024;"
 E7 = "constexpr int BT_E4 = 7;"
+R1 = "constexpr int BT_R = 1;"
+I1A, I1B = "fuse_nsf_bigtab_kernel<false, 1, BT_R>", "fuse_nsf_bigtab_kernel<true, 1, BT_R>"
 VARIANTS = {
-    # 8 waves x 256 VGPRs, two float4 (8 scores) searched in lockstep
-    "t512_ilv2": [(T1024, "constexpr int BT_T = 512;"), (E7, "constexpr int BT_E4 = 14;"), ("fuse_nsf_bigtab_kernel<false, 1>", "fuse_nsf_bigtab_kernel<false, 2>"),
-                  ("fuse_nsf_bigtab_kernel<true, 1>", "fuse_nsf_bigtab_kernel<true, 2>")],
+    # 8 waves x 256 VGPRs: two items per table residency (half the swaps), one or two float4 searched in lockstep
+    "t512_r2": [(T1024, "constexpr int BT_T = 512;"), (E7, "constexpr int BT_E4 = 14;"), (R1, "constexpr int BT_R = 2;")],
+    "t512_r2_ilv2": [(T1024, "constexpr int BT_T = 512;"), (E7, "constexpr int BT_E4 = 14;"), (R1, "constexpr int BT_R = 2;"),
+                     (I1A, "fuse_nsf_bigtab_kernel<false, 2, BT_R>"), (I1B, "fuse_nsf_bigtab_kernel<true, 2, BT_R>")],
     "t512_ilv1": [(T1024, "constexpr int BT_T = 512;"), (E7, "constexpr int BT_E4 = 14;")],
     # no HBM reads of scores after the first step (lookups + swaps + stores only)
     "nostream": [("        return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(base + min(my_off() + 4 * BT_T * i, lim)));   // streamed once",
