@@ -27,7 +27,9 @@ through a placeholder. sentence-transformers / colbert-ai are NOT stubbed:
 their arithmetic is not reproduced here ("parity unpinned" at those call sites,
 see DESIGN.md).
 
-Fixtures are data only: seeded synthetic inputs + the reference's outputs.
+Fixtures are data only: seeded synthetic inputs + the reference's outputs.  A full run takes ~12 minutes, 11 of them in
+gen_pr28k: the reference's percentile-rank transform materialises a [27,943, 27,942] float32 distance matrix (3.1 GB, twice)
+per list (hybrid.py:273), eight lists in all; it needs ~8 GB of RAM.
 Usage: python oracle/gen_golden.py [generator ...]  (rewrites tests/golden/*.npz|json; no argument = all of them)
 """
 import json

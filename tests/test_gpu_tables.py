@@ -394,3 +394,27 @@ def test_scores_a_rounding_below_the_table_maximum(ops, oracle, P):
         else:
             fin = np.isfinite(exp)
             assert np.array_equal(np.isfinite(got), fin) and np.max(np.abs(got[fin] - exp[fin])) <= 1e-4
+
+
+def test_cli_percentile_rank_with_a_table_of_the_size_the_reference_reads(tmp_path):
+    """`python src/retrievers/hybrid.py --fusion nsf --normalization percentile-rank` (one of the three normalisers of every run_hybrid.sh
+    combination, run_hybrid.sh:35) reads `score_distributions_raw_<eval>_28k.csv` (hybrid.py:412,451): 27,943 rows per system on LLeQA.  A
+    file of that size through main() -- the equal-weights fusion and the weight sweep -- takes the long-table kernel."""
+    import pandas as pd
+    from fusion_amd import ops
+    from fusion_amd.retrievers.hybrid import build_parser, main
+    out = str(tmp_path)
+    rng = np.random.default_rng(2)
+    P = 27943
+    pd.DataFrame({"bm25": quantile_table(np.maximum(0.0, rng.gamma(0.5, 4.0, 200_000) - 2.0) + 1e-3, P),
+                  "dpr": quantile_table(rng.uniform(-0.2, 0.9, 200_000), P)}).to_csv(os.path.join(out, "score_distributions_raw_indomain_28k.csv"), index=False)
+    base = f"--data_split test --models_domain legal --synthetic 600,6 --output_dir {out} --run_bm25 --run_dpr --fusion nsf --normalization percentile-rank".split()
+    ops.last_tables_path = None
+    a, _ = build_parser().parse_known_args(base)
+    sc = main(a)
+    assert ops.last_tables_path == "lds-swap" and 0.0 <= sc["recall@1000"] <= 1.0
+    ops.last_tables_path = None
+    a, _ = build_parser().parse_known_args(base + ["--tune_linear_fusion_weight"])
+    rows = main(a)
+    df = pd.read_csv(os.path.join(out, "nsf_percentile-rank_indomain.csv"))
+    assert ops.last_tables_path == "lds-swap" and len(rows) == len(df) == 21 and list(df.columns)[-2:] == ["weight_bm25", "weight_dpr"]

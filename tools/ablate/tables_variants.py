@@ -17,6 +17,9 @@ VARIANTS = {
     "t512_r2": [(T1024, "constexpr int BT_T = 512;"), (E7, "constexpr int BT_E4 = 14;"), (R1, "constexpr int BT_R = 2;")],
     "t512_r2_ilv2": [(T1024, "constexpr int BT_T = 512;"), (E7, "constexpr int BT_E4 = 14;"), (R1, "constexpr int BT_R = 2;"),
                      (I1A, "fuse_nsf_bigtab_kernel<false, 2, BT_R>"), (I1B, "fuse_nsf_bigtab_kernel<true, 2, BT_R>")],
+    "ilv2": [(I1A, "fuse_nsf_bigtab_kernel<false, 2, BT_R>"), (I1B, "fuse_nsf_bigtab_kernel<true, 2, BT_R>")],
+    "nosched": [("                        __builtin_amdgcn_sched_barrier(0);   // one group's searches at a time", "                        // (no sched barrier)")],
+    "lut8k": [("    for (int lutb = 16384; lutb >= 2048 && !p.ok; lutb >>= 1) {", "    for (int lutb = 8192; lutb >= 2048 && !p.ok; lutb >>= 1) {")],
     "t512_ilv1": [(T1024, "constexpr int BT_T = 512;"), (E7, "constexpr int BT_E4 = 14;")],
     # no HBM reads of scores after the first step (lookups + swaps + stores only)
     "nostream": [("        return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(base + min(my_off() + 4 * BT_T * i, lim)));   // streamed once",
