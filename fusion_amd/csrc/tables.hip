@@ -14,10 +14,10 @@
 //     and nothing is accumulated through memory;
 //   * per (item, system) step the system's table and its bucket table are brought into LDS by LDS-DMA (global_load_lds, 16 B
 //     per lane, no VGPRs) from an aligned, sentinel-padded copy in the workspace -- 144 KB from L2 per swap (the tables are read
-//     by every workgroup: L2-resident), ~2.5 us against ~28 k searches (measured: 0.03 of the 0.27 ms).  With S = 1
+//     by every workgroup: L2-resident), ~3 us against ~28 k searches (measured: 0.05 of the 0.25 ms).  With S = 1
 //     (Aggregator.tune normalises system by system) the table is loaded once per workgroup;
 //   * the step's scores are requested from HBM one step AHEAD: a float4's registers take the same float4 of the next step as
-//     soon as it has been searched (measured: the stream costs 0.03 ms instead of its 0.09 standalone);
+//     soon as it has been searched (measured: the stream costs 0.055 ms instead of its 0.09 standalone);
 //   * the search: an equi-width bucket table over [tab[0], tab[P-1]] with 16,384 buckets (uint16: 32 KB) is built ONCE per call
 //     by fz_nsf_tables_prepare with the SAME float expression the scores go through (bucket(x) = (int)clamp((x - lo) * inv_w)),
 //     lut[b] = #{k : bucket(tab[k]) < b}.  bucket() is monotone, so for a score in bucket b every entry before lut[b] is
@@ -31,8 +31,8 @@
 //     workspace, the expression of fuse.hip's transform<FZ_NORM_NCE>), it either sits next to the table in LDS (P <= ~16 k) or
 //     is swapped in over the table once the item's 28 indices per thread are known.
 //
-// What bounds it (profiles/r04_pmc_tables.json, S = 4, Q = 1024, N = P - 1 = 27,942: 0.27 ms = 2.1 TB/s of the fusion's algorithmic
-// bytes): 51 vector instructions and 4.6 LDS instructions per score -- 0.15 ms of vector-ALU issue and 0.12 ms of LDS cycles (62 % of
+// What bounds it (profiles/r04_pmc_tables.json, S = 4, Q = 1024, N = P - 1 = 27,942: 0.25 ms = 2.3 TB/s of the fusion's algorithmic
+// bytes): 49 vector instructions and 4.6 LDS instructions per score -- 0.14 ms of vector-ALU issue and 0.12 ms of LDS cycles (62 % of
 // them bank conflicts: the reads are random by nature) that overlap only in part; the round-3 path it replaces at these sizes
 // (fz_fuse_nsf_f32's global-memory search) takes 2.8 ms, NCE 9.4 ms.
 //
