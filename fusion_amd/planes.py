@@ -121,12 +121,12 @@ class FusedResult:
         lens = self.lens.cpu().numpy()
         f32 = sc.dtype == np.float32
         out = []
+        # nsf scores leave the reference as np.float32 scalars (hybrid.py:258 ... zip(keys, scores.cpu().numpy())), rrf / bcf / 'none' as
+        # Python floats: iterating a float32 array yields exactly those scalars, .tolist() the Python floats -- one C loop each
         with _gc_paused():
-          for q in range(order.shape[0]):
-            n = int(lens[q])
-            # nsf scores leave the reference as np.float32 scalars (hybrid.py:258 ... zip(keys, scores.cpu().numpy())), rrf / bcf / 'none'
-            # as Python floats: iterating a float32 array yields exactly those scalars, .tolist() the Python floats -- one C loop each
-            out.append(_dict_list(self.ids[order[q, :n]].tolist(), list(sc[q, :n]) if f32 else sc[q, :n].tolist()))
+            for q in range(order.shape[0]):
+                n = int(lens[q])
+                out.append(_dict_list(self.ids[order[q, :n]].tolist(), list(sc[q, :n]) if f32 else sc[q, :n].tolist()))
         return out
 
     def predictions(self, topk: int | None = None) -> list[list]:

@@ -650,12 +650,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", default="", help="comma-separated case names (e.g. tables,fuse): soak those families alone")
     a = ap.parse_args()
+    cases = [f for f in CASES if not a.only or f.__name__[len("case_"):] in a.only.split(",")]
+    assert cases, f"--only {a.only}: no such case"
     oracle.build()
     rng = np.random.default_rng(a.seed)
     t0, n, counts, last = time.time(), 0, {}, time.time()
     while time.time() - t0 < a.seconds:
-        f = CASES[int(rng.integers(0, len(CASES)))]
+        f = cases[int(rng.integers(0, len(cases)))]
         state = rng.bit_generator.state
         try:
             desc = f(rng)
