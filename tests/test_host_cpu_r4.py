@@ -95,3 +95,31 @@ def test_bench_launcher_argv_and_guard():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(os.environ, WORLD_SIZE="1"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_tables_abi_planning_and_validation_without_gpu():
+    """The long-table entry points' host side (no launch): workspace sizes, which kernel a call would take, argument checks."""
+    import ctypes as C
+    from fusion_amd import _lib
+    L = _lib.lib()
+    i32 = lambda *v: (C.c_int32 * len(v))(*v)
+    b4 = L.fz_nsf_tables_workspace_bytes(4, i32(27943, 27943, 27943, 27943), 4)
+    b4n = L.fz_nsf_tables_workspace_bytes(4, i32(27943, 27943, 27943, 27943), 5)
+    assert 4 * (27943 * 4 + 32768) < b4 < 4 * 160 * 1024 and b4n - b4 >= 4 * 27943 * 4          # NCE adds one value table per system
+    assert L.fz_nsf_tables_workspace_bytes(1, i32(38000), 4) > 0 and L.fz_nsf_tables_workspace_bytes(1, i32(40000), 4) == 0   # beyond LDS
+    assert L.fz_nsf_tables_workspace_bytes(1, i32(0), 4) == 0 and L.fz_nsf_tables_workspace_bytes(9, i32(5), 4) == 0
+    assert L.fz_nsf_tables_header_offset(2, i32(100, 200), 4, 1) > 0 and L.fz_nsf_tables_header_offset(2, i32(100, 200), 4, 2) == C.c_size_t(-1).value
+    # which kernel: fake (aligned) plane addresses, no memory behind them -- the function only looks at shapes and alignment
+    planes = (C.c_void_p * 4)(0x1000, 0x2000, 0x3000, 0x4000)
+    path = lambda S, P, ld=28032, out=0x8000, norm=4: L.fz_nsf_tables_path(planes, None, S, 8, 27942, ld, norm, i32(*P), out)
+    assert path(4, [1001] * 4) == 0 and path(4, [27943] * 4) == 1 and path(1, [27943]) == 1 and path(4, [10001] * 4) == 1
+    assert path(1, [60000]) == 2 and path(4, [27943] * 4, out=0x8004) == 2 and path(4, [27943] * 4, ld=27943) == 2
+    assert path(4, [27943] * 4, norm=1) == _lib.FZ_ERR_ARG and path(4, [27943, 0, 5, 5]) == _lib.FZ_ERR_ARG
+    d = (C.c_void_p * 1)(0x1000)
+    assert L.fz_nsf_tables_prepare(d, i32(27943), 1, 4, None, 0, None) == _lib.FZ_ERR_WORKSPACE
+    assert L.fz_nsf_tables_prepare(d, i32(27943), 1, 2, None, 0, None) == _lib.FZ_ERR_ARG
+    assert L.fz_nsf_tables_prepare(d, i32(70000), 1, 4, None, 0, None) == _lib.FZ_ERR_UNSUPPORTED
+    w = (C.c_double * 1)(1.0)
+    assert L.fz_fuse_nsf_tables_f32(planes, None, w, 1, 8, 27942, 28032, 4, d, i32(27943), None, 0, 0x8000, None, 0, None) == _lib.FZ_ERR_WORKSPACE
+    assert L.fz_fuse_nsf_tables_f32(planes, None, w, 1, 0, 27942, 28032, 4, d, i32(27943), None, 0, None, None, 0, None) == _lib.FZ_OK   # empty batch
+    assert L.fz_fuse_nsf_tables_f32(planes, None, w, 1, 8, 27942, 28032, 4, d, i32(60000), None, 0, 0x8000, None, 0, None) == _lib.FZ_ERR_UNSUPPORTED

@@ -43,9 +43,10 @@ def test_c_abi_host_side_under_asan_ubsan():
     if not os.path.exists(rt):
         pytest.skip("clang has no shared ASan runtime in this image")
     tests = ["tests/test_host_cpu.py::test_library_loads_and_exports_header_symbols", "tests/test_host_cpu.py::test_abi_argument_validation_without_gpu",
-             "tests/test_host_cpu.py::test_integration_md_binding_matches_the_abi", "tests/test_host_cpu.py::test_workspace_planning_is_consistent"]
+             "tests/test_host_cpu.py::test_integration_md_binding_matches_the_abi", "tests/test_host_cpu.py::test_workspace_planning_is_consistent",
+             "tests/test_host_cpu_r4.py::test_tables_abi_planning_and_validation_without_gpu"]
     rc, out = _run([sys.executable, "-m", "pytest", *tests, "-x", "-q", "-p", "no:cacheprovider"], dict(LD_PRELOAD=rt, FUSION_AMD_LIB=so), timeout=900)
-    assert rc == 0 and "4 passed" in out and "ERROR: AddressSanitizer" not in out and "runtime error" not in out, out[-4000:]
+    assert rc == 0 and "5 passed" in out and "ERROR: AddressSanitizer" not in out and "runtime error" not in out, out[-4000:]
 
 
 def test_no_mfma_result_is_read_before_it_is_written(tmp_path):
