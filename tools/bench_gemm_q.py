@@ -6,7 +6,7 @@ g = torch.Generator(device="cuda").manual_seed(1)
 N = 27942
 for d in (768, 32008):
     Dn = ops.normalize_rows(torch.randn((N, d), generator=g, device="cuda"))
-    for Q in (1024, 195, 192, 201, 200, 128, 64):
+    for Q in (1024, 224, 208, 195, 193, 192, 201, 200, 160, 128, 64):
         Qn = ops.normalize_rows(torch.randn((Q, d), generator=g, device="cuda"))
         out = ops.alloc_plane(Q, N, torch.float32, "cuda")
         ms = timeit(lambda: ops.dot_scores(Qn, Dn, out=out), n=20 if d == 768 else 3, warm=2)
