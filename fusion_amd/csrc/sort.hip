@@ -51,6 +51,20 @@ struct SortArgs {
     int stats_rows;              //   hybrid.py:254-262), a by-product of having the row in registers; chunks == 1 only
     const int32_t* stats_len;    // nullable [rows]: the statistics cover the first stats_len[row] entries of the SORTED list (a ranking
                                  //   truncated to its top-k: PLAID-style short lists, return_topk); fp32 keys only
+    int bucket_rank;             // 1 = rows of a 1024-thread workgroup are ordered by the bucket ranking where it applies (set by the launcher)
+};
+
+// rows the bucket ranking ordered | of those, rows whose neighbour check swapped a pair back | rows it gave up on after starting
+// (ties, a crowd at the floor, an overfull bucket, a check it could not settle).  Read by fz_sort_bucket_rank_rows (tests, tools).
+__device__ unsigned long long g_bucket_rank_rows[3];
+
+// Bucket ranking (see sort_rows_kernel): fine / coarse bucket counts and the words of LDS its tables take in the counter area.
+constexpr int BR_FINE = 16384, BR_COARSE = 1024, BR_WORDS = BR_FINE / 2 + BR_COARSE + 1024;   // + one bit per slot (bucket starts)
+constexpr int BR_MIN_KEYS = 4096, BR_MAX_BUCKET = 128;
+template <int T, int E, int KW> struct SortLds {
+    static constexpr bool br = T == 1024 && KW == 1 && (size_t)(32 + T * E + BR_WORDS) * 4 <= 160 * 1024;
+    static constexpr size_t area = (size_t)(T / 64) * 256 * 4 + (KW == 2 ? (size_t)T * E : 0);   // counters (+ fp64: one move byte per slot)
+    static constexpr size_t bytes = (size_t)(32 + T * E) * 4 + (br && area < (size_t)BR_WORDS * 4 ? (size_t)BR_WORDS * 4 : area);
 };
 
 // GEN (fp64 only): the generic eight-pass form, run as a second launch for the rows the fast form flags (see below).
@@ -62,9 +76,10 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     constexpr int LG = (KW == 2) ? 7 : 14;         // global loads in flight per thread before the first use (one HBM latency per group)
     constexpr int WALK = 16;                        // longest equal-high-word run the fp64 repair re-sorts in place
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* exch = smem;                         // [T*E]
-    uint32_t* cnt = smem + T * E;                  // [NW*256] (plain LDS pointer: volatile would lower to flat sc0 sc1 accesses)
-    uint32_t* misc = smem + T * E + NW * 256;      // [32]
+    uint32_t* misc = smem;                         // [32]
+    uint32_t* exch = smem + 32;                    // [T*E]
+    uint32_t* cnt = smem + 32 + T * E;             // [NW*256] (plain LDS pointer: volatile would lower to flat sc0 sc1 accesses); the bucket
+                                                   //   ranking's tables (BR_WORDS words) start here too, over the fp64 move bytes behind it
 
     const int prow = blockIdx.x;
     const int row = prow / a.chunks;
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     // fp64 key of the element at column `col` (re-derivable at any time from global memory: L2 / Infinity-Cache hits)
     auto key64 = [&](uint2 v) -> uint64_t { return desc_key_f64(__hiloint2double((int)v.y, (int)v.x)); };
 
-    if (threadIdx.x < 4) misc[8 + threadIdx.x] = (threadIdx.x & 1) ? 0xffffffffu : 0u;  // [8] = or, [9] = and of the sort words
+    if (threadIdx.x < 8) misc[8 + threadIdx.x] = (threadIdx.x == 1 || threadIdx.x == 3) ? 0xffffffffu : 0u;  // [8] = or, [9] = and of the sort words; [10] = max, [11] = min, [12] .. [15] = sums (bucket ranking)
     uint32_t orw = 0, andw = 0xffffffffu;
     if (irow) {
         // placed sequence: column j sits at sequence position init_rank[j].  Keys and positions are read coalesced by
@@ -367,7 +382,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         __syncthreads();
     };
     // move (ks, payload) to the slots in meta's high halves (a permutation of [0, m)); slots >= m keep theirs
-    auto permute_to_meta_hi = [&]() {
+    auto permute_to_meta_hi = [&]() __attribute__((always_inline)) {
         SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) exch[meta[i] >> 16] = ks[i];
@@ -398,12 +413,314 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         }
     };
 
+    // ---- bucket ranking: the stable order by the 32-bit sort word WITHOUT the digit passes ------------------------------------------
+    // A row of a ranker's scores is a sample of a smooth distribution: spread over 16,384 buckets whose widths follow the row's own
+    // density, a key shares its bucket with one or two others, and its rank is the bucket's first slot plus the number of bucket
+    // members that precede it -- a handful of comparisons where the four digit passes spend ~8 ballots per key bit.
+    //   0. range [wmin, wmax] of the sort words; t = w - wmin in 1,024 equal COARSE buckets (c = t >> s1);
+    //   1. a histogram of 4 keys per thread over the coarse buckets -> coarse bucket c is cut into nsub[c] ~ its share of the keys FINE
+    //      buckets: fine(w) = base[c] + floor(frac * nsub[c]), rem(w) = the next 16 bits of that product.  (fine, rem) is a monotone
+    //      function of w, exact (distinct words, distinct values) wherever a coarse bucket holds more than a few dozen keys;
+    //   2. counting sort by fine bucket: packed 16-bit LDS counters (atomic add), exclusive scan, a second atomic add on the
+    //      offsets hands out the slots; a slot holds rem << 16 | sequence position;
+    //   3. every key counts the members of its bucket below its own (rem, position): that is its rank;
+    //   4. keys and payloads move to their ranks (one exchange, as after a digit pass), and every slot checks its left neighbour:
+    //      two DISTINCT words that shared (fine, rem) may be in position order instead of word order.  Then -- or when a bucket holds more
+    //      than BR_MAX_BUCKET keys (heavy ties: BM25's zeros), or the sequence has holes -- the digit passes run after all: the
+    //      arrangement is a stable permutation by a coarsening of the word, so they finish it to the same result.
+    // All integer arithmetic on the sort word: NaN / inf / signed zeros are whatever desc_key made of them.
+    constexpr bool BR = !GEN && SortLds<T, E, KW>::br;
+    auto bucket_rank = [&]() __attribute__((always_inline)) -> bool {
+      if constexpr (!BR) return false; else {
+        uint32_t* cntF = cnt;                       // [BR_FINE / 2]: two 16-bit counters per word (fine bucket 2k low, 2k + 1 high)
+        uint32_t* tab = cnt + BR_FINE / 2;          // [BR_COARSE]: sample count, then base << 16 | nsub
+        uint32_t* bm = tab + BR_COARSE;             // [T*E/32 + 1]: bit p = slot p is the first of its bucket; bit m closes the last one
+        const int t = threadIdx.x;
+        auto wg_excl_scan = [&](uint32_t v, uint32_t& total) -> uint32_t {   // exclusive prefix over the workgroup's threads
+            const uint32_t incl = wave_incl_scan_u32(v, lane);
+            if (lane == 63) misc[16 + w] = incl;
+            __syncthreads();
+            uint32_t base = 0, tot = 0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) { const uint32_t x = misc[16 + ww]; base += ww < w ? x : 0u; tot += x; }
+            __syncthreads();
+            total = tot;
+            return base + incl - v;
+        };
+        // 0. range; holes (a slot below m without an element: placed / gathered sequences only); equal neighbours among a thread's keys
+        //    (a row that is half zeros is turned away here, before its samples queue up on one LDS address)
+        uint32_t mn = 0xffffffffu, mx = 0u, eq = 0u;
+        bool hole = false;
+        SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            if ((slot0 + i * 64) < m) {
+                mn = ks[i] < mn ? ks[i] : mn; mx = ks[i] > mx ? ks[i] : mx;
+                hole |= (meta[i] & 0xffffu) == 0xffffu;
+                if (i > 0) eq += ks[i] == ks[i > 0 ? i - 1 : 0] ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t a1 = __shfl_xor(mn, o, 64), b1 = __shfl_xor(mx, o, 64);
+            mn = a1 < mn ? a1 : mn; mx = b1 > mx ? b1 : mx;
+            eq += __shfl_xor(eq, o, 64);
+        }
+        if (lane == 0) { atomicMin(&misc[11], mn); atomicMax(&misc[10], mx); atomicAdd(&misc[13], eq); }   // initialised before the load phase
+        {
+            uint4* z = reinterpret_cast<uint4*>(cnt);
+            for (int x = t; x < BR_WORDS / 4; x += T) z[x] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (__syncthreads_or(hole ? 1 : 0)) return false;
+        if (misc[13] > (uint32_t)m / 16u) return false;                // more than ~6 % equal neighbours (block-uniform)
+        // The sort word of a float: 0x7fffffff - |bits| for x >= 0, 0x80000000 + |bits| for x < 0 -- between the smallest positive and the
+        // smallest negative value of the row lie all the exponents nobody uses.  Magnitudes more than 24 binades below the row's largest are
+        // clamped to that floor (they share one bucket value; a stray one is the check's business) and the gap is cut out: t counts sort
+        // words from the row's first, over at most 2 x 24 binades.
+        const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[11]), w_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[10]);
+        const uint32_t magp = w_lo < 0x80000000u ? 0x7fffffffu - w_lo : 0u, magn = w_hi >= 0x80000000u ? w_hi - 0x80000000u : 0u;
+        const uint32_t magmax = magp > magn ? magp : magn;
+        constexpr uint32_t FLOOR = 24u << (KW == 1 ? 23 : 20);         // (fp64: the high word, exponent at bit 20)
+        const uint32_t eps = magmax > FLOOR ? magmax - FLOOR : 0u;
+        const uint32_t zp = 0x7fffffffu - eps, zn = 0x80000000u + eps;
+        auto t_of = [&](uint32_t kw, uint32_t base_p, uint32_t base_n) -> uint32_t {   // base_n = base_p + the gap's width
+            const bool neg = kw >= 0x80000000u;
+            const uint32_t lo = kw < zp ? kw : zp, hi = kw > zn ? kw : zn;
+            return (neg ? hi : lo) - (neg ? base_n : base_p);
+        };
+        const uint32_t tmin = t_of(w_lo, 0u, 2u * eps);
+        const uint32_t range = t_of(w_hi, 0u, 2u * eps) - tmin;
+        if (range == 0u) return false;              // (every key at the floor)
+        const uint32_t tb_p = tmin, tb_n = tmin + 2u * eps;
+        const int nbits = 32 - __builtin_clz(range);
+        const int s1 = nbits > 10 ? nbits - 10 : 0;
+        const uint32_t shl = (uint32_t)(32 - s1) & 31u, fmask = s1 ? 0xffffffffu : 0u;
+        // 1. sample: four keys per thread into the coarse histogram -- and into a 2,048-slot hash table of sort words (the still unused
+        //    fine counters): a sample that finds its own word there is a TIE.  A row with heavy ties (SPLADE's or BM25's zeros, a few hundred
+        //    distinct values) would fill single buckets and serialise the histogram's atomics on single counters: found out here, cheaply
+        {
+            uint32_t ns = 0, dup = 0;
+            SLOT_FRESH();
+#pragma unroll
+            for (int i = 0; i < E; i += (E + 3) / 4) {
+                const bool in = (slot0 + i * 64) < m;
+                if (in) {
+                    atomicAdd(&tab[t_of(ks[i], tb_p, tb_n) >> s1], 1u);
+                    dup += atomicExch(&cntF[(ks[i] * 2654435761u) >> 21], ks[i]) == ks[i] ? 1u : 0u;
+                }
+                ns += (uint32_t)__popcll(__ballot(in));
+            }
+            dup = wave_reduce_sum(dup);
+            if (lane == 0) { atomicAdd(&misc[14], ns); atomicAdd(&misc[15], dup); }
+        }
+        __syncthreads();
+        SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; i += (E + 3) / 4) if ((slot0 + i * 64) < m) cntF[(ks[i] * 2654435761u) >> 21] = 0u;
+        if (misc[15] > misc[14] / 32u) return false;                   // (block-uniform)
+        {
+            static_assert(BR_COARSE == T, "one thread per coarse bucket");
+            const uint32_t nsamp = misc[14], mine = tab[t];                               // (at least one sample: m >= BR_MIN_KEYS)
+            // a crowd at the floor (a heavy tail, or zeros under larger scores) is one bucket value: the digit passes' business
+            const bool at_floor = eps != 0u && ((w_lo < 0x80000000u && (uint32_t)t == (zp - tb_p) >> s1) || (w_hi >= 0x80000000u && (uint32_t)t == (zn - tb_n) >> s1));
+            if (__syncthreads_or((at_floor && mine > nsamp / 64u) ? 1 : 0)) return false;
+            const float kf = (float)(BR_FINE - BR_COARSE - 16) / (float)nsamp;
+            const uint32_t nsub = 1u + (uint32_t)((float)mine * kf);
+            uint32_t total;
+            const uint32_t base = wg_excl_scan(nsub, total);
+            tab[t] = (base << 16) | nsub;
+        }
+        __syncthreads();
+        auto fine_rem = [&](uint32_t kw, uint32_t& fine, uint32_t& rem) {
+            const uint32_t tt = t_of(kw, tb_p, tb_n);
+            const uint32_t tb = tab[tt >> s1];
+            const uint32_t f24 = ((tt << shl) & fmask) >> 8;                              // the position inside the coarse bucket, 24 bits
+            const uint64_t prod = (uint64_t)f24 * (uint64_t)(tb & 0xffffu);                // < 2^38 (v_mul_u32_u24 + v_mul_hi_u32_u24)
+            fine = (tb >> 16) + (uint32_t)(prod >> 24);
+            rem = (uint32_t)(prod >> 8) & 0xffffu;
+        };
+        // 2. fine histogram, scan, placement
+        SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            if ((slot0 + i * 64) < m) {
+                uint32_t fine, rem;
+                fine_rem(ks[i], fine, rem);
+                atomicAdd(&cntF[fine >> 1], 1u << ((fine & 1u) * 16u));
+            }
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        {
+            static_assert(BR_FINE == 16 * T, "sixteen fine buckets (eight packed words) per thread");
+            uint4* my4 = reinterpret_cast<uint4*>(cntF + 8 * t);
+            const uint4 q0 = my4[0], q1 = my4[1];
+            uint32_t wv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            uint32_t tot = 0, big = 0, sq = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t lo = wv[k] & 0xffffu, hi = wv[k] >> 16;
+                tot += lo + hi; big = lo > big ? lo : big; big = hi > big ? hi : big;
+                sq += lo * lo + hi * hi;
+            }
+            sq = wave_reduce_sum(sq);
+            if (lane == 0) atomicAdd(&misc[12], sq);                   // the ranking's work: sum of squared bucket sizes
+            uint32_t total;
+            uint32_t run = wg_excl_scan(tot, total);
+            uint32_t st0 = run;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t lo = wv[k] & 0xffffu, hi = wv[k] >> 16;
+                if (lo) atomicOr(&bm[st0 >> 5], 1u << (st0 & 31u));
+                st0 += lo;
+                if (hi) atomicOr(&bm[st0 >> 5], 1u << (st0 & 31u));
+                st0 += hi;
+            }
+            if (t == T - 1) atomicOr(&bm[(uint32_t)m >> 5], 1u << ((uint32_t)m & 31u));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t lo = wv[k] & 0xffffu, hi = wv[k] >> 16;
+                wv[k] = run | ((run + lo) << 16);
+                run += lo + hi;
+            }
+            my4[0] = make_uint4(wv[0], wv[1], wv[2], wv[3]); my4[1] = make_uint4(wv[4], wv[5], wv[6], wv[7]);
+            if (__syncthreads_or(big > (uint32_t)BR_MAX_BUCKET ? 1 : 0)) return false;
+            if (misc[12] > 8u * (uint32_t)m) return false;             // (ties: a few hundred distinct values)
+        }
+        SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int p = slot0 + i * 64;
+            if (p < m) {
+                uint32_t fine, rem;
+                fine_rem(ks[i], fine, rem);
+                const uint32_t sh = (fine & 1u) * 16u;
+                const uint32_t old = atomicAdd(&cntF[fine >> 1], 1u << sh);     // the offset word: start before, end after the last member
+                const uint32_t dst = (old >> sh) & 0xffffu;
+                exch[dst] = (rem << 16) | (uint32_t)p;
+                meta[i] = __builtin_amdgcn_perm(dst, meta[i], 0x05040100u);      // where this key's entry went
+            }
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // 3. rank, slot by slot: the thread of slot d finds d's bucket in the bitmap of bucket starts and counts the members below its
+        //    entry -- the lanes of a wave look at 64 consecutive slots, i.e. at the same few buckets (broadcast reads, equal trip counts).
+        //    Straight-line for buckets of up to eight slots that begin and end within a bitmap word of d's (the rest: rolled loops).
+        //    The thread keeps 16 bits per slot: the rank of the entry that sits there.
+        static_assert(E % 2 == 0, "two ranks per register");
+        uint32_t rk[E / 2];
+        SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int d = slot0 + i * 64;
+            const int dd = d < m ? d : 0;
+            int wi = dd >> 5;
+            const uint32_t mine = exch[dd];
+            const uint32_t Wp = wi ? bm[wi - 1] : 0u, W0 = bm[wi], Wn = bm[wi + 1];
+            const uint32_t low = (2u << (dd & 31)) - 1u;               // bits 0 .. d & 31
+            uint32_t z = W0 & low, z2 = W0 & ~low;
+            int ws = wi, we = wi;
+            if (z == 0u) { z = Wp; --ws; }
+            if (z2 == 0u) { z2 = Wn; ++we; }
+            if (z == 0u || z2 == 0u) {                                 // a bucket of more than 32 slots around d (rare)
+                while (z == 0u) { --ws; z = bm[ws]; }                  // (bit 0 of word 0 is set: terminates)
+                while (z2 == 0u) { ++we; z2 = bm[we]; }                // (bit m is set: terminates)
+            }
+            const uint32_t st = (uint32_t)(ws * 32 + 31 - __builtin_clz(z));
+            const uint32_t en = (uint32_t)(we * 32 + __builtin_ctz(z2));
+            uint32_t v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = exch[st + e];           // (beyond the bucket: other entries or the words behind exch[]; not counted)
+            const uint32_t n = en - st;
+            uint32_t r = st;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r += ((uint32_t)e < n && v[e] < mine) ? 1u : 0u;
+            if (n > 8u) {
+                for (uint32_t j = st + 8u; j < en; ++j) r += exch[j] < mine ? 1u : 0u;
+            }
+            if (i & 1) rk[i >> 1] |= r << 16; else rk[i >> 1] = r;
+            if (i & 1) { asm volatile("" : "+v"(rk[i >> 1])); __builtin_amdgcn_sched_barrier(0); }
+        }
+        __syncthreads();
+        // 4. two hops through LDS, words then payloads: owner -> its entry's slot -> that slot's rank.  Then every slot checks its left
+        //    neighbour: two DISTINCT words that shared (fine, rem) may stand in position order instead of word order.
+        bool bad = false;
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            SLOT_FRESH();
+#pragma unroll
+            for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) exch[meta[i] >> 16] = round ? (meta[i] & 0xffffu) : ks[i];
+            __syncthreads();
+            SLOT_FRESH();
+#pragma unroll
+            for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) { if (round) meta[i] = exch[(slot0 + i * 64)]; else ks[i] = exch[(slot0 + i * 64)]; }
+            __syncthreads();
+            SLOT_FRESH();
+#pragma unroll
+            for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) exch[(rk[i >> 1] >> ((i & 1) * 16)) & 0xffffu] = round ? meta[i] : ks[i];
+            __syncthreads();
+            SLOT_FRESH();
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int p = slot0 + i * 64;
+                if (p < m) {
+                    if (round) meta[i] = exch[p];
+                    else { ks[i] = exch[p]; bad |= p > 0 && exch[p > 0 ? p - 1 : 0] > ks[i]; }
+                }
+            }
+            __syncthreads();
+        }
+        if (!__syncthreads_or(bad ? 1 : 0)) return true;
+        // 5. (about one row in a hundred) an inverted neighbour pair is swapped back; anything a single round of disjoint swaps does not
+        //    settle is left to the digit passes
+        SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) exch[(slot0 + i * 64)] = ks[i];
+        __syncthreads();
+        bad = false;
+        SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int p = slot0 + i * 64;
+            if (p < m) {
+                const bool il = p > 0 && exch[p > 0 ? p - 1 : 0] > ks[i], ir = p + 1 < m && ks[i] > exch[p + 1 < m ? p + 1 : p];
+                bad |= il && ir;                                         // three in a row: not a swap
+                meta[i] = __builtin_amdgcn_perm((uint32_t)(il ? p - 1 : (ir ? p + 1 : p)), meta[i], 0x05040100u);
+            }
+        }
+        if (__syncthreads_or(bad ? 1 : 0)) return false;               // (ks / meta untouched: still a stable arrangement by a coarsening of the word)
+        if (t == 0) atomicAdd(&g_bucket_rank_rows[1], 1ull);
+        permute_to_meta_hi();
+        SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) exch[(slot0 + i * 64)] = ks[i];
+        __syncthreads();
+        bad = false;
+        SLOT_FRESH();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int p = slot0 + i * 64;
+            if (p < m) bad |= p > 0 && exch[p > 0 ? p - 1 : 0] > ks[i];
+        }
+        return !__syncthreads_or(bad ? 1 : 0);
+      }
+    };
+
     static_assert(KW == 1 || E <= 32, "fp64: per-thread slot masks are 32 bits");
     uint32_t signm = 0u, nanm = 0u;   // fp64: bit i = slot i's key has its (ascending-key) sign bit set / is the NaN key
     uint32_t contm = 0u;              // fp64: bit i = slot i continues the equal-high-word run of the slot before it
-    for (int pass = 0; pass < 4; ++pass) {
-        if (((diff >> (pass * 8)) & 0xffu) == 0u) continue;  // constant digit among real keys: order unchanged
-        radix_pass(pass * 8, (diff_match >> (pass * 8)) & 0xffu);
+    bool ranked = false;              // block-uniform
+    if constexpr (BR) {
+        if (a.bucket_rank && m >= BR_MIN_KEYS && diff != 0u) {
+            ranked = bucket_rank();
+            if (threadIdx.x == 0) atomicAdd(&g_bucket_rank_rows[ranked ? 0 : 2], 1ull);
+        }
+    }
+    if (!ranked) {
+        for (int pass = 0; pass < 4; ++pass) {
+            if (((diff >> (pass * 8)) & 0xffu) == 0u) continue;  // constant digit among real keys: order unchanged
+            radix_pass(pass * 8, (diff_match >> (pass * 8)) & 0xffu);
+        }
     }
     if constexpr (GEN) {
         // generic form: the four passes above ran over the LOW key words; now the high words (re-derived from global
@@ -514,7 +831,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         static_assert(2 * NWORDS + BIGCAP <= NW * 256 && BIGMAX < 4096, "repair state lives in the counter area");
         uint32_t* dirtybits = cnt + NWORDS;
         uint32_t* biglist = cnt + 2 * NWORDS;
-        int8_t* delta = reinterpret_cast<int8_t*>(smem + T * E + NW * 256 + 32);   // [T*E] bytes
+        int8_t* delta = reinterpret_cast<int8_t*>(cnt + NW * 256);   // [T*E] bytes
         const int t = threadIdx.x;
         SLOT_FRESH();
 #pragma unroll
@@ -991,14 +1308,19 @@ static inline bool pick_cfg(int n, int kw, SortCfg& c) {
 
 template <int T, int E, int KW>
 static int launch_cfg(const SortArgs& a, int prows, hipStream_t st) {
-    constexpr size_t lds = ((size_t)T * E + (T / 64) * 256 + 32) * 4 + (KW == 2 ? (size_t)T * E : 0);   // fp64: + one move byte per slot
+    constexpr size_t lds = SortLds<T, E, KW>::bytes;
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
     static unsigned long long lds_set = 0ull, lds_set_gen = 0ull;   // per (T,E,KW) instantiation
     if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, KW, false>, lds, lds_set)) return rc;
     if constexpr (KW == 2)
         if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, 2, true>, lds, lds_set_gen)) return rc;
     if (KW == 2 && !a.row_flags) return FZ_ERR_WORKSPACE;
-    sort_rows_kernel<T, E, KW, false><<<prows, T, lds, st>>>(a);
+    SortArgs b = a;
+    {   // FZ_SORT_BUCKET_RANK=0: digit passes only (A/B runs, tests of the two forms against each other)
+        const char* e = getenv("FZ_SORT_BUCKET_RANK");
+        b.bucket_rank = (e && e[0] == '0') ? 0 : 1;
+    }
+    sort_rows_kernel<T, E, KW, false><<<prows, T, lds, st>>>(b);
     FZ_LAUNCH_CHECK();
     if constexpr (KW == 2) {   // rows the fast form flagged (a dirty run of > 17 equal high words): generic eight passes; all others exit at once
         sort_rows_kernel<T, E, 2, true><<<prows, T, lds, st>>>(a);
@@ -1163,6 +1485,19 @@ extern "C" int fz_select_topk_f(const void* fused, int key_bits, const int32_t* 
     else FZ_SEL(1024, 28)
 #undef FZ_SEL
     FZ_LAUNCH_CHECK();
+    return FZ_OK;
+}
+
+extern "C" int fz_sort_bucket_rank_rows(uint64_t* counts3, int reset) {
+    if (counts3) {
+        unsigned long long h[3];
+        FZ_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bucket_rank_rows), sizeof h));
+        for (int i = 0; i < 3; ++i) counts3[i] = (uint64_t)h[i];
+    }
+    if (reset) {
+        const unsigned long long z[3] = {0ull, 0ull, 0ull};
+        FZ_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_bucket_rank_rows), z, sizeof z));
+    }
     return FZ_OK;
 }
 

@@ -266,6 +266,15 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
     return order, sk, rank
 
 
+def sort_bucket_rank_rows(reset: bool = False) -> tuple[int, int, int]:
+    """(rows the bucket ranking ordered, of those rows with a swapped pair put back, rows it handed to the digit passes) on the current
+    device since the last reset (fz_sort_bucket_rank_rows; synchronises the device: tests and tools)."""
+    import ctypes
+    c = (ctypes.c_uint64 * 3)()
+    check(_lib.lib().fz_sort_bucket_rank_rows(ctypes.cast(c, ctypes.c_void_p), 1 if reset else 0), "fz_sort_bucket_rank_rows")
+    return int(c[0]), int(c[1]), int(c[2])
+
+
 def select_topk(fused: torch.Tensor, pos: torch.Tensor | None, k: int, cap: int | None = None):
     """First k entries of sort_rows_desc(fused, init_rank=pos) without sorting the rows (fz_select_topk_f + two small row sorts): the
     fused lists main() actually reads (predictions(1000), hybrid.py:537).  fused [Q, N] float32 / float64 plane, pos [Q, N] int32 plane =

@@ -102,6 +102,15 @@ int fz_sort_max_n_f64(void);
  * fp64 keys are sorted by their high word (4 radix passes) and repaired in place where equal high words hide a low-word
  * inversion; a row with such a run longer than 17 keys is flagged in the workspace and redone by a generic 8-pass launch. */
 size_t fz_sort_workspace_bytes(int key_bits, int rows, int n);
+/* fp32 rows of 4,096 .. 28,672 keys (one 1,024-thread workgroup) whose scores are spread like a ranker's -- few ties -- are ordered
+ * without the digit passes: BUCKET RANKING (16,384 buckets whose widths follow the row's own density, a counting sort by bucket, each
+ * key's rank = its bucket's first slot + the members below it, a neighbour check on the result; csrc/sort.hip).  Rows it does not
+ * suit (heavy ties, a crowd of values 24 binades below the row's largest, an overfull bucket, a check it cannot settle) take the digit
+ * passes as before; the output is the same permutation either way, bit for bit.  FZ_SORT_BUCKET_RANK=0 in the environment turns it
+ * off (A/B runs).  fz_sort_bucket_rank_rows: counts3[0] = rows ordered that way on the current device since the last reset,
+ * counts3[1] = of those, rows that needed a swapped pair put back, counts3[2] = rows that started on it and were handed to the digit
+ * passes; reset != 0 clears the counters.  Synchronises the device (tests and tools only). */
+int fz_sort_bucket_rank_rows(uint64_t* counts3, int reset);
 /* row_stats (nullable, [4][rows] fp32): mean | UNBIASED standard deviation | min | max of each list's values as float32 (fp64 keys
  * rounded first) -- torch.mean / torch.std / torch.min / torch.max of hybrid.py:254-262, a by-product of having the row in
  * registers (min and max of a sorted list are its two ends; a NaN sorts first and makes both NaN): with them min-max and z-score

@@ -69,6 +69,50 @@ def case_sort(rng):
     return f"sort f{64 if f64 else 32} rows={rows} n={n} row_len={row_len is not None}"
 
 
+def case_sort_bucket(rng):
+    """fp32 rows in the bucket ranking's range (4,096 .. 28,672 keys), spread like scores: a random smooth distribution of random
+    scale, shift and sign, with what the ranking has to survive mixed in -- values an ulp apart, tie groups, a crowd of tiny values,
+    specials -- as identity, gathered and placed sequences."""
+    rows = int(rng.integers(1, 5))
+    n = int(rng.integers(4096, 28673))
+    kind = rng.integers(0, 5)
+    if kind == 0: k = rng.normal(0, 1, (rows, n))
+    elif kind == 1: k = rng.uniform(-1, 1, (rows, n))
+    elif kind == 2: k = np.exp(rng.normal(0, rng.uniform(0.2, 3.0), (rows, n)))
+    elif kind == 3: k = rng.beta(rng.uniform(0.5, 5), rng.uniform(0.5, 5), (rows, n))
+    else: k = np.where(rng.random((rows, n)) < 0.5, rng.normal(-3, 0.3, (rows, n)), rng.gamma(2.0, 1.0, (rows, n)))
+    k = (k * 10.0 ** rng.uniform(-6, 6) * rng.choice([1.0, -1.0]) + (0.0 if rng.random() < 0.5 else rng.normal(0, 1) * 10.0 ** rng.uniform(-3, 3))).astype(np.float32)
+    for r in range(rows):
+        for _ in range(int(rng.integers(0, 6))):                      # runs of values an ulp apart, at random positions, in random order
+            v = [k[r, rng.integers(0, n)]]
+            for _ in range(int(rng.integers(1, 6))):
+                v.append(np.nextafter(v[-1], np.float32(np.inf if rng.random() < 0.5 else -np.inf)))
+            k[r, rng.choice(n, size=len(v), replace=False)] = rng.permutation(np.array(v, dtype=np.float32))
+        if rng.random() < 0.3:
+            k[r, rng.choice(n, size=int(rng.integers(2, 600)), replace=False)] = k[r, 0]                       # a tie group
+        if rng.random() < 0.2:
+            k[r, rng.choice(n, size=int(rng.integers(1, n // 3)), replace=False)] *= np.float32(2.0 ** -int(rng.integers(20, 40)))   # tiny values
+        if rng.random() < 0.15:
+            k[r, rng.integers(0, n)] = rng.choice([np.inf, -np.inf, np.nan, -0.0, 0.0])
+    mode = rng.integers(0, 3)
+    lens = rng.integers(0, n + 1, rows).astype(np.int32) if rng.random() < 0.4 else np.full(rows, n, dtype=np.int32)
+    if mode == 0:
+        o, sk, r_ = ops.sort_rows_desc(plane(k), row_len=dev(lens), want_rank=True)
+        eo, esk, er = oracle.sort_rows_desc(k, row_len=lens, want_rank=True)
+    else:
+        init = np.stack([rng.permutation(n) for _ in range(rows)]).astype(np.int32)
+        irank = np.full((rows, n), -1, dtype=np.int32)
+        for r in range(rows):
+            init[r, lens[r]:] = -1
+            irank[r, init[r, :lens[r]]] = np.arange(lens[r], dtype=np.int32)
+        if mode == 1: o, sk, r_ = ops.sort_rows_desc(plane(k), init_order=plane(init), row_len=dev(lens), want_rank=True)
+        else: o, sk, r_ = ops.sort_rows_desc(plane(k), init_rank=plane(irank), row_len=dev(lens), want_rank=True)
+        eo, esk, er = oracle.sort_rows_desc(k, init_order=init, row_len=lens, want_rank=True)
+    np.testing.assert_array_equal(o.cpu().numpy(), eo); np.testing.assert_array_equal(r_.cpu().numpy(), er)
+    np.testing.assert_array_equal(sk.cpu().numpy(), esk)
+    return f"bucket-range sort rows={rows} n={n} kind={kind} mode={mode}"
+
+
 def case_placed(rng):
     N, Q = int(rng.integers(1, 6000)), int(rng.integers(1, 4))
     planes, ranks, orders, lens = systems(rng, 1, Q, N, rng.random() < 0.5)
@@ -642,7 +686,7 @@ def case_empty(rng):
     return f"empty batches n={n}"
 
 
-CASES = [case_encoder, case_lists, case_empty, case_sort, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
+CASES = [case_encoder, case_lists, case_empty, case_sort, case_sort_bucket, case_sort_bucket, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
          case_topk_stream, case_segments, case_fused_search, case_sort_stats, case_select, case_splade_head, case_fuse_ranked, case_maxsim, case_f16_kernels, case_encoder_amp, case_rerun, case_rerun, case_sparse, case_tables, case_tables]
 
 
@@ -672,6 +716,7 @@ def main():
             print(f"[{time.time() - t0:5.0f}s] {n} cases ok; last: {desc}", flush=True); last = time.time()
     torch.cuda.synchronize()
     print(f"OK: {n} random cases in {time.time() - t0:.0f} s (seed {a.seed}): {counts}")
+    print("row sort, bucket ranking: rows ordered | of those with a pair swapped back | rows handed to the digit passes =", ops.sort_bucket_rank_rows())
 
 
 if __name__ == "__main__":
