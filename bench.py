@@ -392,7 +392,18 @@ def measure_configs(dev, N=27942):
         ms = timeit_ms(lambda: ops.dot_scores(Qs, Dn, out=So), n=20)
         out.append(dict(config="2: DPR cos-sim scoring", shape=dict(Q=Q, N=N, d=d), **roof("dot_scores_kernel", ms, 2.0 * Q * N * d, "mfma_f32")))
         ms = timeit_ms(lambda: ops.sort_rows_desc(So, want_keys=False, want_rank=True), n=10)
-        out.append(dict(config="2: DPR full ranking", shape=dict(Q=Q, N=N), **roof("sort_rows_kernel (f32 keys)", ms, Q * N * 12, "hbm")))
+        ops.sort_bucket_rank_rows(reset=True)
+        ops.sort_rows_desc(So, want_keys=False, want_rank=True)
+        br = ops.sort_bucket_rank_rows(reset=True)
+        prev = os.environ.get("FZ_SORT_BUCKET_RANK")
+        os.environ["FZ_SORT_BUCKET_RANK"] = "0"     # the same rows by the four digit passes (round 3's path; same permutation, tests/test_gpu_sort_bucket.py)
+        try:
+            ms_digits = timeit_ms(lambda: ops.sort_rows_desc(So, want_keys=False, want_rank=True), n=10)
+        finally:
+            if prev is None: os.environ.pop("FZ_SORT_BUCKET_RANK", None)
+            else: os.environ["FZ_SORT_BUCKET_RANK"] = prev
+        out.append(dict(config="2: DPR full ranking", shape=dict(Q=Q, N=N), **roof("sort_rows_kernel (f32 keys)", ms, Q * N * 12, "hbm"),
+                        ms_digit_passes=ms_digits, rows_bucket_ranked=br[0], rows_pair_swapped_back=br[1], rows_handed_to_digit_passes=br[2]))
     del Dn, Qn
 
     log("configs: DPR done")

@@ -17,6 +17,12 @@
 //                and read them back in striped order.
 // Passes whose digit is constant over the row are skipped.  LDS: up to 156 KiB of the CU's
 // 160 KiB, i.e. one 1024-thread workgroup per CU.
+//
+// Round 4: fp32 rows of 4,096 .. 28,672 keys that look like a ranker's scores (few ties) skip the digit passes: BUCKET RANKING --
+// a counting sort over 16,384 buckets whose widths follow the row's own density, every key's rank = its bucket's first slot + the
+// bucket members below it, one neighbour check on the result (see `bucket_rank` in the kernel).  239 instead of 282 vector
+// instructions per key and 42 % fewer LDS bank-conflict cycles (profiles/r04_pmc_sort_{bucket,digits}.json): 0.32 instead of 0.37 ms
+// per 1024 x 27,942 cosine scores.  Rows it does not suit are found out early and take the digit passes; same permutation either way.
 #include <type_traits>
 
 #include "common.h"
@@ -711,7 +717,8 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     uint32_t contm = 0u;              // fp64: bit i = slot i continues the equal-high-word run of the slot before it
     bool ranked = false;              // block-uniform
     if constexpr (BR) {
-        if (a.bucket_rank && m >= BR_MIN_KEYS && diff != 0u) {
+        const int npass = (int)((diff & 0xffu) != 0u) + (int)((diff & 0xff00u) != 0u) + (int)((diff & 0xff0000u) != 0u) + (int)((diff >> 24) != 0u);
+        if (a.bucket_rank && m >= BR_MIN_KEYS && npass >= 3) {          // (two digit passes -- scores within one binade -- are cheaper than the ranking)
             ranked = bucket_rank();
             if (threadIdx.x == 0) atomicAdd(&g_bucket_rank_rows[ranked ? 0 : 2], 1ull);
         }

@@ -1,5 +1,7 @@
-"""What a radix pass and the fixed parts of the row sort cost: keys with 0..4 varying bytes (fp32) and fp64 variants.  Usage: python tools/sort_pass_cost.py [lib.so ...]"""
+"""What a radix pass and the fixed parts of the row sort cost: keys with 0..4 varying bytes (fp32) and fp64 variants -- the DIGIT passes
+(the bucket ranking of fp32 rows is switched off here; tools/run_sort_ab.py compares the two).  Usage: python tools/sort_pass_cost.py [lib.so ...]"""
 import os, sys, torch
+os.environ["FZ_SORT_BUCKET_RANK"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fusion_amd import _lib, ops
 from tools.bench_sort import timeit
