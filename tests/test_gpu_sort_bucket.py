@@ -186,3 +186,36 @@ def test_a_ranking_batch_at_full_size(ops):
     t_sk, t_order = torch.sort(S, dim=1, descending=True, stable=True)
     assert torch.equal(sk, t_sk) and torch.equal(order.long(), t_order)
     assert torch.equal(torch.gather(rank, 1, order.long()), torch.arange(N, device="cuda", dtype=torch.int32).expand(Q, N))
+
+
+@pytest.mark.parametrize("n", [40000, 70001])
+def test_rows_longer_than_one_workgroup_keep_the_digit_passes(ops, oracle, n):
+    """Chunk-sort + merge (rows beyond 35,840 fp32 keys): the chunks are 35,840 keys long -- 35 keys per thread, whose LDS leaves no room
+    for the ranking's tables -- and take the digit passes; nothing tries."""
+    rng = np.random.default_rng(n)
+    k = scores("cosine", rng, 3, n)
+    (order, sk, rank), counts = both_forms(ops, lambda: ops.sort_rows_desc(plane(ops, k), want_rank=True))
+    e_order, e_sk, e_rank = oracle.sort_rows_desc(k, want_rank=True)
+    np.testing.assert_array_equal(order.cpu().numpy(), e_order)
+    np.testing.assert_array_equal(rank.cpu().numpy(), e_rank)
+    np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)
+    assert counts == (0, 0, 0), counts
+
+
+def test_statistics_of_a_ranking_cut_to_its_top_k(ops):
+    """stats_len: mean / std / min / max over the first k entries of the SORTED list, taken from the sorted registers -- after the bucket ranking
+    as after the digit passes (hybrid.py:254-262 on a return_topk list)."""
+    rng = np.random.default_rng(21)
+    rows, n = 6, 27942
+    k = scores("cosine", rng, rows, n)
+    lens = np.array([1000, 500, 27942, 1, 20000, 4096], dtype=np.int32)
+    st = torch.empty((4, rows), dtype=torch.float32, device="cuda")
+    (order, sk, rank, stats), counts = both_forms(ops, lambda: ops.sort_rows_desc(plane(ops, k), want_rank=True, stats_out=st, stats_len=dev(lens)) + (st.clone(),))
+    assert counts[0] == rows, counts
+    srt = -np.sort(-k.astype(np.float64), axis=1)
+    for r in range(rows):
+        head = srt[r, :lens[r]]
+        np.testing.assert_allclose(stats[0, r].item(), head.mean(), rtol=1e-6, atol=1e-7)
+        if lens[r] > 1:
+            np.testing.assert_allclose(stats[1, r].item(), head.std(ddof=1), rtol=1e-5)
+        assert stats[2, r].item() == np.float32(head.min()) and stats[3, r].item() == np.float32(head.max())

@@ -54,8 +54,6 @@ def main():
     ok &= both("dpr f32 order+keys+rank+stats", lambda: ops.sort_rows_desc(S, want_rank=True, stats_out=st) + (st,))
     ok &= both("dpr f32 order+rank", lambda: ops.sort_rows_desc(S, want_keys=False, want_rank=True))
     # bm25 (bench.py's synthetic index and query terms)
-    class A: pass
-    a = A(); a.queries = Q; a.corpus = N; a.dim = 64; a.encode_buckets = 1; a.encode_mode = "none"; a.overlap_bm25 = False
     rng = np.random.default_rng(7)
     V, lens, tok, doc, p = bench.synth_bm25_index(N, np.random.default_rng(99))
     key = tok.astype(np.int64) * N + doc
