@@ -67,6 +67,9 @@ __device__ unsigned long long g_bucket_rank_rows[3];
 // Bucket ranking (see sort_rows_kernel): fine / coarse bucket counts and the words of LDS its tables take in the counter area.
 constexpr int BR_FINE = 16384, BR_COARSE = 1024, BR_WORDS = BR_FINE / 2 + BR_COARSE + 1024;   // + one bit per slot (bucket starts)
 constexpr int BR_MIN_KEYS = 4096, BR_MAX_BUCKET = 128;
+#ifndef BR_STRAIGHT
+#define BR_STRAIGHT 6                               // bucket members read without a loop by the rank phase
+#endif
 template <int T, int E, int KW> struct SortLds {
     static constexpr bool br = T == 1024 && KW == 1 && (size_t)(32 + T * E + BR_WORDS) * 4 <= 160 * 1024;
     static constexpr size_t area = (size_t)(T / 64) * 256 * 4 + (KW == 2 ? (size_t)T * E : 0);   // counters (+ fp64: one move byte per slot)
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         __syncthreads();
         // 3. rank, slot by slot: the thread of slot d finds d's bucket in the bitmap of bucket starts and counts the members below its
         //    entry -- the lanes of a wave look at 64 consecutive slots, i.e. at the same few buckets (broadcast reads, equal trip counts).
-        //    Straight-line for buckets of up to eight slots that begin and end within a bitmap word of d's (the rest: rolled loops).
+        //    Straight-line for buckets of up to six slots that begin and end within a bitmap word of d's (the rest: rolled loops).
         //    The thread keeps 16 bits per slot: the rank of the entry that sits there.
         static_assert(E % 2 == 0, "two ranks per register");
         uint32_t rk[E / 2];
@@ -634,15 +637,15 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             }
             const uint32_t st = (uint32_t)(ws * 32 + 31 - __builtin_clz(z));
             const uint32_t en = (uint32_t)(we * 32 + __builtin_ctz(z2));
-            uint32_t v[8];
+            uint32_t v[BR_STRAIGHT];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = exch[st + e];           // (beyond the bucket: other entries or the words behind exch[]; not counted)
+            for (int e = 0; e < BR_STRAIGHT; ++e) v[e] = exch[st + e];           // (beyond the bucket: other entries or the words behind exch[]; not counted)
             const uint32_t n = en - st;
             uint32_t r = st;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r += ((uint32_t)e < n && v[e] < mine) ? 1u : 0u;
-            if (n > 8u) {
-                for (uint32_t j = st + 8u; j < en; ++j) r += exch[j] < mine ? 1u : 0u;
+            for (int e = 0; e < BR_STRAIGHT; ++e) r += ((uint32_t)e < n && v[e] < mine) ? 1u : 0u;
+            if (n > (uint32_t)BR_STRAIGHT) {
+                for (uint32_t j = st + (uint32_t)BR_STRAIGHT; j < en; ++j) r += exch[j] < mine ? 1u : 0u;
             }
             if (i & 1) rk[i >> 1] |= r << 16; else rk[i >> 1] = r;
             if (i & 1) { asm volatile("" : "+v"(rk[i >> 1])); __builtin_amdgcn_sched_barrier(0); }
