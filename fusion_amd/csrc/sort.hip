@@ -425,18 +425,20 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     // ---- bucket ranking: the stable order by the 32-bit sort word WITHOUT the digit passes ------------------------------------------
     // A row of a ranker's scores is a sample of a smooth distribution: spread over 16,384 buckets whose widths follow the row's own
     // density, a key shares its bucket with one or two others, and its rank is the bucket's first slot plus the number of bucket
-    // members that precede it -- a handful of comparisons where the four digit passes spend ~8 ballots per key bit.
-    //   0. range [wmin, wmax] of the sort words; t = w - wmin in 1,024 equal COARSE buckets (c = t >> s1);
+    // members that precede it -- a handful of comparisons where the four digit passes spend a ballot per key bit.
+    //   0. range of the sort words; t(w) = w counted from the row's first word, with the unused exponents between the smallest positive
+    //      and negative magnitudes cut out and magnitudes 24 binades under the largest clamped; 1,024 equal COARSE buckets (c = t >> s1);
     //   1. a histogram of 4 keys per thread over the coarse buckets -> coarse bucket c is cut into nsub[c] ~ its share of the keys FINE
     //      buckets: fine(w) = base[c] + floor(frac * nsub[c]), rem(w) = the next 16 bits of that product.  (fine, rem) is a monotone
     //      function of w, exact (distinct words, distinct values) wherever a coarse bucket holds more than a few dozen keys;
     //   2. counting sort by fine bucket: packed 16-bit LDS counters (atomic add), exclusive scan, a second atomic add on the
-    //      offsets hands out the slots; a slot holds rem << 16 | sequence position;
-    //   3. every key counts the members of its bucket below its own (rem, position): that is its rank;
-    //   4. keys and payloads move to their ranks (one exchange, as after a digit pass), and every slot checks its left neighbour:
-    //      two DISTINCT words that shared (fine, rem) may be in position order instead of word order.  Then -- or when a bucket holds more
-    //      than BR_MAX_BUCKET keys (heavy ties: BM25's zeros), or the sequence has holes -- the digit passes run after all: the
-    //      arrangement is a stable permutation by a coarsening of the word, so they finish it to the same result.
+    //      offsets hands out the slots; a slot holds rem << 16 | sequence position; a bitmap marks the buckets' first slots;
+    //   3. the thread of SLOT d counts the members of d's bucket below d's entry: that entry's rank (16 bits per slot);
+    //   4. words, then payloads, travel owner -> entry slot -> rank through LDS, and every slot checks its left neighbour: two DISTINCT
+    //      words that shared (fine, rem) stand in position order instead of word order;
+    //   5. such a pair is swapped back.  Anything else -- three in a row; and before that: rows with heavy ties, a crowd at the floor, a
+    //      bucket over BR_MAX_BUCKET keys, holes in the sequence, fewer than three varying key bytes -- is left to the digit passes: the
+    //      arrangement is at every point a stable permutation by a coarsening of the word, so they finish it to the same result.
     // All integer arithmetic on the sort word: NaN / inf / signed zeros are whatever desc_key made of them.
     constexpr bool BR = !GEN && SortLds<T, E, KW>::br;
     auto bucket_rank = [&]() __attribute__((always_inline)) -> bool {
