@@ -23,7 +23,8 @@ over the ranks, queries encoded data-parallel (all-gather of the [Q, 768] embedd
 streaming top-1000, ONE RCCL all-gather of the per-shard [Q, k] lists + identical local merge.  Strong scaling (the
 corpus is fixed).  `--workload lleqa` at N > 1 gives query-sharded replicas with no data-path collective instead.
 
-Prints ONE JSON line on rank 0.
+Prints ONE compact JSON line on rank 0's stdout (headline + config + stages + roofline + cpu_baseline + parity + targets: a few kB,
+size pinned by tests/test_bench_line_cpu.py); the full record (roofline_all, configs_measured ...) goes to bench_detail.json and stderr.
 """
 import argparse
 import json
@@ -885,6 +886,93 @@ def e_sample(dev, n, d):
     return torch.randn((n, d), generator=g, device=dev)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The ONE stdout line: compact by construction.  Round 4's line grew to 20 kB and the driver's record came back unparsed;
+# everything bulky (`roofline_all`, `configs_measured`, per-rank device names ...) now goes to bench_detail.json next to this
+# script (and gpurun_out/ when present) and to stderr, and tests/test_bench_line_cpu.py pins the line's size.
+# ---------------------------------------------------------------------------------------------------------------------
+LINE_BUDGET = 6000                                    # bytes; the test asserts it on recorded detail files
+HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+
+
+def _r(x, nd=4):
+    """Round floats for the compact line (value / ms_per_step keep every digit); non-finite floats become None: strict JSON."""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return round(x, nd) if abs(x) < 1e6 else round(x, 1)
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def _short(s, n=110):
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 3] + "..."
+
+
+def compact_line(res):
+    """The headline dict the driver parses, from the full result `res` (what bench_detail.json holds)."""
+    line = {k: res[k] for k in HEAD_KEYS if k in res}
+    cfg = dict(res.get("config", {}))
+    cfg["workload"] = _short(cfg.get("workload", ""), 240)
+    line["config"] = _r(cfg)
+    if "stages_ms" in res:
+        line["stages_ms"] = _r(res["stages_ms"])
+    if "score_fuse_qps_per_gpu" in res:
+        line["score_fuse_qps_per_gpu"] = _r(res["score_fuse_qps_per_gpu"], 1)
+    rl = res.get("roofline")
+    if rl:
+        rl = dict(rl)
+        if rl.get("traffic_source"):
+            rl["traffic_source"] = rl["traffic_source"].split(" ")[0]            # the file name only
+        rl["kernel"] = _short(rl.get("kernel", ""), 80)
+        line["roofline"] = _r(rl, 5)
+    cb = res.get("cpu_baseline")
+    if cb:
+        cb = dict(cb)
+        cb["sample"] = _short(cb.get("sample", ""), 118)
+        line["cpu_baseline"] = _r(cb)
+    if "parity_sample" in res:
+        line["parity_sample"] = {k: (float(f"{v:.3g}") if isinstance(v, float) else v) for k, v in res["parity_sample"].items()}
+    ns = res.get("north_star_targets")
+    if ns:                                                                       # bare numbers: value, target, met
+        line["north_star_targets"] = {k: ({"value": _r(v["value"]), "target": v["target"], "met": v["met"]} if v else None) for k, v in ns.items()}
+    for k in ("collective", "same_workload_one_gpu", "rehearsal"):               # the N > 1 line's own pieces
+        if k in res:
+            v = res[k]
+            line[k] = _r({kk: _short(vv, 60) for kk, vv in v.items() if kk != "what"}) if isinstance(v, dict) else _short(v, 100)
+    if "sharded_equals_single_gpu" in res:
+        line["sharded_equals_single_gpu"] = {k: v for k, v in res["sharded_equals_single_gpu"].items() if k != "what"}
+    if "ranks" in res:
+        line["ranks"] = len(res["ranks"])
+    if "shard_rows" in res:
+        line["shard_rows"] = res["shard_rows"]
+    line["detail"] = "bench_detail.json"
+    return line
+
+
+def emit(res):
+    """Full record -> bench_detail.json (+ gpurun_out/) and stderr; the compact line -> stdout, alone, last."""
+    full = json.dumps(res)
+    for path in (os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(full + "\n")
+        except OSError as ex:
+            log(f"could not write {path}: {ex}")
+    print("[bench detail] " + full, file=sys.stderr, flush=True)
+    line = json.dumps(compact_line(res), allow_nan=False)
+    if len(line) > LINE_BUDGET:
+        log(f"compact line is {len(line)} B > {LINE_BUDGET}: dropping stages_ms")
+        slim = compact_line(res); slim.pop("stages_ms", None)
+        line = json.dumps(slim, allow_nan=False)
+    sys.stderr.flush()
+    print(line, flush=True)
+
+
 def launcher_argv(argv, n_gpus, port):
     """`python bench.py --gpus N ...` outside torch.distributed.run: the command line of the N-rank job this process starts as a CHILD
     (one rank per GPU, RCCL over xGMI; 127.0.0.1 rendezvous: the container hostname may not resolve) -- the driver's own form."""
@@ -953,7 +1041,7 @@ def main():
         if args.rehearsal:
             res["rehearsal"] = "ranks share devices: control-flow rehearsal only, the numbers mean nothing"
         if rank == 0:
-            print(json.dumps(res))
+            emit(res)
         if dist:
             torch.cuda.synchronize()
             dist.barrier()                      # rank 0's extras (one-GPU reference, CPU baseline) end before any rank tears the group down
@@ -1055,7 +1143,7 @@ def main():
                 elif name.startswith("boundary: Aggregator.fuse rrf"):
                     res["config"]["boundary_rrf_ms_per_query"] = round(c["ms_per_query"], 2)
         res["north_star_targets"] = north_star_targets(res)
-        print(json.dumps(res))
+        emit(res)
     if dist:
         dist.destroy_process_group()
 
