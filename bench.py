@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32, dense
 MFMA_F16_PEAK_TF = 2500.0      # v_mfma_f32_32x32x16_f16, dense
 METRIC = "queries/sec end-to-end (encode+score+fuse), LLeQA test; recall@500 parity"
-TRAFFIC_PROFILES = ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
+TRAFFIC_PROFILES = ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
 # the stages of the step that ARE the path's kernels (scoring, ranking, fusion behind the C ABI).  The bench line's
 # `roofline` names the one of THESE that takes the most time per step; the encoder's kernels (HIP and vendor) stay in `roofline_all`.
 PATH_STAGES = ("dpr_score", "dpr_rank", "bm25_score", "bm25_rank", "fuse_rrf", "final_order")
@@ -67,6 +67,7 @@ def parse():
     p.add_argument("--overlap-bm25", action="store_true", help="run the BM25 branch on a second stream next to the encoder (measured: no gain, the encoder saturates the GPU)")
     p.add_argument("--no-gemm-tuning", action="store_true",
                    help="leave the encoder's fp32 Linears to the library heuristics instead of PyTorch TunableOp (fusion_amd/tuned/gemm_gfx950.csv)")
+    p.add_argument("--two-kernel-fuse", action="store_true", help="round 4's step: fz_fuse_rank_f64 then fz_sort_rows_desc_placed on its float64 plane (A/B against the fused sort)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-configs", action="store_true", help="skip the configs_measured block (configs 2-5 timed live after the headline region)")
     p.add_argument("--no-one-gpu-reference", action="store_true",
@@ -201,6 +202,7 @@ def build_lleqa(args, dev, rank):
     st["buckets"] = args.encode_buckets
     st["encode_mode"] = args.encode_mode
     st["overlap"] = args.overlap_bm25
+    st["two_kernel_fuse"] = args.two_kernel_fuse
     st["host"] = dict(idf=idf, toff=toff, pd=pd, tf=tf, lens=lens, qoff=qoff, qterms=qterms)
     st["bm25_postings"] = int(df[qterms].sum())     # postings the batch's query terms touch (terms repeat: bm25.py:152 does not de-duplicate)
     return st
@@ -248,9 +250,12 @@ def step_lleqa(st, ev=None):
         torch.cuda.current_stream().wait_stream(side)
         for t in (B, o_b, r_b):
             t.record_stream(torch.cuda.current_stream())
-    fused = ops.fuse_rank([r_b, r_d], st["lens2"], "rrf")
-    if ev: ev.mark("fuse_rrf")
-    order, scores, _ = ops.sort_rows_desc(fused, init_rank=r_b, covers_all=True)   # ties keep BM25's (system 0) order; full lists, as fuse_device calls it
+    if st.get("two_kernel_fuse"):   # round 4's form (--two-kernel-fuse): the float64 fused plane written by one kernel and sorted by the next
+        fused = ops.fuse_rank([r_b, r_d], st["lens2"], "rrf")
+        if ev: ev.mark("fuse_rrf")
+        order, scores, _ = ops.sort_rows_desc(fused, init_rank=r_b, covers_all=True)
+    else:   # as Aggregator.fuse_device calls it: RRF formed per key in the final sort's load phase; ties keep BM25's (system 0) order; full lists
+        order, scores, _ = ops.sort_rank_fused([r_b, r_d], st["lens2"], "rrf", init_rank=r_b, covers_all=True)
     if ev: ev.mark("final_order")
     return order, scores, (S, B, q_emb)
 
@@ -278,9 +283,12 @@ def algorithmic_work(st):
         # BM25: every touched posting read once (doc id + tf, 8 B) + the fp64 score plane written once
         "bm25_score": dict(kernel="bm25_kernel", bound="hbm", work=st.get("bm25_postings", 0) * 8 + e * 8),
         "bm25_rank": dict(kernel="sort_rows_kernel (f64 keys)", bound="hbm", work=e * (8 + 4 + 4)),
-        "fuse_rrf": dict(kernel="fuse_rank_kernel", bound="hbm", work=e * (2 * 4 + 8)),
-        "final_order": dict(kernel="sort_rows_kernel (f64 keys, placed)", bound="hbm", work=e * (8 + 4 + 4 + 8)),
     })
+    if st.get("two_kernel_fuse"):
+        w["fuse_rrf"] = dict(kernel="fuse_rank_kernel", bound="hbm", work=e * (2 * 4 + 8))
+        w["final_order"] = dict(kernel="sort_rows_kernel (f64 keys, placed)", bound="hbm", work=e * (8 + 4 + 4 + 8))
+    else:   # two rank planes in, order + fused float64 scores out: the float64 plane between fusion and sort does not exist
+        w["final_order"] = dict(kernel="sort_rows_kernel<FUSE> (rrf formed on load, f64 keys, placed)", bound="hbm", work=e * (2 * 4 + 4 + 8))
     return w
 
 
@@ -290,8 +298,8 @@ def profiled_traffic(stage, st):
     shape it was collected on, otherwise None.  Returns (bytes, source file)."""
     if (st["Q"], st["N"], st["d"]) != (1024, 27942, 768):
         return None, None
-    pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1,", "bm25_rank": "sort_rows_kernel<1024, 28, 2, false",
-            "final_order": "sort_rows_kernel<1024, 28, 2, false", "fuse_rrf": "fuse_rank_kernel", "bm25_score": "bm25_kernel", "encode_attn": "attn_varlen_kernel",
+    pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1,", "bm25_rank": "sort_rows_kernel<1024, 28, 2, false, false",
+            "final_order": "sort_rows_kernel<1024, 28, 2, false, true", "fuse_rrf": "fuse_rank_kernel", "bm25_score": "bm25_kernel", "encode_attn": "attn_varlen_kernel",
             "encode_gelu": "gelu_kernel", "encode_ln": "add_layernorm_kernel"}
     for name in TRAFFIC_PROFILES:
         try:
@@ -488,6 +496,10 @@ def measure_configs(dev, N=27942):
         # float64 fused rows over full lists (the BM25 + DPR RRF hybrid of the headline step): the full lists Aggregator.fuse returns vs the
         # top-1000 form main() reads (hybrid.py:537; rows selected, not sorted)
         two = {n: systems[n] for n in ("bm25", "dpr")}
+        lens_two = torch.stack([s.lens for s in two.values()]).contiguous()
+        ms = timeit_ms(lambda: ops.fuse_rank([s.rank for s in two.values()], lens_two, "rrf"), n=10)
+        out.append(dict(config="1: rrf fusion alone (fuse_rank_kernel, S=2; the full-list path forms it inside the final sort since round 5, long rows and the top-k selection still launch it)",
+                        shape=dict(Q=Q, N=N, S=2), **roof("fuse_rank_kernel", ms, Q * N * (2 * 4 + 8), "hbm")))
         ms_full = timeit_ms(lambda: Aggregator.fuse_device(two, "rrf", None, {}, {}), n=5)
         ms_top = timeit_ms(lambda: Aggregator.fuse_device(two, "rrf", None, {}, {}, topk=1000), n=5)
         out.append(dict(config="1: Aggregator.fuse_device rrf BM25+DPR, topk=1000 (fz_select_topk_f + two 2k-key sorts; NOT what Aggregator.fuse returns) vs the full lists",
@@ -606,12 +618,12 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
 
         def step(mark):
             mark("start")
-            B = ops.bm25_scores(bm["toff"], bm["pdoc"], bm["ptf"], bm["idf"], bm["doc_len"], bm["avgdl"], 2.5, 0.2, qoff, qterms, Q, N, doc_norm=bm["doc_norm"],
-                                slice_off=bm["slice_off"])
+            B, B32 = ops.bm25_scores(bm["toff"], bm["pdoc"], bm["ptf"], bm["idf"], bm["doc_len"], bm["avgdl"], 2.5, 0.2, qoff, qterms, Q, N, doc_norm=bm["doc_norm"],
+                                     slice_off=bm["slice_off"], want_f32=True)      # as BM25.search_device: the float32 plane from the same launch
             mark("bm25_score")
             st4 = torch.empty((4, Q), dtype=torch.float32, device=dev)
             o_b, sk_b, r_b = ops.sort_rows_desc(B, want_rank=True, stats_out=st4)
-            sys_b = RankedSystem(scores=ops.f64_to_f32(B), order=o_b, rank=r_b, lens=torch.full((Q,), N, dtype=torch.int32, device=dev), ids=ids_np,
+            sys_b = RankedSystem(scores=B32, order=o_b, rank=r_b, lens=torch.full((Q,), N, dtype=torch.int32, device=dev), ids=ids_np,
                                  sorted_scores=sk_b, full=True, scores64=B, score_sorted=True, stats4=st4)
             mark("bm25_rank")
             e = enc["dpr"].encode_ids_packed(qids_d, qlen); mark("dpr_encode")
@@ -1161,6 +1173,8 @@ def north_star_targets(res):
     for c in res.get("configs_measured", []):
         if c.get("config", "").startswith("4: nsf") and c.get("shape", {}).get("Q") == 1024:
             fuse[c["config"][3:]] = c["frac"]
+        elif c.get("config", "").startswith("1: rrf fusion alone") and c.get("shape", {}).get("Q") == 1024:
+            fuse["rrf S=2, fuse_rank_kernel alone"] = c["frac"]
     best = max(fuse.values()) if fuse else None
     out["fuse_hbm_frac"] = {"value": best, "target": 0.90, "met": bool(best is not None and best >= 0.90), "all": fuse, "peak_GBs": HBM_PEAK_GBS,
                             "note": "fractions of the 8.0 TB/s spec; MI355X_MICROARCH.md measures 6.29 TB/s for a float4 copy on this part (0.79 of spec), "

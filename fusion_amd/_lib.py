@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FUSION_AMD_LIB: another build of the same library (the host-sanitized one of `make -C fusion_amd/csrc hostasan`); same ABI check applies
 LIB_PATH = os.environ.get("FUSION_AMD_LIB") or os.path.join(_HERE, "libfusion_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 FZ_OK, FZ_ERR_ARG, FZ_ERR_UNSUPPORTED, FZ_ERR_HIP, FZ_ERR_WORKSPACE = 0, -1, -2, -3, -4
 NORMS = {"min-max": 1, "z-score": 2, "arctan": 3, "percentile-rank": 4, "normal-curve-equivalent": 5}
@@ -51,6 +51,8 @@ _PROTOS = {
     "fz_sort_bucket_rank_rows": (_i, [_vp, _i]),
     "fz_sort_rows_desc": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_sort_rows_desc_placed": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fz_sort_rank_fused_desc": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fz_rrf_terms_f64": (_i, [_i, _i, _vp, _vp]),
     "fz_select_topk_f": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fz_fuse_rank_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fz_row_stats_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -85,6 +87,7 @@ _PROTOS = {
     "fz_bm25_slice_docs": (_i, []),
     "fz_bm25_slice_offsets": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "fz_bm25_scores_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "fz_bm25_scores_f64_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
     "fz_tune_max_gold": (_i, []),
     "fz_gold_ranks_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fz_gold_ranks_f64w": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

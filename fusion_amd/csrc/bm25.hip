@@ -17,6 +17,8 @@ struct Bm25Args {
     double avgdl, k1, b;
     const int64_t* qoff; const int32_t* qterms;
     int N; double* scores; int lds;
+    float* scores32; int lds32;   // nullable: the same scores rounded to float32 (torch.tensor(scores, dtype=float32), hybrid.py:255), written
+                                  //   from the same LDS accumulators -- the separate plane-sized conversion pass (fz_f64_to_f32) goes away
 };
 
 // LDS-resident accumulators: one workgroup = (query, slice of BM25_SLICE documents).  The random read-modify-writes of
@@ -102,6 +104,10 @@ __global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
     __syncthreads();
     double* __restrict__ row = a.scores + (size_t)q * a.lds + d0;
     for (int j = threadIdx.x; j < n; j += blockDim.x) row[j] = acc[j];
+    if (a.scores32) {
+        float* __restrict__ row32 = a.scores32 + (size_t)q * a.lds32 + d0;
+        for (int j = threadIdx.x; j < n; j += blockDim.x) row32[j] = (float)acc[j];
+    }
 }
 
 __global__ void bm25_slice_offsets_kernel(const int64_t* __restrict__ toff, const int32_t* __restrict__ pdoc, int V, int NS, int64_t* __restrict__ out) {
@@ -145,10 +151,17 @@ extern "C" int fz_bm25_slice_offsets(const int64_t* toff, const int32_t* pdoc, i
 extern "C" int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf,
                                   const int32_t* doc_len, const double* doc_norm, const int64_t* slice_off, double avgdl, double k1, double b,
                                   const int64_t* qoff, const int32_t* qterms, int Q, int N, double* scores, int lds, void* stream) {
-    if (Q < 0 || N < 0 || lds < N) return FZ_ERR_ARG;
+    return fz_bm25_scores_f64_f32(toff, pdoc, ptf, idf, doc_len, doc_norm, slice_off, avgdl, k1, b, qoff, qterms, Q, N, scores, lds, nullptr, 0, stream);
+}
+
+extern "C" int fz_bm25_scores_f64_f32(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf,
+                                      const int32_t* doc_len, const double* doc_norm, const int64_t* slice_off, double avgdl, double k1, double b,
+                                      const int64_t* qoff, const int32_t* qterms, int Q, int N, double* scores, int lds, float* scores32,
+                                      int lds32, void* stream) {
+    if (Q < 0 || N < 0 || lds < N || (scores32 && lds32 < N)) return FZ_ERR_ARG;
     if (Q == 0 || N == 0) return FZ_OK;           // empty tensors carry null pointers
     if (!toff || !idf || !doc_len || !qoff || !scores) return FZ_ERR_ARG;
-    Bm25Args a{toff, pdoc, ptf, idf, doc_len, doc_norm, slice_off, avgdl, k1, b, qoff, qterms, N, scores, lds};
+    Bm25Args a{toff, pdoc, ptf, idf, doc_len, doc_norm, slice_off, avgdl, k1, b, qoff, qterms, N, scores, lds, scores32, lds32};
     constexpr size_t lds_bytes = (size_t)BM25_SLICE * sizeof(double);
     static unsigned long long lds_set = 0ull;
     if (int rc = raise_lds_limit((const void*)bm25_kernel, lds_bytes, lds_set)) return rc;

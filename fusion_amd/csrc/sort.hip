@@ -18,7 +18,7 @@
 // Passes whose digit is constant over the row are skipped.  LDS: up to 156 KiB of the CU's
 // 160 KiB, i.e. one 1024-thread workgroup per CU.
 //
-// Round 4: fp32 rows of 4,096 .. 28,672 keys that look like a ranker's scores (few ties) skip the digit passes: BUCKET RANKING --
+// Round 4: fp32 rows of 8,193 .. 28,672 columns (a 1,024-thread workgroup's rows) with at least 4,096 keys in them that look like a ranker's scores (few ties) skip the digit passes: BUCKET RANKING --
 // a counting sort over 16,384 buckets whose widths follow the row's own density, every key's rank = its bucket's first slot + the
 // bucket members below it, one neighbour check on the result (see `bucket_rank` in the kernel).  239 instead of 282 vector
 // instructions per key and 42 % fewer LDS bank-conflict cycles (profiles/r04_pmc_sort_{bucket,digits}.json): 0.32 instead of 0.37 ms
@@ -58,6 +58,14 @@ struct SortArgs {
     const int32_t* stats_len;    // nullable [rows]: the statistics cover the first stats_len[row] entries of the SORTED list (a ranking
                                  //   truncated to its top-k: PLAID-style short lists, return_topk); fp32 keys only
     int bucket_rank;             // 1 = rows of a 1024-thread workgroup are ordered by the bucket ranking where it applies (set by the launcher)
+    // FUSE (fz_sort_rank_fused_desc): there is no key plane -- the float64 key of column j is the rank fusion of hybrid.py:248-252,301-304,
+    // formed on load from the S rank planes exactly as fuse_rank_kernel (fuse.hip) forms it: 0.0 + sum over the systems, in system order, of
+    // 1/(60 + r + 1) (rrf) or (n - r + 1)/n (bcf) over the systems that list the document (r >= 0); -inf when none does
+    const int32_t* fuse_ranks[FZ_MAX_SYSTEMS];   // [rows][key_row_stride] each
+    const int32_t* fuse_lens;    // [S][fuse_rows] list lengths (bcf's n)
+    int fuse_S, fuse_method, fuse_rows;
+    int fuse_first_is_pos;       // placed form with init_rank == fuse_ranks[0] (every list full: first-insertion order = system 0's ranking):
+                                 //   the position just loaded IS system 0's rank, its plane is not read a second time
 };
 
 // rows the bucket ranking ordered | of those, rows whose neighbour check swapped a pair back | rows it gave up on after starting
@@ -74,13 +82,40 @@ template <int T, int E, int KW> struct SortLds {
     static constexpr size_t bytes = (size_t)(32 + T * E) * 4 + (br && area < (size_t)BR_WORDS * 4 ? (size_t)BR_WORDS * 4 : area);
 };
 
+// 1.0 / x in float64 for an integer-valued x in [1, 2^20]: the division's own Newton-Raphson steps (LLVM lowers an f64 division to
+// v_div_scale x2, v_rcp_f64, five v_fma_f64, v_mul_f64, v_div_fmas, v_div_fixup; with a numerator of 1.0 and a denominator that needs no
+// scaling the scale / fixup steps are identities and the multiplication is by 1.0) -- seven instructions instead of twelve, the same
+// correctly rounded quotient: tests/test_gpu_rank_fused.py compares every x the sort can see (and 2^20 beyond) with the IEEE division.
+__device__ __forceinline__ double recip_small_int_f64(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);       // the residual of the quotient (the numerator is 1.0: q = y)
+    return __builtin_fma(e, y, y);
+}
+__global__ void rrf_terms_kernel(int count, int fast, double* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < count) out[r] = fast ? recip_small_int_f64((double)(60 + r + 1)) : 1.0 / (double)(60 + r + 1);
+}
+
 // GEN (fp64 only): the generic eight-pass form, run as a second launch for the rows the fast form flags (see below).
-template <int T, int E, int KW, bool GEN>
+// MODE: which of the kernel's many callers an instantiation serves -- what is not served is gone at compile time, and with it the row
+// pointers and flags that otherwise stay live from the prologue to the output phase (they were the shipped hot kernels' spills):
+//   SORT_ANY   every feature (chunked long rows, segmented top-k lists, column / id maps, id outputs);
+//   SORT_ROWS  whole rows of one plane: the rankers' sorts and the final order (identity / gathered / placed sequence, statistics);
+//   SORT_FUSE  SORT_ROWS whose float64 keys are formed from rank planes on load (fz_sort_rank_fused_desc), no statistics.
+enum { SORT_ANY = 0, SORT_ROWS = 1, SORT_FUSE = 2 };
+template <int T, int E, int KW, bool GEN, int MODE = SORT_ANY>
 __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
+    constexpr bool FUSE = MODE == SORT_FUSE, LEAN = MODE != SORT_ANY;
     static_assert(!GEN || KW == 2, "the generic form exists for fp64 keys only");
+    static_assert(!FUSE || KW == 2, "rank fusion forms float64 keys");
     constexpr int NW = T / 64;
     constexpr uint32_t SENT = 0xffffffffu;
     constexpr int LG = (KW == 2) ? 7 : 14;         // global loads in flight per thread before the first use (one HBM latency per group)
+    constexpr int LGF = FUSE ? 4 : LG;             // ... in the gathered / plain load phase (FUSE: the per-key sums need the registers)
     constexpr int WALK = 16;                        // longest equal-high-word run the fp64 repair re-sorts in place
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* misc = smem;                         // [32]
@@ -88,12 +123,13 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     uint32_t* cnt = smem + 32 + T * E;             // [NW*256] (plain LDS pointer: volatile would lower to flat sc0 sc1 accesses); the bucket
                                                    //   ranking's tables (BR_WORDS words) start here too, over the fp64 move bytes behind it
 
+    // LEAN serves whole rows only (the launcher sees to it): no chunks, segments, column / id maps -- known at compile time
     const int prow = blockIdx.x;
-    const int row = prow / a.chunks;
-    const int chunk = prow - row * a.chunks;
+    const int row = LEAN ? prow : prow / a.chunks;
+    const int chunk = LEAN ? 0 : prow - row * a.chunks;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
-    const int c0 = chunk * a.chunk_len;
+    const int c0 = LEAN ? 0 : chunk * a.chunk_len;
     // this thread's first slot; SLOT_FRESH() makes it opaque again so that the 28 per-item slot numbers are re-derived (one add)
     // in every phase instead of being kept live -- 28 registers -- from the first phase to the last
     int slot0 = w * E * 64 + lane;
@@ -107,7 +143,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     m = m < 0 ? 0 : (m > a.chunk_len ? a.chunk_len : m);
     // statistics by-product (block-uniform): over the whole list from the load phase, or -- stats_len -- over the first slen entries
     // of the sorted list from the registers of the output phase
-    const bool st_on = a.row_stats && a.chunks == 1;
+    const bool st_on = !FUSE && a.row_stats && (LEAN || a.chunks == 1);
     int slen = (st_on && a.stats_len) ? a.stats_len[row] : m;
     slen = slen < 0 ? 0 : (slen > m ? m : slen);
     const bool st_prefix = st_on && slen < m;
@@ -122,7 +158,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
 
     // uniform row bases + 32-bit per-lane indices (saddr+voffset addressing; no 64-bit per-item addresses)
     const size_t krow = (size_t)row * a.key_row_stride;
-    const bool seg = a.seg_len < a.n_total;  // block-uniform: segmented rows ([G][rows][k] top-k lists)
+    const bool seg = !LEAN && a.seg_len < a.n_total;  // block-uniform: segmented rows ([G][rows][k] top-k lists)
     const float* __restrict__ kf = reinterpret_cast<const float*>(a.keys) + krow;
     const uint2* __restrict__ kd = reinterpret_cast<const uint2*>(a.keys) + krow;   // a double as its (low, high) words
     const int32_t* __restrict__ init_row = a.init_order ? a.init_order + krow : nullptr;
@@ -134,12 +170,12 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     const int lim = m < a.out_limit ? m : a.out_limit;
     const size_t obase = (size_t)row * a.out_row_stride + (size_t)chunk * a.out_chunk_stride;
     int32_t* __restrict__ o_order = a.order ? a.order + obase : nullptr;
-    int64_t* __restrict__ o_ids = a.out_ids ? a.out_ids + obase : nullptr;
+    int64_t* __restrict__ o_ids = (!LEAN && a.out_ids) ? a.out_ids + obase : nullptr;
     float* __restrict__ o_kf = a.sorted_keys ? reinterpret_cast<float*>(a.sorted_keys) + obase : nullptr;
     uint32_t* __restrict__ o_kw = a.sorted_keys ? reinterpret_cast<uint32_t*>(reinterpret_cast<double*>(a.sorted_keys) + obase) : nullptr;   // fp64 keys, word by word
     int32_t* __restrict__ o_rank = a.rank ? a.rank + (size_t)row * a.out_row_stride : nullptr;
-    const int32_t* __restrict__ cmap = a.colmap ? a.colmap + (size_t)row * a.colmap_row_stride : nullptr;
-    const int64_t* __restrict__ imap = a.idmap ? a.idmap + krow : nullptr;
+    const int32_t* __restrict__ cmap = (!LEAN && a.colmap) ? a.colmap + (size_t)row * a.colmap_row_stride : nullptr;
+    const int64_t* __restrict__ imap = (!LEAN && a.idmap) ? a.idmap + krow : nullptr;
 
     // Register state, TWO words per key at any time (E = 28 keys x 3 words does not fit the 128 VGPRs of a 1024-thread
     // workgroup): fp32 -> ks = the key; fp64 -> ks = the HIGH key word during the passes, the LOW key word afterwards
@@ -149,6 +185,90 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
 
     // fp64 key of the element at column `col` (re-derivable at any time from global memory: L2 / Infinity-Cache hits)
     auto key64 = [&](uint2 v) -> uint64_t { return desc_key_f64(__hiloint2double((int)v.y, (int)v.x)); };
+    // FUSE: a key costs S divisions to form, and the fp64 form needs every key's words twice (high words for the passes, low words for
+    // the repair).  The low sort words of the load phase are parked in the LOW-HALF slots of this row's sorted-score output -- written by
+    // nobody before the output phase, indexed by the slot the thread itself loaded (it reads back what it wrote) -- instead of being
+    // formed a second time: 4 B out + 4 B in per key (L2 / Infinity Cache) for S divisions.
+    uint32_t* const stash = reinterpret_cast<uint32_t*>(a.order ? a.order + obase : nullptr);   // (the order output: see below)
+    // FUSE: a key costs S divisions to form, and the fp64 form needs every key's words twice.  The low sort words of the load phase are
+    // parked in this row's ORDER output -- written by nobody before the output phase, indexed by the column / slot the thread itself
+    // loaded (it reads back what it wrote; L2 / Infinity Cache) -- instead of being formed a second time.  Placed rows that do not fill
+    // the row (entries of `order` beyond the list belong to the caller) and calls without an order output form them again.
+    const bool use_stash = FUSE && !GEN && stash != nullptr && (!irow || m == a.n_total);   // block-uniform
+    // FUSE: the fused float64 scores of B columns (col < 0: not an element, its value is never used), in two halves so that callers can
+    // put other work between them: fuse_issue = the rank loads of the FIRST round (N1 = 0, 1 or 2 systems from `s` on), fuse_finish =
+    // the adds in system order from 0.0 like fuse_rank_kernel's -- r0v (r0: system 0's ranks are in the caller's registers: the placed
+    // form's positions), the first round, then the remaining systems two at a time (loads, then adds).
+    auto fuse_issue = [&](auto bt, auto n1_tag, const int (&col)[decltype(bt)::value], int s, int (&ra)[decltype(bt)::value],
+                          int (&rb)[decltype(bt)::value]) __attribute__((always_inline)) {
+        constexpr int B = decltype(bt)::value, N1 = decltype(n1_tag)::value;
+        if constexpr (FUSE && N1 > 0) {
+            const int32_t* __restrict__ pa = a.fuse_ranks[s] + krow;
+            const int32_t* __restrict__ pb = a.fuse_ranks[N1 > 1 ? s + 1 : s] + krow;
+#pragma unroll
+            for (int k = 0; k < B; ++k) { const int c = col[k] < 0 ? 0 : col[k]; ra[k] = pa[c]; if constexpr (N1 > 1) rb[k] = pb[c]; }
+        }
+    };
+    auto fuse_finish = [&](auto bt, auto n1_tag, const int (&col)[decltype(bt)::value], const int (&r0v)[decltype(bt)::value], const bool r0,
+                           int s, int (&ra)[decltype(bt)::value], int (&rb)[decltype(bt)::value],
+                           uint2 (&out)[decltype(bt)::value]) __attribute__((always_inline)) {
+        constexpr int B = decltype(bt)::value, N1 = decltype(n1_tag)::value;
+        if constexpr (FUSE) {
+            double acc[B];
+            uint32_t pres = 0u;
+#pragma unroll
+            for (int k = 0; k < B; ++k) acc[k] = 0.0;
+            auto add = [&](int k, int r, double n) {
+                if (r >= 0) {
+                    const double c = a.fuse_method == FZ_RRF ? recip_small_int_f64((double)(60 + r + 1))   // hybrid.py:252: 1 / (60 + idx + 1)
+                                                             : (n - (double)r + 1.0) / n;                  // hybrid.py:249 (sic)
+                    acc[k] = acc[k] + c;
+                    pres |= 1u << k;
+                }
+            };
+            auto len_of = [&](int sx) -> double { return a.fuse_method == FZ_BCF ? (double)a.fuse_lens[(size_t)sx * a.fuse_rows + row] : 0.0; };
+            if (r0) {
+                const double n0 = len_of(0);
+#pragma unroll
+                for (int k = 0; k < B; ++k) if (col[k] >= 0) add(k, r0v[k], n0);
+            }
+            if constexpr (N1 > 0) {
+                const double na = len_of(s), nb = len_of(N1 > 1 ? s + 1 : s);
+#pragma unroll
+                for (int k = 0; k < B; ++k) if (col[k] >= 0) { add(k, ra[k], na); if constexpr (N1 > 1) add(k, rb[k], nb); }
+            }
+            for (int s2 = s + N1; N1 == 2 && s2 < a.fuse_S; s2 += 2) {                          // (block-uniform; S > 3 only)
+                const bool two = s2 + 1 < a.fuse_S;
+                if (two) fuse_issue(bt, std::integral_constant<int, 2>{}, col, s2, ra, rb); else fuse_issue(bt, std::integral_constant<int, 1>{}, col, s2, ra, rb);
+                __builtin_amdgcn_sched_barrier(0);
+                const double na = len_of(s2), nb = len_of(two ? s2 + 1 : s2);
+#pragma unroll
+                for (int k = 0; k < B; ++k) if (col[k] >= 0) { add(k, ra[k], na); if (two) add(k, rb[k], nb); }
+            }
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                const double v = ((pres >> k) & 1u) ? acc[k] : -(double)INFINITY;
+                out[k] = make_uint2((uint32_t)__double2loint(v), (uint32_t)__double2hiint(v));
+            }
+        }
+    };
+    // how many systems the first round loads: 2 when there are two left after r0 (one memory round trip for S <= 2 + r0), else 1 or 0
+    auto fuse_vals = [&](auto bt, const int (&col)[decltype(bt)::value], const int (&r0v)[decltype(bt)::value], const bool r0,
+                         uint2 (&out)[decltype(bt)::value]) __attribute__((always_inline)) {
+        constexpr int B = decltype(bt)::value;
+        if constexpr (FUSE) {
+            const int s = r0 ? 1 : 0, left = a.fuse_S - s;
+            int ra[B], rb[B];
+            auto go = [&](auto n1_tag) __attribute__((always_inline)) {
+                fuse_issue(bt, n1_tag, col, s, ra, rb);
+                __builtin_amdgcn_sched_barrier(0);
+                fuse_finish(bt, n1_tag, col, r0v, r0, s, ra, rb, out);
+            };
+            if (left >= 2) go(std::integral_constant<int, 2>{});
+            else if (left == 1) go(std::integral_constant<int, 1>{});
+            else go(std::integral_constant<int, 0>{});
+        }
+    };
 
     if (threadIdx.x < 8) misc[8 + threadIdx.x] = (threadIdx.x == 1 || threadIdx.x == 3) ? 0xffffffffu : 0u;  // [8] = or, [9] = and of the sort words; [10] = max, [11] = min, [12] .. [15] = sums (bucket ranking)
     uint32_t orw = 0, andw = 0xffffffffu;
@@ -162,6 +282,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = SENT;
         __syncthreads();
         SLOT_FRESH();
+        if constexpr (!FUSE) {
 #pragma unroll
         for (int i0 = 0; i0 < E; i0 += LG) {
             uint32_t pos_t[LG], lo_t[LG], hi_t[LG];
@@ -182,6 +303,45 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
                 if (j < a.n_total && pos_t[i - i0] < (uint32_t)m) exch[pos_t[i - i0]] = kw;
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        } else {
+            // FUSE: a batch's keys take S divisions each to form -- the NEXT batch's loads (positions + the first round's ranks) are issued
+            // before that arithmetic, not after it: two register stages, the batch loop fully unrolled
+            constexpr int NB = (E + LG - 1) / LG;
+            const int s0 = a.fuse_first_is_pos ? 1 : 0, left = a.fuse_S - s0;                   // block-uniform
+            auto run = [&](auto n1_tag) __attribute__((always_inline)) {
+                int col_t[2][LG], pos_i[2][LG], ra[2][LG], rb[2][LG];
+                auto issue = [&](int b, int st) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int k = 0; k < LG; ++k) {
+                        const int j = (slot0 + (b * LG + k) * 64);
+                        const bool in = b * LG + k < E && j < a.n_total;
+                        col_t[st][k] = in ? j : -1;
+                        pos_i[st][k] = in ? irow[j] : -1;
+                    }
+                    fuse_issue(std::integral_constant<int, LG>{}, n1_tag, col_t[st], s0, ra[st], rb[st]);
+                };
+                issue(0, 0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int st = b & 1;
+                    if (b + 1 < NB) issue(b + 1, st ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    uint2 v_t[LG];
+                    fuse_finish(std::integral_constant<int, LG>{}, n1_tag, col_t[st], pos_i[st], a.fuse_first_is_pos != 0, s0, ra[st], rb[st], v_t);
+#pragma unroll
+                    for (int k = 0; k < LG; ++k) {
+                        const int j = col_t[st][k];
+                        const uint64_t k64 = key64(v_t[k]);
+                        if (!GEN && use_stash && j >= 0) stash[j] = (uint32_t)k64;
+                        if (j >= 0 && (uint32_t)pos_i[st][k] < (uint32_t)m) exch[pos_i[st][k]] = (uint32_t)(k64 >> (GEN ? 0 : 32));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (left >= 2) run(std::integral_constant<int, 2>{});
+            else if (left == 1) run(std::integral_constant<int, 1>{});
+            else run(std::integral_constant<int, 0>{});
         }
         __syncthreads();
         SLOT_FRESH();
@@ -219,7 +379,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         __syncthreads();
     } else {
         double s1 = 0.0, s2 = 0.0, sn = 0.0, x0 = 0.0;   // row statistics (only when a.row_stats, whole-list form)
-        if (st_load) {
+        if (!FUSE && st_load) {
             float f0;
             if (KW == 1) f0 = kf[elem(init_row ? 0 : c0)];
             else { const uint2 v0 = kd[elem(init_row ? 0 : c0)]; f0 = (float)__hiloint2double((int)v0.y, (int)v0.x); }
@@ -227,10 +387,11 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         }
         SLOT_FRESH();
 #pragma unroll
-        for (int i0 = 0; i0 < E; i0 += LG) {
-            uint32_t lo_t[LG], hi_t[KW == 2 ? LG : 1];
+        for (int i0 = 0; i0 < E; i0 += LGF) {
+            uint32_t lo_t[LGF], hi_t[KW == 2 ? LGF : 1];
+            [[maybe_unused]] int col_t[FUSE ? LGF : 1];
 #pragma unroll
-            for (int i = i0; i < (i0 + LG < E ? i0 + LG : E); ++i) {
+            for (int i = i0; i < (i0 + LGF < E ? i0 + LGF : E); ++i) {
                 // branch-free: out-of-range lanes load a safe element (column c0 exists because m > 0) and discard it
                 const int p = (slot0 + i * 64);
                 const bool valid = p < m;
@@ -240,15 +401,30 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
                 // payload: the source column (gathered sequence) or the column inside the chunk
                 meta[i] = ok ? (uint32_t)(init_row ? col : col - c0) : 0xffffu;
                 col = ok ? col : c0;
-                if (KW == 1) lo_t[i - i0] = __float_as_uint(kf[elem(col)]);
+                if constexpr (FUSE) col_t[i - i0] = ok ? col : -1;
+                else if (KW == 1) lo_t[i - i0] = __float_as_uint(kf[elem(col)]);
                 else { const uint2 v = kd[elem(col)]; lo_t[i - i0] = v.x; hi_t[KW == 2 ? i - i0 : 0] = v.y; }
+            }
+            if constexpr (FUSE) {
+#pragma unroll
+                for (int k = (i0 + LGF < E ? LGF : E - i0); k < LGF; ++k) col_t[k] = -1;
+                uint2 v_t[LGF];
+                if (init_row) __builtin_amdgcn_sched_barrier(0);
+                fuse_vals(std::integral_constant<int, LGF>{}, col_t, col_t, false, v_t);
+#pragma unroll
+                for (int k = 0; k < LGF; ++k) { lo_t[k] = v_t[k].x; hi_t[k] = v_t[k].y; }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = i0; i < (i0 + LG < E ? i0 + LG : E); ++i) {
+            for (int i = i0; i < (i0 + LGF < E ? i0 + LGF : E); ++i) {
                 const bool ok = meta[i] != 0xffffu;
-                const uint32_t kw = KW == 1 ? desc_key_f32(__uint_as_float(lo_t[i - i0]))
-                                            : (uint32_t)(key64(make_uint2(lo_t[i - i0], hi_t[KW == 2 ? i - i0 : 0])) >> (GEN ? 0 : 32));
+                uint32_t kw;
+                if constexpr (KW == 1) kw = desc_key_f32(__uint_as_float(lo_t[i - i0]));
+                else {
+                    const uint64_t k64 = key64(make_uint2(lo_t[i - i0], hi_t[KW == 2 ? i - i0 : 0]));
+                    kw = (uint32_t)(k64 >> (GEN ? 0 : 32));
+                    if constexpr (FUSE && !GEN) { if (use_stash && ok) stash[(slot0 + i * 64)] = (uint32_t)k64; }
+                }
                 ks[i] = ok ? kw : SENT;
                 orw |= ok ? kw : 0u; andw &= ok ? kw : 0xffffffffu;
                 if (st_load) {   // the value as the normalisations see it: float32 (BM25's float64 scores rounded, hybrid.py:261)
@@ -414,7 +590,10 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         for (int i = 0; i < E; ++i) {
             const uint32_t py = meta[i] & 0xffffu;
             const int col = py == 0xffffu ? c0 : (int)py + ((init_row || irow) ? 0 : c0);
-            const uint64_t kk = key64(kd[elem(col)]);
+            uint2 kv[1];
+            if constexpr (FUSE) { const int c1[1] = {col}; fuse_vals(std::integral_constant<int, 1>{}, c1, c1, false, kv); }
+            else kv[0] = kd[elem(col)];
+            const uint64_t kk = key64(kv[0]);
             ks[i] = py == 0xffffu ? SENT : (high ? (uint32_t)(kk >> 32) : (uint32_t)kk);
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
@@ -794,11 +973,35 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         __syncthreads();
         // ---- low words: re-derived by the thread that loaded the element, published under its payload ----
         constexpr int LGG = 4;   // (7 in flight measured the same)
+        if (use_stash) {         // FUSE: the low sort words parked by the load phase, by the slot this thread loaded
+            SLOT_FRESH();
+#pragma unroll
+            for (int i0 = 0; i0 < E; i0 += 7) {
+                uint32_t lw[7];
+                int pay_t[7];
+#pragma unroll
+                for (int i = i0; i < (i0 + 7 < E ? i0 + 7 : E); ++i) {
+                    const int p = (slot0 + i * 64);
+                    int pay;   // payload this slot was loaded with (see the re-deriving form below)
+                    if (irow) pay = p < a.n_total ? p : -1;
+                    else if (init_row) { int col = p < m ? init_row[c0 + p] : -1; pay = (unsigned)col < (unsigned)a.n_total ? col : -1; }
+                    else pay = p < m ? p : -1;
+                    pay_t[i - i0] = pay;
+                    lw[i - i0] = stash[pay < 0 ? 0 : p];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = i0; i < (i0 + 7 < E ? i0 + 7 : E); ++i)
+                    if (pay_t[i - i0] >= 0) exch[pay_t[i - i0]] = lw[i - i0];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         SLOT_FRESH();
 #pragma unroll
         for (int i0 = 0; i0 < E; i0 += LGG) {
             uint32_t lo_t[LGG], hi_t[LGG];
             int pay_t[LGG];
+            [[maybe_unused]] int col_t[FUSE ? LGG : 1];
 #pragma unroll
             for (int i = i0; i < (i0 + LGG < E ? i0 + LGG : E); ++i) {
                 const int p = (slot0 + i * 64);
@@ -807,14 +1010,24 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
                 else if (init_row) { col = p < m ? init_row[c0 + p] : -1; col = (unsigned)col < (unsigned)a.n_total ? col : -1; pay = col; }
                 else { pay = p < m ? p : -1; col = pay < 0 ? -1 : c0 + pay; }
                 pay_t[i - i0] = pay;
-                const uint2 v = kd[elem(col < 0 ? c0 : col)];
-                lo_t[i - i0] = v.x; hi_t[i - i0] = v.y;
+                if constexpr (FUSE) col_t[i - i0] = col;
+                else { const uint2 v = kd[elem(col < 0 ? c0 : col)]; lo_t[i - i0] = v.x; hi_t[i - i0] = v.y; }
+            }
+            if constexpr (FUSE) {
+#pragma unroll
+                for (int k = (i0 + LGG < E ? LGG : E - i0); k < LGG; ++k) { col_t[k] = -1; pay_t[k] = -1; }
+                uint2 v_t[LGG];
+                if (init_row) __builtin_amdgcn_sched_barrier(0);
+                fuse_vals(std::integral_constant<int, LGG>{}, col_t, col_t, false, v_t);
+#pragma unroll
+                for (int k = 0; k < LGG; ++k) { lo_t[k] = v_t[k].x; hi_t[k] = v_t[k].y; }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = i0; i < (i0 + LGG < E ? i0 + LGG : E); ++i)
                 if (pay_t[i - i0] >= 0) exch[pay_t[i - i0]] = (uint32_t)key64(make_uint2(lo_t[i - i0], hi_t[i - i0]));
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         __syncthreads();
         SLOT_FRESH();
@@ -978,6 +1191,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) {
             auto val = [&](int col) -> float {
+                if (FUSE) return 0.f;                        // (the launcher rejects row_stats with rank fusion)
                 if (KW == 1) return kf[elem(col)];
                 const uint2 v = kd[elem(col)];
                 return (float)__hiloint2double((int)v.y, (int)v.x);
@@ -1003,7 +1217,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     // ---- output (coalesced: consecutive lanes = consecutive ranks) -------------------------
     // rank = inverse permutation.  Scattering it straight to HBM costs as much as the four radix passes
     // (27,942 random 4-byte writes per row); it is inverted in LDS instead and stored coalesced.
-    const bool rank_via_lds = o_rank && !cmap && a.chunks == 1;   // block-uniform
+    const bool rank_via_lds = o_rank && !cmap && (LEAN || a.chunks == 1);   // block-uniform
     const bool full_row = (m == a.n_total) && !init_row && !irow;   // a gathered/placed sequence may skip columns
     if (rank_via_lds && !full_row) {
         SLOT_FRESH();
@@ -1316,24 +1530,24 @@ static inline bool pick_cfg(int n, int kw, SortCfg& c) {
     return true;
 }
 
-template <int T, int E, int KW>
+template <int T, int E, int KW, int MODE = SORT_ANY>
 static int launch_cfg(const SortArgs& a, int prows, hipStream_t st) {
     constexpr size_t lds = SortLds<T, E, KW>::bytes;
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
-    static unsigned long long lds_set = 0ull, lds_set_gen = 0ull;   // per (T,E,KW) instantiation
-    if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, KW, false>, lds, lds_set)) return rc;
+    static unsigned long long lds_set = 0ull, lds_set_gen = 0ull;   // per (T,E,KW,FUSE) instantiation
+    if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, KW, false, MODE>, lds, lds_set)) return rc;
     if constexpr (KW == 2)
-        if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, 2, true>, lds, lds_set_gen)) return rc;
+        if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, 2, true, MODE>, lds, lds_set_gen)) return rc;
     if (KW == 2 && !a.row_flags) return FZ_ERR_WORKSPACE;
     SortArgs b = a;
     {   // FZ_SORT_BUCKET_RANK=0: digit passes only (A/B runs, tests of the two forms against each other)
         const char* e = getenv("FZ_SORT_BUCKET_RANK");
         b.bucket_rank = (e && e[0] == '0') ? 0 : 1;
     }
-    sort_rows_kernel<T, E, KW, false><<<prows, T, lds, st>>>(b);
+    sort_rows_kernel<T, E, KW, false, MODE><<<prows, T, lds, st>>>(b);
     FZ_LAUNCH_CHECK();
     if constexpr (KW == 2) {   // rows the fast form flagged (a dirty run of > 17 equal high words): generic eight passes; all others exit at once
-        sort_rows_kernel<T, E, 2, true><<<prows, T, lds, st>>>(a);
+        sort_rows_kernel<T, E, 2, true, MODE><<<prows, T, lds, st>>>(a);
         FZ_LAUNCH_CHECK();
     }
     return FZ_OK;
@@ -1342,6 +1556,23 @@ static int launch_cfg(const SortArgs& a, int prows, hipStream_t st) {
 static int launch_sort(const SortArgs& a, int kw, int prows, int n_chunk, hipStream_t st) {
     SortCfg c;
     if (!pick_cfg(n_chunk, kw, c)) return FZ_ERR_UNSUPPORTED;
+    if (a.fuse_S > 0) {   // rank fusion as the load phase (float64 keys, one workgroup per row)
+        if (kw != 2 || a.chunks != 1 || a.row_stats) return FZ_ERR_UNSUPPORTED;
+#define FZ_SORT_CASE(TT, EE) if (c.T == TT && c.E == EE) return launch_cfg<TT, EE, 2, SORT_FUSE>(a, prows, st);
+        FZ_SORT_CASE(256, 4) FZ_SORT_CASE(256, 16) FZ_SORT_CASE(512, 16) FZ_SORT_CASE(1024, 16) FZ_SORT_CASE(1024, 28)
+#undef FZ_SORT_CASE
+        return FZ_ERR_UNSUPPORTED;
+    }
+    // whole rows of one plane, 1024-thread configurations (the rankers' sorts and the final order at LLeQA size): the lean instantiation
+    static const int lean_env = [] { const char* e = getenv("FZ_SORT_LEAN"); return e ? atoi(e) : -1; }();   // A/B runs: 0 = never, 1 = fp32 rows too
+    if (lean_env != 0 && a.chunks == 1 && a.seg_len >= a.n_total && !a.colmap && !a.idmap && !a.out_ids && c.T == 1024) {
+        // float64 keys: the lean form holds no spilled register (120 VGPRs; SORT_ANY: 9 spilled) and measures 2.5 % (plain rows) to
+        // 7 % (placed rows) faster.  float32 keys stay on SORT_ANY unless FZ_SORT_LEAN=1: hipcc schedules their lean form into MORE
+        // spills (122, sixteen reloads inside the pass loop) and it measures 15 % slower (profiles/r05_sort_modes_ab.json)
+        if (kw == 2 && c.E == 16) return launch_cfg<1024, 16, 2, SORT_ROWS>(a, prows, st);
+        if (kw == 2 && c.E == 28) return launch_cfg<1024, 28, 2, SORT_ROWS>(a, prows, st);
+        if (kw == 1 && lean_env == 1 && c.E == 28) return launch_cfg<1024, 28, 1, SORT_ROWS>(a, prows, st);
+    }
 #define FZ_SORT_CASE(TT, EE)                                                      \
     if (c.T == TT && c.E == EE) return kw == 1 ? launch_cfg<TT, EE, 1>(a, prows, st) : launch_cfg<TT, EE, 2>(a, prows, st);
     FZ_SORT_CASE(256, 4) FZ_SORT_CASE(256, 16) FZ_SORT_CASE(512, 16) FZ_SORT_CASE(1024, 16) FZ_SORT_CASE(1024, 28)
@@ -1610,6 +1841,46 @@ extern "C" int fz_sort_rows_desc_placed(const void* keys, int key_bits, const in
     a.out_row_stride = ld; a.out_chunk_stride = 0; a.out_limit = n;
     if (key_bits == 64) { if (!workspace || workspace_bytes < fz_sort_workspace_bytes(64, rows, n)) return FZ_ERR_WORKSPACE; a.row_flags = (int32_t*)workspace; }
     return launch_sort(a, key_bits / 32, rows, n, as_stream(stream));
+}
+
+// Rank fusion + final order in one kernel (hybrid.py:248-252 + :301-306): what fz_fuse_rank_f64 followed by fz_sort_rows_desc[_placed] on its
+// float64 plane computes -- the same fused scores bit for bit (formed per key on load by the expression of fuse_rank_kernel), the same
+// stable order -- without the [rows][ld] float64 plane ever being written or read (229 MB out + 458 MB in at Q = 1024, N = 27,942).
+extern "C" int fz_sort_rank_fused_desc(const int32_t* const* ranks_h, const int32_t* lens, int S, int method, const int32_t* init_order,
+                                       const int32_t* init_rank, const int32_t* row_len, int rows, int n, int ld, int32_t* order,
+                                       double* sorted_scores, int32_t* rank, void* workspace, size_t workspace_bytes, void* stream) {
+    if (S <= 0 || S > FZ_MAX_SYSTEMS || rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
+    if (method != FZ_RRF && method != FZ_BCF) return FZ_ERR_ARG;
+    if (init_order && init_rank) return FZ_ERR_ARG;
+    if (rows == 0 || n == 0) return FZ_OK;
+    if (!ranks_h || !lens) return FZ_ERR_ARG;
+    if (n > 28672) return FZ_ERR_UNSUPPORTED;      // longer rows: fz_fuse_rank_f64 + fz_sort_rows_desc (chunk-sort + merge)
+    SortArgs a{};
+    for (int s = 0; s < S; ++s) {
+        if (!ranks_h[s]) return FZ_ERR_ARG;
+        a.fuse_ranks[s] = ranks_h[s];
+    }
+    a.fuse_lens = lens; a.fuse_S = S; a.fuse_method = method; a.fuse_rows = rows;
+    a.fuse_first_is_pos = (init_rank && init_rank == ranks_h[0]) ? 1 : 0;
+    a.init_order = init_order; a.init_rank = init_rank; a.row_len = row_len;
+    a.n_total = n; a.key_row_stride = ld; a.seg_len = n; a.seg_stride = 0;
+    a.chunks = 1; a.chunk_len = n;
+    a.order = order; a.sorted_keys = sorted_scores; a.rank = rank;
+    a.out_row_stride = ld; a.out_chunk_stride = 0; a.out_limit = n;
+    if (!workspace || workspace_bytes < fz_sort_workspace_bytes(64, rows, n)) return FZ_ERR_WORKSPACE;
+    a.row_flags = (int32_t*)workspace;
+    return launch_sort(a, 2, rows, n, as_stream(stream));
+}
+
+// Diagnostic: out[r] = 1 / (60 + r + 1) in float64 for r < count -- fast != 0: by the division-free form the fused sort's load phase uses
+// (recip_small_int_f64), else by the IEEE division fuse_rank_kernel uses.  Tests compare the two (and NumPy) over every rank.
+extern "C" int fz_rrf_terms_f64(int count, int fast, double* out, void* stream) {
+    if (count < 0 || count > (1 << 20)) return FZ_ERR_ARG;
+    if (count == 0) return FZ_OK;
+    if (!out) return FZ_ERR_ARG;
+    rrf_terms_kernel<<<(count + 255) / 256, 256, 0, as_stream(stream)>>>(count, fast, out);
+    FZ_LAUNCH_CHECK();
+    return FZ_OK;
 }
 
 // ---- top-k: chunk-sort-truncate levels until one workgroup can finish the row ---------------

@@ -334,6 +334,63 @@ def fuse_rank(ranks: list[torch.Tensor], lens: torch.Tensor, method: str) -> tor
     return fused
 
 
+def sort_rank_fused(ranks: list[torch.Tensor], lens: torch.Tensor, method: str, init_order: torch.Tensor | None = None,
+                    init_rank: torch.Tensor | None = None, row_len: torch.Tensor | None = None, want_rank: bool = False,
+                    covers_all: bool = False):
+    """rrf / bcf fusion (hybrid.py:248-252,301-304) and the stable descending sort of the fused scores (hybrid.py:306) in ONE kernel:
+    sort_rows_desc(fuse_rank(ranks, lens, method), init_order / init_rank, row_len) without the float64 plane in between
+    (fz_sort_rank_fused_desc).  Returns (order, fused scores in list order [float64], rank | None) -- bit-identical to the two calls.
+    Rows longer than one workgroup holds raise FusionHipError(FZ_ERR_UNSUPPORTED): callers take the two calls there."""
+    for r in ranks:
+        _dev(r, torch.int32, "sort_rank_fused(ranks)")
+    _same_shape(ranks, "sort_rank_fused")
+    first_is_pos = init_rank is not None and init_rank is ranks[0]
+    ranks = harmonise(list(ranks))
+    if first_is_pos:
+        init_rank = ranks[0]
+    _dev(lens, torch.int32, "sort_rank_fused(lens)")
+    lens = lens.contiguous()
+    rows, n = ranks[0].shape
+    _need(tuple(lens.shape) == (len(ranks), rows), f"sort_rank_fused(lens): expected shape {(len(ranks), rows)}, got {tuple(lens.shape)}")
+    _need(init_order is None or init_rank is None, "sort_rank_fused: pass init_order or init_rank, not both")
+    ld = _same_ld(*ranks)
+    dev = ranks[0].device
+    partial = (row_len is not None or init_order is not None or init_rank is not None) and not covers_all
+
+    def mk(dtype, fill):
+        shape = (max(rows, 1), ld)
+        base = torch.full(shape, fill, dtype=dtype, device=dev) if partial else torch.empty(shape, dtype=dtype, device=dev)
+        return base[:rows, :n]
+    order, sk = mk(torch.int32, -1), mk(torch.float64, float("-inf"))
+    rank = mk(torch.int32, -1) if want_rank else None
+    for name, t in (("init_order", init_order), ("init_rank", init_rank)):
+        if t is not None:
+            _dev(t, torch.int32, f"sort_rank_fused({name})")
+            _need(tuple(t.shape) == (rows, n), f"sort_rank_fused({name}): expected shape {(rows, n)}, got {tuple(t.shape)}")
+    if init_order is not None and _ld(init_order) != ld and rows > 1:
+        t = mk(torch.int32, -1); t.copy_(init_order); init_order = t
+    if init_rank is not None and _ld(init_rank) != ld and rows > 1:
+        t = mk(torch.int32, -1); t.copy_(init_rank); init_rank = t
+    if row_len is not None:
+        _dev(row_len, torch.int32, "sort_rank_fused(row_len)")
+        row_len = row_len.contiguous()
+        _need(row_len.numel() == rows, f"sort_rank_fused(row_len): expected {rows} entries, got {row_len.numel()}")
+    lib = _lib.lib()
+    wsb = int(lib.fz_sort_workspace_bytes(64, rows, n))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    check(lib.fz_sort_rank_fused_desc(_ptr_array(ranks), _ptr(lens), len(ranks), RANK_METHODS[method], _ptr(init_order), _ptr(init_rank),
+                                      _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk), _ptr(rank), _ptr(ws), wsb, _stream(ranks[0])),
+          "fz_sort_rank_fused_desc")
+    return order, sk, rank
+
+
+def rrf_terms(count: int, fast: bool, device="cuda") -> torch.Tensor:
+    """[count] float64: 1 / (60 + r + 1) as the fused sort forms it (fast) or as fz_fuse_rank_f64 does (IEEE division) -- a diagnostic."""
+    out = torch.empty(int(count), dtype=torch.float64, device=device)
+    check(_lib.lib().fz_rrf_terms_f64(int(count), 1 if fast else 0, _ptr(out), _stream(out)), "fz_rrf_terms_f64")
+    return out
+
+
 def row_stats(scores: torch.Tensor, rank: torch.Tensor | None, norm: str):
     _dev(scores, torch.float32, "row_stats(scores)")
     rows, N = scores.shape
@@ -785,6 +842,7 @@ class TopkStream:
         self.windows_redone = 0
         self._pieces = []                # what the current window was fed with: ("scores", piece, id_base) | ("gemm", Qn, Dpiece, id_base)
         self._unheld = False             # ... and whether some of it was fed without being held (feed(hold=False))
+        self._ever_unheld = False        # an unheld window has been folded: the flag may carry ITS overflow, which no later redo can repair
         wsb = int(_lib.lib().fz_topk_fold_workspace_bytes(rows, k, cap))
         self._ws, self._wsb = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev), wsb
 
@@ -864,8 +922,10 @@ class TopkStream:
                 ns, ni = topk_merge(torch.stack([ns, ps]), torch.stack([ni, pi]))
             self.tau.copy_(ns[:, self.k - 1])
             self.cand_len.zero_()
-            self.overflow.zero_()
+            if not self._ever_unheld:        # (else the flag may be an EARLIER, unheld window's: it stays set and the caller redoes the search)
+                self.overflow.zero_()
             self.windows_redone += 1
+        self._ever_unheld = self._ever_unheld or self._unheld
         self._pieces.clear()
         self._unheld = False                 # (an overflow of that window has left the flag set: it is never cleared again)
         self.best_s, self.best_i = ns, ni
@@ -916,7 +976,9 @@ def bm25_slice_offsets(toff: torch.Tensor, pdoc: torch.Tensor, N: int) -> torch.
 
 
 def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float, qoff, qterms, Q: int, N: int,
-                doc_norm: torch.Tensor | None = None, slice_off: torch.Tensor | None = None) -> torch.Tensor:
+                doc_norm: torch.Tensor | None = None, slice_off: torch.Tensor | None = None, want_f32: bool = False):
+    """BM25 scores [Q, N] float64 (bm25.py:149-156).  want_f32: also the float32 rounding of the same scores (the plane the normalisations
+    read, hybrid.py:255), written by the same launch -> (float64 plane, float32 plane)."""
     dev = idf.device
     for t, dt, what in ((toff, torch.int64, "toff"), (pdoc, torch.int32, "pdoc"), (ptf, torch.int32, "ptf"), (idf, torch.float64, "idf"),
                         (doc_len, torch.int32, "doc_len"), (qoff, torch.int64, "qoff"), (qterms, torch.int32, "qterms")):
@@ -931,9 +993,11 @@ def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float
         _need(_dev(slice_off, torch.int64, "bm25_scores(slice_off)").is_contiguous() and tuple(slice_off.shape) == (idf.numel(), NS + 1),
               f"bm25_scores(slice_off): expected a contiguous [{idf.numel()}, {NS + 1}] table (ops.bm25_slice_offsets)")
     out = torch.empty((max(Q, 1), max(round_up(N, _PAD), _PAD)), dtype=torch.float64, device=dev)[:Q, :N]
-    check(_lib.lib().fz_bm25_scores_f64(_ptr(toff), _ptr(pdoc), _ptr(ptf), _ptr(idf), _ptr(doc_len), _ptr(doc_norm), _ptr(slice_off), float(avgdl), float(k1),
-                                        float(b), _ptr(qoff), _ptr(qterms), Q, N, _ptr(out), _ld(out), _stream(idf)), "fz_bm25_scores_f64")
-    return out
+    out32 = alloc_plane(Q, N, torch.float32, dev) if want_f32 else None
+    check(_lib.lib().fz_bm25_scores_f64_f32(_ptr(toff), _ptr(pdoc), _ptr(ptf), _ptr(idf), _ptr(doc_len), _ptr(doc_norm), _ptr(slice_off), float(avgdl),
+                                            float(k1), float(b), _ptr(qoff), _ptr(qterms), Q, N, _ptr(out), _ld(out), _ptr(out32),
+                                            _ld(out32) if want_f32 else 0, _stream(idf)), "fz_bm25_scores_f64_f32")
+    return (out, out32) if want_f32 else out
 
 
 # ---------------------------------------------------------------------------------------

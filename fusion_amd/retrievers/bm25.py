@@ -61,28 +61,28 @@ class BM25:
             self._norm_key = key
         return self._norm
 
-    def scores(self, queries: list[str]) -> torch.Tensor:
-        """[Q, N] float64 plane; query terms are NOT de-duplicated (bm25.py:152)."""
+    def scores(self, queries: list[str], want_f32: bool = False):
+        """[Q, N] float64 plane (want_f32: and its float32 rounding, from the same launch); query terms are NOT de-duplicated (bm25.py:152)."""
         qt = [[self.vocab.get(w, -1) for w in q.split()] for q in queries]
         qoff = np.zeros(len(qt) + 1, dtype=np.int64)
         np.cumsum([len(x) for x in qt], out=qoff[1:])
         flat = np.array([t for x in qt for t in x] or [0], dtype=np.int32)
         return ops.bm25_scores(self.toff, self.pdoc, self.ptf, self.idf, self.doc_len, self.avgdl, self.k1, self.b,
                                torch.from_numpy(qoff).to(self.device), torch.from_numpy(flat).to(self.device), len(queries), self.corpus_size,
-                               doc_norm=self._doc_norm(), slice_off=self.slice_off)
+                               doc_norm=self._doc_norm(), slice_off=self.slice_off, want_f32=want_f32)
 
     def search_device(self, queries: list[str], ids: np.ndarray | None = None) -> RankedSystem:
-        sc64 = self.scores(queries)
+        sc64, sc32 = self.scores(queries, want_f32=True)
         Q, N = sc64.shape
         stats4 = None   # mean | std | min | max of every list's float32 scores: by-products of the ranking sort (rows that fit one workgroup)
         if N <= ops.sort_max_n(torch.float64) and Q > 0:
             stats4 = torch.empty((4, Q), dtype=torch.float32, device=self.device)
         order, sk, rank = ops.sort_rows_desc(sc64, want_rank=True, stats_out=stats4)   # ranks from the float64 scores, ties -> ascending index
         lens = torch.full((Q,), N, dtype=torch.int32, device=self.device)
-        # float32 plane for the normalisations (torch.tensor(scores, dtype=float32), hybrid.py:255); the float64 scores stay
-        # for the 'none' passthrough, which keeps BM25's Python floats (hybrid.py:280).  Rounding is monotone: the float32
-        # scores are in descending order along the float64 ranking too.
-        return RankedSystem(scores=ops.f64_to_f32(sc64), order=order, rank=rank, lens=lens,
+        # float32 plane for the normalisations (torch.tensor(scores, dtype=float32), hybrid.py:255), written by the scoring kernel from
+        # the accumulators it holds (no conversion pass); the float64 scores stay for the 'none' passthrough, which keeps BM25's Python
+        # floats (hybrid.py:280).  Rounding is monotone: the float32 scores are in descending order along the float64 ranking too.
+        return RankedSystem(scores=sc32, order=order, rank=rank, lens=lens,
                             ids=np.arange(N, dtype=np.int64) if ids is None else ids, sorted_scores=sk, full=True,
                             scores64=sc64, score_sorted=True, stats4=stats4)
 

@@ -338,6 +338,7 @@ class Aggregator:
     # and cut; below it the selection's extra launches and its flag read cost more than the sort (bench.py: 0.26 vs 0.14 ms at Q = 195)
     SELECT_MIN_Q = 512
     last_topk_path = None     # "select" | "sort": which of the two the last fuse_device(topk=...) took (tests pin it)
+    last_rank_fused_sort = None   # True: the last rrf / bcf fusion ran as the load phase of the final sort (one kernel, no float64 plane)
 
     @classmethod
     def _wide(cls, w) -> bool:
@@ -373,9 +374,14 @@ class Aggregator:
         ranks = None if all_full else [None if s.full else s.rank for s in S]   # validity: only the partial lists carry any
         vbits = None if all_full else [s.valid_bits() for s in S]              # ... and the nsf passes read it as 1 bit per document
 
+        rank_fused_sort = False
         if method in ("bcf", "rrf"):
             lens = torch.stack([s.lens for s in S]).contiguous()
-            fused = ops.fuse_rank([s.rank for s in S], lens, method)
+            # the fusion is the LOAD PHASE of the final sort (ops.sort_rank_fused: no float64 plane between two kernels) wherever one
+            # workgroup holds a row and the full lists are wanted; the top-k selection reads the fused plane, so it keeps the two calls
+            will_select = topk is not None and topk < N and all_full and Q >= cls.SELECT_MIN_Q
+            rank_fused_sort = 0 < N <= ops.sort_max_n(torch.float64) and Q > 0 and not will_select
+            fused = None if rank_fused_sort else ops.fuse_rank([s.rank for s in S], lens, method)
         elif method == "nsf":
             if percentile_distributions is None:            # the reference calls .get() on it for every system (hybrid.py:213)
                 raise AttributeError("'NoneType' object has no attribute 'get'")
@@ -399,9 +405,19 @@ class Aggregator:
         # topk: float64 fused rows (rrf / bcf / 'none' / np.float64 weights) over full lists are selected, not sorted -- two thirds of the
         # full float64 sort's time at N = 27,942.  float32 rows (the selection costs what their four-pass sort costs) and partial lists
         # (the inverse insertion order costs more than the selection saves) are sorted and cut
-        select = topk is not None and topk < N and fused.dtype == torch.float64 and all_full and Q >= cls.SELECT_MIN_Q   # (small batches: launch- and sync-bound, the sort wins)
+        select = (topk is not None and topk < N and fused is not None and fused.dtype == torch.float64 and all_full
+                  and Q >= cls.SELECT_MIN_Q)   # (small batches: launch- and sync-bound, the sort wins)
         cls.last_topk_path = "sort"
-        if all_full:
+        cls.last_rank_fused_sort = rank_fused_sort
+        if rank_fused_sort:
+            if all_full:    # first-insertion order == system 0's ranking, whose rank plane is also the first fusion operand: read once
+                lens_out = torch.full((Q,), N, dtype=torch.int32, device=dev)
+                order, sk, _ = ops.sort_rank_fused([s.rank for s in S], lens, method, init_rank=S[0].rank, covers_all=True)
+            else:
+                ins, U = ops.insertion_order([s.order for s in S], lens, N)
+                lens_out = U
+                order, sk, _ = ops.sort_rank_fused([s.rank for s in S], lens, method, init_order=ins, row_len=U)
+        elif all_full:
             # first-insertion order == system 0's ranking: its rank plane places every doc (coalesced, no gather)
             if select:
                 sel = ops.select_topk(fused, S[0].rank, topk)

@@ -102,7 +102,7 @@ int fz_sort_max_n_f64(void);
  * fp64 keys are sorted by their high word (4 radix passes) and repaired in place where equal high words hide a low-word
  * inversion; a row with such a run longer than 17 keys is flagged in the workspace and redone by a generic 8-pass launch. */
 size_t fz_sort_workspace_bytes(int key_bits, int rows, int n);
-/* fp32 rows of 4,096 .. 28,672 keys (one 1,024-thread workgroup) whose scores are spread like a ranker's -- few ties -- are ordered
+/* fp32 rows of 8,193 .. 28,672 columns (the rows a 1,024-thread workgroup sorts) that hold at least 4,096 keys and whose scores are spread like a ranker's -- few ties -- are ordered
  * without the digit passes: BUCKET RANKING (16,384 buckets whose widths follow the row's own density, a counting sort by bucket, each
  * key's rank = its bucket's first slot + the members below it, a neighbour check on the result; csrc/sort.hip).  Rows it does not
  * suit (heavy ties, a crowd of values 24 binades below the row's largest, an overfull bucket, a check it cannot settle) take the digit
@@ -130,6 +130,21 @@ int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* init_order,
 int fz_sort_rows_desc_placed(const void* keys, int key_bits, const int32_t* init_rank, const int32_t* row_len, int rows, int n,
                              int ld, int32_t* order, void* sorted_keys, int32_t* rank, void* workspace, size_t workspace_bytes,
                              void* stream);
+
+/* Rank fusion (K5b below) AS THE LOAD PHASE of the final ordering -- hybrid.py:248-252 (the per-rank terms), :301-304 (the float64 sums in
+ * system order) and :306 (the stable descending sort) in one kernel: what fz_fuse_rank_f64 followed by fz_sort_rows_desc[_placed] on its
+ * plane returns, bit for bit (order, the fused float64 scores in sorted_scores, rank), without the [rows][ld] float64 plane existing.
+ * ranks_h: HOST array of S device rank planes [rows][ld] int32 (-1 = the system does not list the document); lens [S][rows] int32 (device).
+ * Incoming sequence (the fused dict's first-insertion order): init_rank (placed; when it is ranks_h[0] itself -- every list full -- that
+ * plane is read once), or init_order (gathered; row_len = the number of listed documents), or neither (columns in order).
+ * n <= fz_sort_max_n_f64() (FZ_ERR_UNSUPPORTED beyond: use the two calls).  Workspace: fz_sort_workspace_bytes(64, rows, n). */
+int fz_sort_rank_fused_desc(const int32_t* const* ranks_h, const int32_t* lens, int S, int method, const int32_t* init_order,
+                            const int32_t* init_rank, const int32_t* row_len, int rows, int n, int ld, int32_t* order,
+                            double* sorted_scores, int32_t* rank, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Diagnostic for the call above: out[r] = 1 / (60 + r + 1) (hybrid.py:252) in float64, r < count <= 2^20 -- fast != 0: the division-free
+ * sequence its load phase uses, else the IEEE division of fz_fuse_rank_f64.  The two must agree bit for bit (tests). */
+int fz_rrf_terms_f64(int count, int fast, double* out, void* stream);
 
 /* Top-k form of the final ordering (what main() reads of the fused lists: predictions(1000), hybrid.py:537).  Per row: the candidates for the
  * first k places of the sort above -- every column with pos >= 0 whose fused score, rounded to float32, is not below the k-th largest such
@@ -306,6 +321,11 @@ int fz_bm25_slice_offsets(const int64_t* toff, const int32_t* pdoc, int V, int N
 int fz_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf, const int32_t* doc_len,
                        const double* doc_norm, const int64_t* slice_off, double avgdl, double k1, double b, const int64_t* qoff,
                        const int32_t* qterms, int Q, int N, double* scores, int lds, void* stream);
+/* The same launch also writing the scores rounded to float32 (scores32 [Q][lds32], nullable) -- the plane the normalisations read
+ * (torch.tensor(scores, dtype=float32), hybrid.py:255) -- from the same accumulators: no separate conversion pass over the float64 plane. */
+int fz_bm25_scores_f64_f32(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf, const int32_t* doc_len,
+                           const double* doc_norm, const int64_t* slice_off, double avgdl, double k1, double b, const int64_t* qoff,
+                           const int32_t* qterms, int Q, int N, double* scores, int lds, float* scores32, int lds32, void* stream);
 
 /* ---- N1: weight-grid sweep of the linear fusion, hybrid.py:404-426 ------------------------ */
 /* Fused ranks of the gold documents for W weight vectors at once, without fusing or sorting:
