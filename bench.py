@@ -2,7 +2,10 @@
 """bench.py -- queries/sec end-to-end (encode + score + fuse) on synthetic LLeQA-shaped batches.
 
 N = 1 (the headline line; `--workload lleqa`).  One "step" = one pass of the hot path over one batch of Q synthetic
-queries, inputs resident in HBM:
+queries.  The corpus side is resident in HBM; the queries enter as STRINGS, as model.encode(queries) takes them (hybrid.py:101-102):
+    0. tokenize    Q French-like questions -> token ids on the host (32,005-piece BPE of camembert's layout, tokenizers' encode_batch on all
+                   host cores) + upload -- step i + 1's batch on a host thread while the device runs step i (fusion_amd.tokenization.prefetch;
+                   `--serial-tokenize` shows the step without the overlap, `--token-ids` the rounds 1-4 form that starts from resident ids)
     1. encode      query token ids -> CamemBERT-base-shaped encoder (random init, fp32; padding-free forward: PyTorch-ROCm
                    hipBLASLt Linears + this repo's HIP embedding / attention / GELU / LayerNorm / pooling kernels) -> mean pool
     2. dpr score   normalise + fp32-MFMA cos-sim GEMM against the resident corpus embeddings   [Q, N]
@@ -59,6 +62,8 @@ def parse():
     p.add_argument("--corpus", type=int, default=27942)
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--no-encode", action="store_true", help="skip the transformer forward (score+fuse only; not the headline metric)")
+    p.add_argument("--token-ids", action="store_true", help="start the step from token ids resident on the device (rounds 1-4) instead of from query strings")
+    p.add_argument("--serial-tokenize", action="store_true", help="tokenise every step's batch on the main thread before launching it (no overlap with the device)")
     p.add_argument("--encoder-size", default="base", choices=["base", "tiny"])
     p.add_argument("--encode-buckets", type=int, default=8, help="length buckets for the query encoder (1 = pad everything to the batch maximum)")
     p.add_argument("--encode-mode", default="packed", choices=["packed", "fused", "hf"],
@@ -73,6 +78,8 @@ def parse():
     p.add_argument("--no-one-gpu-reference", action="store_true",
                    help="sharded workload at N > 1: skip the same workload on rank 0 alone (whole corpus on one GPU), reported next to the N-GPU value")
     p.add_argument("--mmarco-docs", type=int, default=8841823)
+    p.add_argument("--no-corpus-encode", action="store_true", help="sharded workload: skip the per-rank corpus-encode rate on mMARCO-shaped passages")
+    p.add_argument("--encode-sample", type=int, default=16384, help="passages per rank in that measurement")
     p.add_argument("--topk", type=int, default=1000)
     p.add_argument("--rehearsal", action="store_true",
                    help="allow several ranks on one device (gloo only): rehearses the N > 1 control flow on a smaller box; the numbers mean nothing")
@@ -170,7 +177,19 @@ def build_lleqa(args, dev, rank):
         if not args.no_gemm_tuning and args.encode_mode == "packed":
             encoders.enable_gemm_tuning()      # TunableOp picks the hipBLASLt / rocBLAS solution per Linear shape (same fp32 arithmetic)
         d = enc.dim
-        ids, mask, qlen = synth_query_tokens(rng, Q, enc.backbone.config.vocab_size, enc.backbone.config.pad_token_id)
+        if args.token_ids:      # rounds 1-4: the step starts from token ids already on the device
+            ids, mask, qlen = synth_query_tokens(rng, Q, enc.backbone.config.vocab_size, enc.backbone.config.pad_token_id)
+        else:                   # the step starts from STRINGS, as model.encode(queries) does (hybrid.py:101-102): synthetic French-like
+            #                     questions of 5-49 words (8-64 pieces: the token budget of the rounds before), tokenised on the host
+            from fusion_amd.synth_text import FrenchLike
+            from fusion_amd.tokenization import SynthFrenchTokenizer
+            st["texts"] = FrenchLike().sentences(rng, Q, 5, 49, question=True)
+            st["tok"] = SynthFrenchTokenizer()
+            assert st["tok"].vocab_size == enc.backbone.config.vocab_size
+            ids, qlen = st["tok"].encode_np(st["texts"], 64, pad_to_max=True)
+            mask = (np.arange(64)[None, :] < qlen[:, None]).astype(np.int64)
+            st["pinned"] = [torch.empty((Q, 64), dtype=torch.int64).pin_memory() for _ in range(2)]
+            st["pinned_free"] = [None, None]          # the event after which a pinned buffer may be written again
         st["enc"], st["ids"], st["mask"] = enc, torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
         st["qlen"] = qlen   # host token counts (a tokenizer returns them): drives length-bucketed batching
     else:
@@ -206,6 +225,57 @@ def build_lleqa(args, dev, rank):
     st["host"] = dict(idf=idf, toff=toff, pd=pd, tf=tf, lens=lens, qoff=qoff, qterms=qterms)
     st["bm25_postings"] = int(df[qterms].sum())     # postings the batch's query terms touch (terms repeat: bm25.py:152 does not de-duplicate)
     return st
+
+
+def tokenized_batches(st, n):
+    """n tokenised copies of the step's batch of query strings, one per step: text -> ids on the host (tokenizers' encode_batch: all host
+    cores, GIL released) into one of two pinned buffers.  Consumed through tokenization.prefetch, batch i + 1 is produced on a host thread
+    while the device runs batch i."""
+    for i in range(n):
+        buf, ev = st["pinned"][i & 1], st["pinned_free"][i & 1]
+        if ev is not None:
+            ev.synchronize()                 # the upload that read this buffer two steps ago has run
+        ids, qlen = st["tok"].encode_np(st["texts"], 64, pad_to_max=True)
+        buf.copy_(torch.from_numpy(ids))
+        yield i & 1, qlen
+
+
+def upload_ids(st, which, qlen):
+    st["ids"].copy_(st["pinned"][which], non_blocking=True)
+    e = torch.cuda.Event(); e.record()
+    st["pinned_free"][which] = e
+    st["qlen"] = qlen
+
+
+def open_query_stream(st, n, serial=False):
+    """The stream of n tokenised query batches the next run_steps() calls consume.  ONE stream feeds the warm-up and the timed steps, so
+    the timed region starts with the pipeline in steady state (batch i + 1 on the host thread while the device runs batch i) and holds
+    exactly one tokenisation per step: the caller asks for one batch more than it consumes (the last step's look-ahead, unused)."""
+    from fusion_amd.tokenization import prefetch
+    close_query_stream(st)
+    if "texts" in st:
+        src = tokenized_batches(st, n)
+        st["stream"], st["stream_serial"] = iter(src if serial else prefetch(src)), serial
+
+
+def close_query_stream(st):
+    s = st.pop("stream", None)
+    if s is not None:
+        s.close()                            # (a generator: ends the worker thread)
+
+
+def run_steps(st, n):
+    """n passes of the hot path; with query strings each pass takes its batch from the open stream (tokenised one step ahead on a host
+    thread, or -- serial -- right here, after the device has finished the previous pass)."""
+    out = None
+    for _ in range(n):
+        if "stream" in st:
+            which, qlen = next(st["stream"])
+            upload_ids(st, which, qlen)
+        out = step_lleqa(st)
+        if st.get("stream_serial"):
+            torch.cuda.synchronize()
+    return out
 
 
 def step_lleqa(st, ev=None):
@@ -298,8 +368,8 @@ def profiled_traffic(stage, st):
     shape it was collected on, otherwise None.  Returns (bytes, source file)."""
     if (st["Q"], st["N"], st["d"]) != (1024, 27942, 768):
         return None, None
-    pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1,", "bm25_rank": "sort_rows_kernel<1024, 28, 2, false, false",
-            "final_order": "sort_rows_kernel<1024, 28, 2, false, true", "fuse_rrf": "fuse_rank_kernel", "bm25_score": "bm25_kernel", "encode_attn": "attn_varlen_kernel",
+    pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1,", "bm25_rank": "sort_rows_kernel<1024, 28, 2, false, 1>",
+            "final_order": "sort_rows_kernel<1024, 28, 2, false, 2>", "fuse_rrf": "fuse_rank_kernel", "bm25_score": "bm25_kernel", "encode_attn": "attn_varlen_kernel",
             "encode_gelu": "gelu_kernel", "encode_ln": "add_layernorm_kernel"}
     for name in TRAFFIC_PROFILES:
         try:
@@ -559,6 +629,35 @@ def measure_configs(dev, N=27942):
 
 
 
+def mmarco_encode_rate(enc, dev, n_passages=16384, seed=17, shard_rows=8841823 // 8):
+    """config 5's ENCODE leg (sentence_transformers.py:339-345: every 50,000-passage chunk is encoded before it is scored) at mMARCO's
+    shape -- short passages, ~ clip(N(70, 30), 8, 256) word pieces: a different GEMM-row regime from the 296-token LLeQA articles -- through
+    DenseEncoder.encode_ids_corpus (padding-free forward, sub-batches of 65,536 token rows).  Data-parallel: every GPU encodes its own
+    shard, no collective.  Returns passages/s, tokens/s, the fraction of the fp32-MFMA peak and what a 1/8 shard of the corpus costs."""
+    rng = np.random.default_rng(seed)
+    cfg = enc.backbone.config
+    lens = np.clip(rng.normal(70, 30, n_passages), 8, 256).astype(np.int64)
+    ids = torch.from_numpy(rng.integers(7, cfg.vocab_size - 1, (n_passages, 256))).to(dev)
+    T = int(lens.sum())
+    h, ff, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    flops = 2.0 * T * L * (4 * h * h + 2 * h * ff) + 4.0 * L * h * float((lens.astype(np.float64) ** 2).sum())
+    tuning_was_on = torch.cuda.tunable.is_enabled() and torch.cuda.tunable.tuning_is_enabled()
+    if tuning_was_on:
+        torch.cuda.tunable.tuning_enable(False)      # recorded solutions stay in use; new sub-batch shapes are not tuned on first use
+    try:
+        enc.encode_ids_corpus(ids, lens)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        enc.encode_ids_corpus(ids, lens)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    finally:
+        if tuning_was_on:
+            torch.cuda.tunable.tuning_enable(True)
+    return dict(passages=n_passages, tokens=T, mean_len=float(lens.mean()), sub_batch_token_rows=int(enc.packed_tokens), ms=dt * 1e3,
+                passages_per_s=n_passages / dt, tokens_per_s=T / dt, flops=flops, bound="mfma", achieved=flops / dt / 1e12, peak=MFMA_F32_PEAK_TF,
+                unit="TFLOP/s", frac=flops / dt / (MFMA_F32_PEAK_TF * 1e12), shard_rows=shard_rows, full_shard_encode_s=shard_rows / (n_passages / dt),
+                full_corpus_one_gpu_s=8841823 / (n_passages / dt))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # config 4 as a PIPELINE (hybrid.py:344-358,431-455): four systems end to end, per stage, and the corpus-side encode
 # ---------------------------------------------------------------------------------------------------------------------
@@ -711,6 +810,9 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
                         full_corpus_s_estimate=dt * 8, flops=fl, bound="mfma", achieved=fl / dt / 1e12, peak=peak, unit="TFLOP/s",
                         frac=fl / dt / (peak * 1e12)))
     enc["colbert"].amp = True
+    log("corpus encode: mMARCO-shaped passages (config 5's encode leg)")
+    out.append(dict(config="5: mMARCO-shaped corpus ENCODE on one GPU (DPR, fp32, padding-free, 65,536-row sub-batches; each GPU encodes its own 1/8 shard, no collective)",
+                    **{"shape": dict(passages=16384, lens="clip(N(70,30),8,256)")}, **mmarco_encode_rate(enc["dpr"], dev)))
     if tuning_was_on:
         torch.cuda.tunable.tuning_enable(True)
     return out
@@ -815,6 +917,19 @@ def bench_sharded(args, dev, rank, world, dist):
         devs = [f"rank 0: cuda:{dev.index} {torch.cuda.get_device_name(dev)}"]
     del Dsm, sh, whole
 
+    # config 5's encode leg: every rank encodes mMARCO-shaped passages of ITS shard (data-parallel, no collective); slowest rank reported
+    enc_leg = None
+    if enc is not None and not args.no_corpus_encode:
+        mine = mmarco_encode_rate(enc, dev, n_passages=args.encode_sample, seed=17 + rank, shard_rows=hi - lo)
+        rates = [mine]
+        if dist:
+            rates = [None] * world
+            dist.all_gather_object(rates, mine)
+        slow = min(rates, key=lambda r: r["passages_per_s"])
+        enc_leg = dict(slow, ranks=world, passages_per_s_all_ranks=sum(r["passages_per_s"] for r in rates),
+                       what="DenseEncoder.encode_ids_corpus over passages of clip(N(70,30),8,256) pieces on every rank at once; the slowest rank's figures, "
+                            "full_shard_encode_s = this rank's shard rows / its rate")
+
     chunk = min(ShardedDenseIndex.CHUNK, hi - lo)
     rl_all = {}
     if "shard_gemm_filter" in per_launch:   # the shard's GEMM with the threshold filter as its epilogue (everything behind the exact head)
@@ -837,12 +952,14 @@ def bench_sharded(args, dev, rank, world, dist):
                                   f"Q={Q} queries per step, top-{k}; data-parallel CamemBERT-base-shaped fp32 query encoder + all-gather of embeddings, "
                                   "chunked fp32-MFMA cos-sim GEMM with the streaming top-k's threshold filter as its epilogue (no score plane), ONE RCCL all-gather of per-shard top-k + local merge",
                       "corpus": N, "dim": d, "queries_per_step": Q, "topk": k, "encode_in_step": enc is not None,
-                      "parallelism": f"corpus row-sharded x{world} (RCCL all-gather of [Q,k] lists), encoder data-parallel x{world}"},
+                      "parallelism": f"corpus row-sharded x{world} (RCCL all-gather of [Q,k] lists), encoder data-parallel x{world}",
+                      **({"corpus_encode_passages_per_s_per_gpu": round(enc_leg["passages_per_s"], 1), "corpus_encode_mfma_f32_frac": round(enc_leg["frac"], 4),
+                          "full_shard_encode_s_per_gpu": round(enc_leg["full_shard_encode_s"], 1)} if enc_leg else {})},
            "stages_ms": stages, "roofline": rl, "roofline_all": rl_all,
            "collective": {"op": "all_gather_into_tensor x2 (fp32 scores, int64 ids)", "payload_bytes_per_rank": Q * k * 12,
                           "gathered_bytes_per_rank": world * Q * k * 12, "ms": ag_ms,
                           "embeddings_allgather_bytes_per_rank": (-(-Q // world)) * d * 4 if enc is not None else 0},
-           "ranks": devs, "shard_rows": hi - lo,
+           "ranks": devs, "shard_rows": hi - lo, "corpus_encode": enc_leg,
            "sharded_equals_single_gpu": {"equal": same, "corpus": Ns, "queries": 64, "k": k,
                                          "what": "ShardedDenseIndex.search over this world's shards vs one-GPU local_topk of the whole corpus, scores and ids bit for bit"}}
     if rank == 0 and world > 1 and not args.no_one_gpu_reference:
@@ -1061,8 +1178,10 @@ def main():
         return
 
     st = build_lleqa(args, dev, rank)
-    for _ in range(args.warmup):
-        step_lleqa(st)
+    if "texts" in st:   # the tokenising thread's Python part (ids -> arrays, ~4 ms) must not hold the launching thread off for a whole default 5 ms slice
+        sys.setswitchinterval(float(os.environ.get("FZ_SWITCH_INTERVAL", "0.0005")))
+    open_query_stream(st, args.warmup + args.steps + 1, serial=args.serial_tokenize)
+    run_steps(st, args.warmup)
 
     def barrier():
         torch.cuda.synchronize()
@@ -1070,10 +1189,10 @@ def main():
         torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step_lleqa(st)
+    out = run_steps(st, args.steps)      # text -> ids is INSIDE the timed region: one batch tokenised (for the next step) per step
     barrier()
     elapsed = time.perf_counter() - t0
+    close_query_stream(st)
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1091,6 +1210,28 @@ def main():
     stages = {k: v / args.steps for k, v in tot.items()}                               # ms per step
     per_launch = {k: tot[k] / cnt[k] for k in tot}                                     # ms per launch
     stages["encode"] = sum(v for k, v in stages.items() if k.startswith("encode_"))    # the whole forward
+
+    host = None
+    if rank == 0 and "texts" in st:
+        # what text -> ids costs on this host, on its own (device idle), the upload, and the same steps WITHOUT the overlap
+        st["tok"].encode_np(st["texts"], 64, pad_to_max=True)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            st["tok"].encode_np(st["texts"], 64, pad_to_max=True)
+        tok_ms = (time.perf_counter() - t0) / 5 * 1e3
+        h2d_ms = timeit_ms(lambda: st["ids"].copy_(st["pinned"][0], non_blocking=True), n=20)
+        ns = max(2, min(5, args.steps))
+        open_query_stream(st, 2 + ns + 1, serial=not args.serial_tokenize)
+        run_steps(st, 2)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        run_steps(st, ns)
+        torch.cuda.synchronize()
+        other_ms = (time.perf_counter() - t0) / ns * 1e3
+        close_query_stream(st)
+        host = dict(tokenize_ms=tok_ms, h2d_ids_ms=h2d_ms, host_threads=os.cpu_count(),
+                    pieces_per_query=float(np.mean(st["qlen"])), tokenizer="32,005-piece BPE, camembert layout, trained on synthetic French-like text (tools/train_synth_tokenizer.py)",
+                    overlapped=not args.serial_tokenize,
+                    **{("ms_per_step_overlapped" if args.serial_tokenize else "ms_per_step_serial_tokenize"): other_ms})
 
     if rank == 0:
         Q, N, d = st["Q"], st["N"], st["d"]
@@ -1114,8 +1255,12 @@ def main():
                                    f"{'CamemBERT-base-shaped fp32 query encoder (random init; ' + st.get('encode_mode', '') + ' forward' + ('' if args.no_gemm_tuning or st.get('encode_mode') != 'packed' else ', hipBLASLt solutions recorded with TunableOp') + ') + ' if not args.no_encode else 'NO encoder + '}"
                                    "fp32-MFMA cos-sim + BM25(f64) + full stable ranking + RRF(f64) + final order",
                        "queries_per_gpu": Q, "corpus": N, "dim": d, "fusion": "rrf", "systems": ["bm25", "dpr"],
-                       "encode_in_step": not args.no_encode, "parallelism": f"query-sharded x{world}, corpus replicated"},
-            "stages_ms": stages,
+                       "encode_in_step": not args.no_encode, "parallelism": f"query-sharded x{world}, corpus replicated",
+                       "input": "query strings (tokenised on the host inside the timed step)" if host else "token ids resident on the device",
+                       "tokenize_in_step": host is not None, "tokenize_overlapped_with_device": bool(host and host["overlapped"]),
+                       **({"tokenize_ms": round(host["tokenize_ms"], 3), "h2d_ids_ms": round(host["h2d_ids_ms"], 4),
+                           "ms_per_step_serial_tokenize": round(host.get("ms_per_step_serial_tokenize", float("nan")), 3)} if host else {})},
+            "stages_ms": stages, "host": host,
             "score_fuse_qps_per_gpu": Q / (sum(v for k, v in stages.items() if not k.startswith("encode")) * 1e-3),
             "roofline": rl, "roofline_all": all_roof,
         }
@@ -1154,6 +1299,13 @@ def main():
                     res["config"]["config4_percentile_P27943_hbm_frac"] = round(c["frac"], 4)
                 elif name.startswith("boundary: Aggregator.fuse rrf"):
                     res["config"]["boundary_rrf_ms_per_query"] = round(c["ms_per_query"], 2)
+                elif name.startswith("5: mMARCO-shaped corpus ENCODE"):
+                    res["config"]["config5_encode_passages_per_s"] = round(c["passages_per_s"], 1)
+                    res["config"]["config5_encode_tokens_per_s"] = round(c["tokens_per_s"], 1)
+                    res["config"]["config5_encode_mfma_f32_frac"] = round(c["frac"], 4)
+                    res["config"]["config5_full_shard_encode_s_per_gpu_at_8"] = round(c["full_shard_encode_s"], 1)
+                elif name.startswith("5: mMARCO 1/8 shard"):
+                    res["config"]["config5_shard_search_ms_q1024"] = round(c["ms"], 2)
         res["north_star_targets"] = north_star_targets(res)
         emit(res)
     if dist:

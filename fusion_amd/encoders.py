@@ -21,6 +21,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .tokenization import prefetch
+
 CAMEMBERT_BASE = dict(vocab_size=32005, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
                       max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, bos_token_id=5, eos_token_id=6)
 TINY = dict(vocab_size=512, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
@@ -80,26 +82,34 @@ class _Base(nn.Module):
         self.max_doc_length = min(self.max_doc_length, limit)
 
     def _batches(self, sentences, batch_size, max_len, pad_to_max=False):
-        # sort by length as SentenceTransformer.encode does, restore order afterwards
+        # sort by length as SentenceTransformer.encode does, restore order afterwards; the NEXT sub-batch is tokenised on a host thread
+        # while this one's forward is launched (tokenization.prefetch: same batches, same order)
         order = sorted(range(len(sentences)), key=lambda i: -len(sentences[i]))
-        for s in range(0, len(order), batch_size):
-            idx = order[s: s + batch_size]
-            ids, mask = self.tokenizer([sentences[i] for i in idx], max_len, pad_to_max)
+
+        def host():
+            for s in range(0, len(order), batch_size):
+                idx = order[s: s + batch_size]
+                yield (idx, *self.tokenizer([sentences[i] for i in idx], max_len, pad_to_max))
+        for idx, ids, mask in prefetch(host()):
             yield idx, ids.to(self._device, non_blocking=True), mask.to(self._device, non_blocking=True)
 
 
 def _token_batches(base, sentences, max_len, batch_size, tokenize=None):
     """Sub-batches for the padding-free forward, longest sentences first (as SentenceTransformer.encode sorts), cut by an
     estimate of the TOKEN count (activations stay under ~1 GB) rather than by sentence count.
-    Yields (indices into `sentences`, ids [b, L] on the HOST, lengths [b] numpy)."""
+    Yields (indices into `sentences`, ids [b, L] on the HOST, lengths [b] numpy); sub-batch i + 1 is tokenised on a host thread while
+    the caller runs sub-batch i on the device (tokenization.prefetch)."""
     order = sorted(range(len(sentences)), key=lambda i: -len(sentences[i]))
-    s = 0
-    while s < len(order):
-        step = max(batch_size, base.packed_tokens // min(max_len, 8 + 2 * len(sentences[order[s]].split())))
-        idx = order[s: s + step]
-        ids, mask = (tokenize or base.tokenizer)([sentences[i] for i in idx], max_len)
-        yield idx, ids, mask.sum(1).numpy()
-        s += step
+
+    def host():
+        s = 0
+        while s < len(order):
+            step = max(batch_size, base.packed_tokens // min(max_len, 8 + 2 * len(sentences[order[s]].split())))
+            idx = order[s: s + step]
+            ids, mask = (tokenize or base.tokenizer)([sentences[i] for i in idx], max_len)
+            yield idx, ids, mask.sum(1).numpy()
+            s += step
+    return prefetch(host())
 
 
 def _id_batches(lengths, max_tokens: int):
@@ -671,13 +681,21 @@ class ColbertEncoder(_Base):
         return tok.contiguous(), torch.from_numpy(off).to(self._device)
 
 
-def random_init(kind: str, device="cuda", size: str = "base", seed: int = 0):
-    """CamemBERT-base-shaped (or tiny) encoder with random weights: `kind` in {'dpr','splade','colbert'}."""
+def random_init(kind: str, device="cuda", size: str = "base", seed: int = 0, tokenizer: str = "hash"):
+    """CamemBERT-base-shaped (or tiny) encoder with random weights: `kind` in {'dpr','splade','colbert'}.
+    tokenizer: 'hash' (whitespace words hashed into the vocabulary) or 'synth-fr' (base size only: the 32,005-piece BPE of
+    tokenization.SynthFrenchTokenizer -- real sub-word work on the host)."""
     cfg = dict(CAMEMBERT_BASE if size == "base" else TINY)
     g = torch.random.get_rng_state()
     torch.manual_seed(seed)
     try:
-        tok = HashTokenizer(cfg["vocab_size"], cfg["pad_token_id"], cfg["bos_token_id"], cfg["eos_token_id"])
+        if tokenizer == "synth-fr":
+            from .tokenization import SynthFrenchTokenizer
+            tok = SynthFrenchTokenizer()
+            if tok.vocab_size != cfg["vocab_size"]:
+                raise ValueError(f"the synthetic tokenizer has {tok.vocab_size} pieces, the {size} model {cfg['vocab_size']}")
+        else:
+            tok = HashTokenizer(cfg["vocab_size"], cfg["pad_token_id"], cfg["bos_token_id"], cfg["eos_token_id"])
         if kind == "dpr":
             return DenseEncoder(_backbone(cfg), tok, device)
         if kind == "splade":

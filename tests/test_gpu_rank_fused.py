@@ -218,3 +218,23 @@ def test_placed_sequence_that_does_not_fill_the_row(ops, oracle, N):
     np.testing.assert_array_equal(order.cpu().numpy(), e_order)
     np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)
     np.testing.assert_array_equal(rank.cpu().numpy(), e_rank)
+
+
+def test_encode_from_strings_with_overlapped_tokenisation_equals_encode_from_ids():
+    """DenseEncoder.encode(strings) -- sub-batch i + 1 tokenised (the 32,005-piece synthetic-French BPE) on a host thread
+    while sub-batch i runs the padding-free forward -- equals the forward over ids tokenised up front in the caller's thread."""
+    from fusion_amd import encoders
+    from fusion_amd.synth_text import FrenchLike
+    enc = encoders.random_init("dpr", device="cuda", size="base", seed=0, tokenizer="synth-fr")
+    enc.packed_tokens = 4096                                       # several sub-batches out of a small input
+    rng = np.random.default_rng(9)
+    texts = FrenchLike().sentences(rng, 300, 3, 60, question=True)
+    got = enc.encode(texts, batch_size=16)
+    ids, lens = enc.tokenizer.encode_np(texts, enc.max_doc_length, pad_to_max=False)
+    exp = torch.empty_like(got)
+    for idx in encoders._id_batches(lens, 4096):
+        sel = torch.from_numpy(np.ascontiguousarray(idx))
+        exp[sel.cuda()] = enc.encode_ids_packed(torch.from_numpy(ids[idx]).cuda(), lens[idx])
+    assert float((got - exp).abs().max()) <= 1e-5 * float(exp.abs().max())
+    again = enc.encode(texts, batch_size=16)
+    assert torch.equal(got, again)                                  # the worker thread changes nothing run to run
