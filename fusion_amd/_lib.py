@@ -51,6 +51,7 @@ _PROTOS = {
     "fz_sort_bucket_rank_rows": (_i, [_vp, _i]),
     "fz_sort_rows_desc": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_sort_rows_desc_placed": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fz_sort_rank_fused_workspace_bytes": (_sz, [_i, _i, _i]),
     "fz_sort_rank_fused_desc": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_rrf_terms_f64": (_i, [_i, _i, _vp, _vp]),
     "fz_select_topk_f": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -64,6 +64,7 @@ struct SortArgs {
     const int32_t* fuse_ranks[FZ_MAX_SYSTEMS];   // [rows][key_row_stride] each
     const int32_t* fuse_lens;    // [S][fuse_rows] list lengths (bcf's n)
     int fuse_S, fuse_method, fuse_rows;
+    double* fuse_gen_plane;      // [rows][key_row_stride]: where the fused scores of a row the fast form FLAGS are written out for the generic launch
     int fuse_first_is_pos;       // placed form with init_rank == fuse_ranks[0] (every list full: first-insertion order = system 0's ranking):
                                  //   the position just loaded IS system 0's rank, its plane is not read a second time
 };
@@ -100,6 +101,29 @@ __global__ void rrf_terms_kernel(int count, int fast, double* __restrict__ out) 
     if (r < count) out[r] = fast ? recip_small_int_f64((double)(60 + r + 1)) : 1.0 / (double)(60 + r + 1);
 }
 
+// FUSE: the fused scores of the rows the fast form flagged (practically never: > 2,048 keys sharing a high word), written out as a plain
+// float64 row for the generic eight-pass launch -- whose FUSE instantiation (~500 B of scratch per lane) made even an EMPTY launch cost
+// 40 us: above ROCr's per-queue scratch limit the dispatch allocates its scratch anew (283 MB of page zeroing per launch, rocprofv3).
+// The arithmetic is fuse_rank_kernel's (IEEE division); every other row's workgroup exits at once.
+__global__ __launch_bounds__(256) void fuse_flagged_rows_kernel(SortArgs a) {
+    const int row = blockIdx.x;                      // one workgroup per row: rows + 1 wave launches to find out that nothing is flagged
+    if (a.row_flags[row] == 0) return;
+    for (int j = threadIdx.x; j < a.n_total; j += blockDim.x) {
+        const size_t off = (size_t)row * a.key_row_stride + j;
+        double acc = 0.0;
+        bool present = false;
+        for (int s = 0; s < a.fuse_S; ++s) {
+            const int r = a.fuse_ranks[s][off];
+            if (r >= 0) {
+                const double n = (double)a.fuse_lens[(size_t)s * a.fuse_rows + row];
+                acc = acc + (a.fuse_method == FZ_RRF ? 1.0 / (double)(60 + r + 1) : (n - (double)r + 1.0) / n);
+                present = true;
+            }
+        }
+        a.fuse_gen_plane[off] = present ? acc : -(double)INFINITY;
+    }
+}
+
 // GEN (fp64 only): the generic eight-pass form, run as a second launch for the rows the fast form flags (see below).
 // MODE: which of the kernel's many callers an instantiation serves -- what is not served is gone at compile time, and with it the row
 // pointers and flags that otherwise stay live from the prologue to the output phase (they were the shipped hot kernels' spills):
@@ -112,6 +136,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     constexpr bool FUSE = MODE == SORT_FUSE, LEAN = MODE != SORT_ANY;
     static_assert(!GEN || KW == 2, "the generic form exists for fp64 keys only");
     static_assert(!FUSE || KW == 2, "rank fusion forms float64 keys");
+    static_assert(!(FUSE && GEN), "rows the fused fast form flags are sorted by the plain generic form from a materialised score row");
     constexpr int NW = T / 64;
     constexpr uint32_t SENT = 0xffffffffu;
     constexpr int LG = (KW == 2) ? 7 : 14;         // global loads in flight per thread before the first use (one HBM latency per group)
@@ -1535,9 +1560,10 @@ static int launch_cfg(const SortArgs& a, int prows, hipStream_t st) {
     constexpr size_t lds = SortLds<T, E, KW>::bytes;
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
     static unsigned long long lds_set = 0ull, lds_set_gen = 0ull;   // per (T,E,KW,FUSE) instantiation
+    constexpr int GEN_MODE = MODE == SORT_FUSE ? (T == 1024 ? SORT_ROWS : SORT_ANY) : MODE;   // flagged rows of the fused form: the plain generic kernel
     if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, KW, false, MODE>, lds, lds_set)) return rc;
     if constexpr (KW == 2)
-        if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, 2, true, MODE>, lds, lds_set_gen)) return rc;
+        if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, 2, true, GEN_MODE>, lds, lds_set_gen)) return rc;
     if (KW == 2 && !a.row_flags) return FZ_ERR_WORKSPACE;
     SortArgs b = a;
     {   // FZ_SORT_BUCKET_RANK=0: digit passes only (A/B runs, tests of the two forms against each other)
@@ -1547,7 +1573,14 @@ static int launch_cfg(const SortArgs& a, int prows, hipStream_t st) {
     sort_rows_kernel<T, E, KW, false, MODE><<<prows, T, lds, st>>>(b);
     FZ_LAUNCH_CHECK();
     if constexpr (KW == 2) {   // rows the fast form flagged (a dirty run of > 17 equal high words): generic eight passes; all others exit at once
-        sort_rows_kernel<T, E, 2, true, MODE><<<prows, T, lds, st>>>(a);
+        SortArgs g = a;
+        if constexpr (MODE == SORT_FUSE) {   // their fused scores as a plain row first (every other row: nothing), then sorted like any float64 plane
+            if (!a.fuse_gen_plane) return FZ_ERR_WORKSPACE;
+            fuse_flagged_rows_kernel<<<(unsigned)prows, 256, 0, st>>>(a);
+            FZ_LAUNCH_CHECK();
+            g.keys = a.fuse_gen_plane; g.fuse_S = 0;
+        }
+        sort_rows_kernel<T, E, 2, true, GEN_MODE><<<prows, T, lds, st>>>(g);
         FZ_LAUNCH_CHECK();
     }
     return FZ_OK;
@@ -1846,6 +1879,14 @@ extern "C" int fz_sort_rows_desc_placed(const void* keys, int key_bits, const in
 // Rank fusion + final order in one kernel (hybrid.py:248-252 + :301-306): what fz_fuse_rank_f64 followed by fz_sort_rows_desc[_placed] on its
 // float64 plane computes -- the same fused scores bit for bit (formed per key on load by the expression of fuse_rank_kernel), the same
 // stable order -- without the [rows][ld] float64 plane ever being written or read (229 MB out + 458 MB in at Q = 1024, N = 27,942).
+static size_t fused_flags_bytes(int rows) { return ((size_t)rows * 4 + 255) / 256 * 256; }
+// row flags + one float64 row per row: where a row the fast form cannot finish (flagged; practically never) gets its fused scores written
+// out for the generic launch.  Untouched otherwise: the bytes are reserved, not moved.
+extern "C" size_t fz_sort_rank_fused_workspace_bytes(int rows, int n, int ld) {
+    if (rows <= 0 || n <= 0 || ld < n) return 0;
+    return fused_flags_bytes(rows) + (size_t)rows * ld * 8;
+}
+
 extern "C" int fz_sort_rank_fused_desc(const int32_t* const* ranks_h, const int32_t* lens, int S, int method, const int32_t* init_order,
                                        const int32_t* init_rank, const int32_t* row_len, int rows, int n, int ld, int32_t* order,
                                        double* sorted_scores, int32_t* rank, void* workspace, size_t workspace_bytes, void* stream) {
@@ -1867,8 +1908,9 @@ extern "C" int fz_sort_rank_fused_desc(const int32_t* const* ranks_h, const int3
     a.chunks = 1; a.chunk_len = n;
     a.order = order; a.sorted_keys = sorted_scores; a.rank = rank;
     a.out_row_stride = ld; a.out_chunk_stride = 0; a.out_limit = n;
-    if (!workspace || workspace_bytes < fz_sort_workspace_bytes(64, rows, n)) return FZ_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < fz_sort_rank_fused_workspace_bytes(rows, n, ld)) return FZ_ERR_WORKSPACE;
     a.row_flags = (int32_t*)workspace;
+    a.fuse_gen_plane = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + fused_flags_bytes(rows));
     return launch_sort(a, 2, rows, n, as_stream(stream));
 }
 

@@ -376,7 +376,7 @@ def sort_rank_fused(ranks: list[torch.Tensor], lens: torch.Tensor, method: str, 
         row_len = row_len.contiguous()
         _need(row_len.numel() == rows, f"sort_rank_fused(row_len): expected {rows} entries, got {row_len.numel()}")
     lib = _lib.lib()
-    wsb = int(lib.fz_sort_workspace_bytes(64, rows, n))
+    wsb = int(lib.fz_sort_rank_fused_workspace_bytes(rows, n, ld))
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
     check(lib.fz_sort_rank_fused_desc(_ptr_array(ranks), _ptr(lens), len(ranks), RANK_METHODS[method], _ptr(init_order), _ptr(init_rank),
                                       _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk), _ptr(rank), _ptr(ws), wsb, _stream(ranks[0])),

@@ -137,7 +137,10 @@ int fz_sort_rows_desc_placed(const void* keys, int key_bits, const int32_t* init
  * ranks_h: HOST array of S device rank planes [rows][ld] int32 (-1 = the system does not list the document); lens [S][rows] int32 (device).
  * Incoming sequence (the fused dict's first-insertion order): init_rank (placed; when it is ranks_h[0] itself -- every list full -- that
  * plane is read once), or init_order (gathered; row_len = the number of listed documents), or neither (columns in order).
- * n <= fz_sort_max_n_f64() (FZ_ERR_UNSUPPORTED beyond: use the two calls).  Workspace: fz_sort_workspace_bytes(64, rows, n). */
+ * n <= fz_sort_max_n_f64() (FZ_ERR_UNSUPPORTED beyond: use the two calls).  Workspace: fz_sort_rank_fused_workspace_bytes(rows, n, ld) --
+ * one flag per row + one float64 row per row, written only for rows whose repair the fast form hands to the generic eight-pass launch
+ * (more than 2,048 keys sharing a high key word: not a ranker's scores; reserved, not moved, otherwise). */
+size_t fz_sort_rank_fused_workspace_bytes(int rows, int n, int ld);
 int fz_sort_rank_fused_desc(const int32_t* const* ranks_h, const int32_t* lens, int S, int method, const int32_t* init_order,
                             const int32_t* init_rank, const int32_t* row_len, int rows, int n, int ld, int32_t* order,
                             double* sorted_scores, int32_t* rank, void* workspace, size_t workspace_bytes, void* stream);

@@ -238,3 +238,27 @@ def test_encode_from_strings_with_overlapped_tokenisation_equals_encode_from_ids
     assert float((got - exp).abs().max()) <= 1e-5 * float(exp.abs().max())
     again = enc.encode(texts, batch_size=16)
     assert torch.equal(got, again)                                  # the worker thread changes nothing run to run
+
+
+@pytest.mark.parametrize("N", [5000, 9000, 27942])
+def test_rows_the_fast_form_hands_to_the_generic_launch(ops, oracle, N):
+    """Fused scores with thousands of keys under ONE high key word and distinct low words (bcf with list lengths of 2^31 - 1: every term is
+    1 - r / 2^31, a sum of three moves by 2^-31 per rank): the fast form's in-place repair gives such a row up, its fused scores are written out
+    as a plain float64 row (fuse_flagged_rows_kernel) and the generic eight-pass launch sorts it -- same lists as the two-call form and the oracle."""
+    rng = np.random.default_rng(N)
+    Q = 3
+    ranks = [np.stack([rng.permutation(N) for _ in range(Q)]).astype(np.int32) for _ in range(3)]
+    lens = np.full((3, Q), 2**31 - 1, dtype=np.int32)
+    f = oracle.fuse_rank(ranks, lens, "bcf")
+    hi = np.sort(f.view(np.uint64) >> 32, axis=1)
+    longest = max(int(np.max(np.diff(np.flatnonzero(np.concatenate([[True], row[1:] != row[:-1], [True]]))))) for row in hi)
+    assert longest > 2048, longest                                         # beyond what the fast form repairs in place
+    rp = [plane(ops, r) for r in ranks]
+    order, sk, rank = ops.sort_rank_fused(rp, dev(lens), "bcf", init_rank=rp[0], want_rank=True, covers_all=True)
+    o0 = np.argsort(ranks[0], axis=1, kind="stable").astype(np.int32)
+    e_order, e_sk, e_rank = oracle.sort_rows_desc(f, init_order=o0, want_rank=True)
+    np.testing.assert_array_equal(order.cpu().numpy(), e_order)
+    np.testing.assert_array_equal(sk.cpu().numpy(), e_sk)
+    np.testing.assert_array_equal(rank.cpu().numpy(), e_rank)
+    o2, s2, _ = ops.sort_rows_desc(ops.fuse_rank(rp, dev(lens), "bcf"), init_rank=rp[0], covers_all=True)
+    assert torch.equal(order, o2) and torch.equal(sk, s2)
