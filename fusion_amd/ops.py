@@ -1018,6 +1018,17 @@ class SparseIndex:
     def tensors(self):
         return self.toff, self.pdoc, self.pw
 
+    def dense_cached(self) -> torch.Tensor:
+        """to_dense(), padded for the GEMM, built once and kept WHILE the index's buffers are the ones it was built from (a rebuilt or
+        re-pointed index re-densifies); drop_dense() gives the N x V float32 matrix (3.6 GB at LLeQA size) back."""
+        key = (self.toff.data_ptr(), self.pdoc.data_ptr(), self.pw.data_ptr(), self.nnz, self.N, self.V)
+        if getattr(self, "_dense_key", None) != key:
+            self._dense, self._dense_key = pad_dim(self.to_dense()), key
+        return self._dense
+
+    def drop_dense(self) -> None:
+        self._dense, self._dense_key = None, None
+
     def to_dense(self) -> torch.Tensor:
         """The [N, V rounded up to 4] float32 matrix the index was built from (normalised rows)."""
         D = torch.zeros((self.N, round_up(max(self.V, 1), 4)), dtype=torch.float32, device=self.pw.device)
@@ -1095,9 +1106,7 @@ def sparse_cos_scores(Qe: torch.Tensor, index: SparseIndex, max_query_density: f
     if density(Qn[:, :index.V]) > max_query_density:
         # re-densified ONCE per index and kept (N x V float32: 3.6 GB at LLeQA size -- a fresh allocation + scatter per query batch would
         # cost more than the GEMM it feeds); a query encoder that is not sparse stays on this path for every batch
-        if getattr(index, "_dense", None) is None:
-            index._dense = pad_dim(index.to_dense())
-        return dot_scores(Qn, index._dense)
+        return dot_scores(Qn, index.dense_cached())
     return sparse_dot(index, *sparse_rows(Qn, index.V))
 
 

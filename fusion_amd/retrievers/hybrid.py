@@ -267,7 +267,8 @@ def pack_ranked_lists(ranked_lists: dict):
     # ids are) map through a direct table -- one gather per list; a sparse id space falls back to searchsorted
     lo = min((int(c.min()) for n in names for c, _ in raw[n] if c.size), default=0)
     hi = max((int(c.max()) for n in names for c, _ in raw[n] if c.size), default=0)
-    direct = hi - lo < (1 << 26)
+    n_ids = sum(int(c.size) for n in names for c, _ in raw[n])            # ids seen, with repeats: an upper bound of the distinct ones
+    direct = hi - lo < (1 << 26) and hi - lo <= 64 * max(n_ids, 1024)    # a few thousand ids spread over 2^26 values: not a 320 MB table
     if direct:
         seen = np.zeros(hi - lo + 1, dtype=bool)
         for n in names:

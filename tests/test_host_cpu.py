@@ -114,12 +114,12 @@ def test_integration_md_binding_matches_the_abi():
     exec(compile(code, "INTEGRATION.md", "exec"), ns)             # module level: loads the library, checks the ABI version, sets argtypes
     L = ns["L"]
     bound = [n for n in _lib.EXPORTS if getattr(getattr(L, n), "argtypes", None) is not None]
-    assert {"fz_sort_rows_desc", "fz_sort_rows_desc_placed", "fz_fuse_rank_f64", "fz_sort_workspace_bytes"} <= set(bound)
+    assert {"fz_sort_rows_desc", "fz_sort_rank_fused_desc", "fz_sort_rank_fused_workspace_bytes", "fz_sort_workspace_bytes"} <= set(bound)
     for n in bound:
         assert list(getattr(L, n).argtypes) == list(_lib._PROTOS[n][1]), n
     calls = [c for c in ast.walk(ast.parse(code)) if isinstance(c, ast.Call) and isinstance(c.func, ast.Attribute)
              and isinstance(c.func.value, ast.Name) and c.func.value.id == "L" and c.func.attr.startswith("fz_")]
-    assert len(calls) >= 5
+    assert len(calls) >= 4
     for c in calls:
         assert len(c.args) == len(_lib._PROTOS[c.func.attr][1]) and not c.keywords, (c.func.attr, len(c.args))
     assert f"fz_abi_version() == {_lib.ABI_VERSION}" in code

@@ -42,6 +42,8 @@ def test_vectorised_packing_equals_the_entry_by_entry_route():
     _same_packing({"s": [L([(7, float("nan")), (5, 1.0)])]})
     _same_packing({"s": [L([(7, np.float32(0.25)), (9, np.float64(2.0)), (8, 3)])]})              # numpy scalars / ints as scores
     _same_packing({"s": [L([(2 ** 40, 1.0), (3, 0.5)])]})                                          # a sparse id space: searchsorted route
+    _same_packing({"s": [L([(2 ** 25, 1.0), (3, 0.5), (77, 0.25)])], "t": [L([(77, 2.0), (2 ** 24 + 1, 1.0)])]})   # a handful of ids over 2^25 values: ADVICE r4 --
+    #                                                                                                no 320 MB direct table for them (searchsorted route too)
     _same_packing({"s": [L([("x", 1.0), ("y", 0.5)])], "t": [L([("y", 2.0)])]})                   # string ids: the generic route
     _same_packing({"s": [L([(True, 1.0), (2, 0.5)])]})                                             # bool is not a plain int
     _same_packing({"s": [L([(2 ** 70, 1.0), (2, 0.5)])]})                                          # does not fit int64
