@@ -124,6 +124,46 @@ def case_placed(rng):
     return f"placed sort Q={Q} N={N}"
 
 
+def case_rank_fused(rng):
+    """fz_sort_rank_fused_desc (rank fusion formed in the final sort's load phase) against the oracle's fuse_rank + stable sort: rrf / bcf,
+    1-5 systems, full lists placed by system 0's rank plane / partial lists gathered by first-insertion order / placed sequences with
+    holes / plain columns; every row-length class of the sort kernel; huge list lengths (bcf terms packed under one high key word: rows the
+    fast form flags for the generic launch)."""
+    method = str(rng.choice(["rrf", "bcf"]))
+    S, Q = int(rng.integers(1, 6)), int(rng.integers(1, 4))
+    N = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 28673)]))
+    mode = str(rng.choice(["full", "partial", "holes", "plain"]))
+    _, ranks, orders, lens = systems(rng, S, Q, N, mode in ("partial", "holes"))
+    if method == "bcf" and rng.random() < 0.3:
+        lens_f = np.full_like(lens, 2**31 - 1)                          # (a - r + 1) / a with a = 2^31 - 1: thousands of keys per high word
+    else:
+        lens_f = lens if mode != "plain" else np.maximum(lens, 1)
+    if method == "bcf":
+        lens_f = np.maximum(lens_f, 1)
+    rp = [plane(r) for r in ranks]
+    f = oracle.fuse_rank(ranks, lens_f, method)
+    if mode == "full":
+        o, sk, rk = ops.sort_rank_fused(rp, dev(lens_f), method, init_rank=rp[0], want_rank=True, covers_all=True)
+        eo, esk, erk = oracle.sort_rows_desc(f, init_order=orders[0], want_rank=True)
+    elif mode == "partial":
+        ins, U = ops.insertion_order([plane(x) for x in orders], dev(lens), N)
+        o, sk, rk = ops.sort_rank_fused(rp, dev(lens_f), method, init_order=ins, row_len=U, want_rank=True)
+        e_ins, e_U = oracle.insertion_order(orders, lens, N)
+        eo, esk, erk = oracle.sort_rows_desc(f, init_order=e_ins, row_len=e_U, want_rank=True)
+    elif mode == "holes":
+        e_ins, e_U = oracle.insertion_order(orders, lens, N)
+        inv = np.full((Q, N), -1, dtype=np.int32)
+        for q in range(Q):
+            inv[q, e_ins[q, : e_U[q]]] = np.arange(e_U[q], dtype=np.int32)
+        o, sk, rk = ops.sort_rank_fused(rp, dev(lens_f), method, init_rank=plane(inv), row_len=dev(e_U), want_rank=True)
+        eo, esk, erk = oracle.sort_rows_desc(f, init_order=e_ins, row_len=e_U, want_rank=True)
+    else:
+        o, sk, rk = ops.sort_rank_fused(rp, dev(lens_f), method, want_rank=True)
+        eo, esk, erk = oracle.sort_rows_desc(f, want_rank=True)
+    np.testing.assert_array_equal(o.cpu().numpy(), eo); np.testing.assert_array_equal(sk.cpu().numpy(), esk); np.testing.assert_array_equal(rk.cpu().numpy(), erk)
+    return f"rank-fused sort {method} {mode} S={S} Q={Q} N={N}"
+
+
 def case_fuse(rng):
     S, Q = int(rng.integers(1, 5)), int(rng.integers(1, 5))
     N = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 33000)]))
@@ -686,7 +726,7 @@ def case_empty(rng):
     return f"empty batches n={n}"
 
 
-CASES = [case_encoder, case_lists, case_empty, case_sort, case_sort_bucket, case_sort_bucket, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
+CASES = [case_encoder, case_lists, case_empty, case_rank_fused, case_rank_fused, case_sort, case_sort_bucket, case_sort_bucket, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
          case_topk_stream, case_segments, case_fused_search, case_sort_stats, case_select, case_splade_head, case_fuse_ranked, case_maxsim, case_f16_kernels, case_encoder_amp, case_rerun, case_rerun, case_sparse, case_tables, case_tables]
 
 
