@@ -721,9 +721,9 @@ def measure_pipeline4(dev, N=27942, queries=(1024, 195)):
                                      slice_off=bm["slice_off"], want_f32=True)      # as BM25.search_device: the float32 plane from the same launch
             mark("bm25_score")
             st4 = torch.empty((4, Q), dtype=torch.float32, device=dev)
-            o_b, sk_b, r_b = ops.sort_rows_desc(B, want_rank=True, stats_out=st4)
+            o_b, _, r_b = ops.sort_rows_desc(B, want_keys=False, want_rank=True, stats_out=st4)   # as BM25.search_device
             sys_b = RankedSystem(scores=B32, order=o_b, rank=r_b, lens=torch.full((Q,), N, dtype=torch.int32, device=dev), ids=ids_np,
-                                 sorted_scores=sk_b, full=True, scores64=B, score_sorted=True, stats4=st4)
+                                 full=True, scores64=B, score_sorted=True, stats4=st4)
             mark("bm25_rank")
             e = enc["dpr"].encode_ids_packed(qids_d, qlen); mark("dpr_encode")
             S_d = ops.dot_scores(ops.normalize_rows(e), Dn); mark("dpr_score")

@@ -992,7 +992,10 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             const bool nan = ks[i] == 0u;           // every NaN maps to the all-zero key; no other key has a zero high word
             const bool sgn = (asc >> 31) & 1u;
             signm |= (uint32_t)sgn << i; nanm |= (uint32_t)nan << i;
-            if (o_kw && p < lim) o_kw[2 * p + 1] = nan ? 0x7ff80000u : (sgn ? (asc & 0x7fffffffu) : ~asc);
+            // the sorted score's HIGH half is final here, its low half only after the repair: parked COMPACTLY at the head of the row's
+            // score output (word p; whole lines) and stored together with the low half as one 8-byte store in the output phase -- two
+            // strided 4-byte passes over the row wrote every line of it twice (2 x 229 MB per 1024 x 27,942 batch, rocprofv3 WRITE_SIZE)
+            if (o_kw && p < lim) o_kw[p] = nan ? 0x7ff80000u : (sgn ? (asc & 0x7fffffffu) : ~asc);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -1250,6 +1253,16 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = 0xffffffffu;   // columns outside the sequence
         __syncthreads();
     }
+    [[maybe_unused]] uint32_t hiw[(KW == 2 && !GEN) ? E : 1];
+    if constexpr (KW == 2 && !GEN) {
+        if (o_kw) {   // (block-uniform) the parked high halves back -- ALL of them, then a barrier: the 8-byte stores below land on the words they were parked in
+            SLOT_FRESH();
+#pragma unroll
+            for (int i = 0; i < E; ++i) { const int p = (slot0 + i * 64); hiw[i] = o_kw[p < lim ? p : 0]; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
         SLOT_FRESH();
 #pragma unroll
     for (int i = 0; i < E; ++i) {
@@ -1261,7 +1274,11 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             if (o_order) o_order[p] = oc;
             if (o_ids) o_ids[p] = imap ? imap[elem(col)] : (oc < 0 ? (int64_t)-1 : a.id_base + (int64_t)oc);
             if (KW == 1) { if (o_kf) o_kf[p] = desc_key_f32_inv(ks[i]); }
-            else if (o_kw) o_kw[2 * p] = ((nanm >> i) & 1u) ? 0u : (((signm >> i) & 1u) ? ~ks[i] : ks[i]);   // low half of desc_key_f64_inv
+            else if (o_kw) {
+                const uint32_t low = ((nanm >> i) & 1u) ? 0u : (((signm >> i) & 1u) ? ~ks[i] : ks[i]);   // low half of desc_key_f64_inv
+                if constexpr (!GEN) reinterpret_cast<uint2*>(o_kw)[p] = make_uint2(low, hiw[i]);
+                else o_kw[2 * p] = low;                            // (generic form: its high halves went out in their own pass)
+            }
             if (rank_via_lds) exch[col] = (uint32_t)p;          // col < n_total <= T*E
             else if (o_rank && oc >= 0) o_rank[oc] = p;
         }

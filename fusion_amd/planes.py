@@ -90,15 +90,22 @@ class RankedSystem:
     def N(self) -> int:
         return self.scores.shape[1]
 
+    def list_scores(self) -> torch.Tensor:
+        """[Q, N] the scores in LIST order (rank r -> score of the document there; -inf past the list's end), in the ranking keys' dtype.
+        The rankers do not have the sort write this plane any more (round 5: nothing on the device reads it -- every fusion kernel works
+        on the planes by corpus position -- and for float64 keys it cost 8 B per document in two partial-line passes): it is one gather,
+        made when the reference-typed lists are asked for."""
+        if self.sorted_scores is not None:
+            return self.sorted_scores
+        src = self.scores64 if self.scores64 is not None else self.scores
+        got = torch.gather(src, 1, self.order.clamp(min=0).long())
+        return torch.where(self.order >= 0, got, torch.full_like(got, float("-inf")))
+
     def to_lists(self, topk: int | None = None) -> list[list[dict]]:
         """-> the reference's RankedLists (hybrid.py:75,106,137)."""
         order = self.order.cpu().numpy()
         lens = self.lens.cpu().numpy()
-        if self.sorted_scores is not None:
-            ss = self.sorted_scores.cpu().numpy()
-        else:
-            sc = self.scores.cpu().numpy()
-            ss = np.take_along_axis(sc, np.maximum(order, 0).astype(np.int64), axis=1)
+        ss = self.list_scores().cpu().numpy()
         out = []
         with _gc_paused():
             for q in range(self.Q):

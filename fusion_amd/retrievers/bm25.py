@@ -77,13 +77,13 @@ class BM25:
         stats4 = None   # mean | std | min | max of every list's float32 scores: by-products of the ranking sort (rows that fit one workgroup)
         if N <= ops.sort_max_n(torch.float64) and Q > 0:
             stats4 = torch.empty((4, Q), dtype=torch.float32, device=self.device)
-        order, sk, rank = ops.sort_rows_desc(sc64, want_rank=True, stats_out=stats4)   # ranks from the float64 scores, ties -> ascending index
+        order, _, rank = ops.sort_rows_desc(sc64, want_keys=False, want_rank=True, stats_out=stats4)   # ranks from the float64 scores, ties -> ascending index
         lens = torch.full((Q,), N, dtype=torch.int32, device=self.device)
         # float32 plane for the normalisations (torch.tensor(scores, dtype=float32), hybrid.py:255), written by the scoring kernel from
         # the accumulators it holds (no conversion pass); the float64 scores stay for the 'none' passthrough, which keeps BM25's Python
         # floats (hybrid.py:280).  Rounding is monotone: the float32 scores are in descending order along the float64 ranking too.
         return RankedSystem(scores=sc32, order=order, rank=rank, lens=lens,
-                            ids=np.arange(N, dtype=np.int64) if ids is None else ids, sorted_scores=sk, full=True,
+                            ids=np.arange(N, dtype=np.int64) if ids is None else ids, full=True,
                             scores64=sc64, score_sorted=True, stats4=stats4)
 
     def search_all(self, queries: list[str], top_k: int) -> list:

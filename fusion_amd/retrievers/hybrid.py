@@ -62,11 +62,11 @@ def _rank_scores(scores: torch.Tensor, ids: np.ndarray, return_topk: int | None)
     stats4 = None
     if N <= ops.sort_max_n(scores.dtype) and Q > 0 and (full or scores.dtype == torch.float32):
         stats4 = torch.empty((4, Q), dtype=torch.float32, device=scores.device)
-    order, sk, rank = ops.sort_rows_desc(scores, want_rank=True, stats_out=stats4, stats_len=None if full or stats4 is None else lens)
+    order, _, rank = ops.sort_rows_desc(scores, want_keys=False, want_rank=True, stats_out=stats4, stats_len=None if full or stats4 is None else lens)
     if not full:  # lists truncated to top-k: docs beyond rank k are absent from the list (in place: the planes keep their padded rows)
         rank.masked_fill_(rank >= k, -1)
         order[:, k:] = -1
-    return RankedSystem(scores=scores, order=order, rank=rank, lens=lens, ids=ids, sorted_scores=sk, full=full, score_sorted=True, stats4=stats4)
+    return RankedSystem(scores=scores, order=order, rank=rank, lens=lens, ids=ids, full=full, score_sorted=True, stats4=stats4)   # (list-order scores: RankedSystem.list_scores, on demand)
 
 
 class Ranker:

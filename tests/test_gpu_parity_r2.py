@@ -65,7 +65,7 @@ def test_search_matches_reference(ops, sim):
     S = ops.dot_scores(Qn, Dn)
     # (a) the full ranking hybrid.py:103 asks for (top_k = N): Ranker's score -> rank path
     rs = _rank_scores(S, np.arange(N), None)
-    order, sk = rs.order.cpu().numpy(), rs.sorted_scores.cpu().numpy()
+    order, sk = rs.order.cpu().numpy(), rs.list_scores().cpu().numpy()
     e_ids, e_sc = z[f"ids__{sim}__kN_qc100_dc500000"], z[f"scores__{sim}__kN_qc100_dc500000"]
     for q in range(Q):
         assert_ranked_close(order[q], sk[q], e_ids[q], e_sc[q], tol)
