@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
-RECORDED = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[2-9]_bench_*.json")))
+RECORDED = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r0[2-9]_bench_*.json")) if not p.endswith("_line.json"))   # full records
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[5-9]_bench_*_line.json")))                                            # compact lines as printed
 
 
 def _reject_constant(c):
@@ -42,6 +43,19 @@ def test_compact_line_from_recorded_detail(path):
             assert k in back["cpu_baseline"], k
     for v in back["config"].values():
         assert not isinstance(v, (dict, list)) or len(json.dumps(v)) < 200
+
+
+@pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
+def test_recorded_compact_lines_are_what_the_driver_can_parse(path):
+    raw = open(path).read().strip()
+    assert "\n" not in raw and len(raw) < bench.LINE_BUDGET
+    line = json.loads(raw, parse_constant=_reject_constant)
+    for k in REQUIRED:
+        assert k in line, k
+    assert "roofline_all" not in line and "configs_measured" not in line and line["detail"] == "bench_detail.json"
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
 
 
 def test_recorded_files_cover_both_workloads():
