@@ -177,15 +177,22 @@ def build_lleqa(args, dev, rank):
         if not args.no_gemm_tuning and args.encode_mode == "packed":
             encoders.enable_gemm_tuning()      # TunableOp picks the hipBLASLt / rocBLAS solution per Linear shape (same fp32 arithmetic)
         d = enc.dim
-        if args.token_ids:      # rounds 1-4: the step starts from token ids already on the device
+        tok = None
+        if not args.token_ids:
+            try:
+                from fusion_amd.tokenization import SynthFrenchTokenizer
+                tok = SynthFrenchTokenizer()
+                assert tok.vocab_size == enc.backbone.config.vocab_size
+            except Exception as ex:   # (a box without the `tokenizers` wheel: measure the rest rather than nothing -- and say so in `config.input`)
+                log(f"no tokenizer ({type(ex).__name__}: {ex}): the step starts from resident token ids")
+                tok = None
+        if tok is None:         # rounds 1-4: the step starts from token ids already on the device
             ids, mask, qlen = synth_query_tokens(rng, Q, enc.backbone.config.vocab_size, enc.backbone.config.pad_token_id)
         else:                   # the step starts from STRINGS, as model.encode(queries) does (hybrid.py:101-102): synthetic French-like
             #                     questions of 5-49 words (8-64 pieces: the token budget of the rounds before), tokenised on the host
             from fusion_amd.synth_text import FrenchLike
-            from fusion_amd.tokenization import SynthFrenchTokenizer
             st["texts"] = FrenchLike().sentences(rng, Q, 5, 49, question=True)
-            st["tok"] = SynthFrenchTokenizer()
-            assert st["tok"].vocab_size == enc.backbone.config.vocab_size
+            st["tok"] = tok
             ids, qlen = st["tok"].encode_np(st["texts"], 64, pad_to_max=True)
             mask = (np.arange(64)[None, :] < qlen[:, None]).astype(np.int64)
             st["pinned"] = [torch.empty((Q, 64), dtype=torch.int64).pin_memory() for _ in range(2)]

@@ -21,10 +21,13 @@ struct Bm25Args {
                                   //   from the same LDS accumulators -- the separate plane-sized conversion pass (fz_f64_to_f32) goes away
 };
 
-// LDS-resident accumulators: one workgroup = (query, slice of BM25_SLICE documents).  The random read-modify-writes of
-// the posting walk hit LDS (ds_read_b64 / ds_write_b64) instead of HBM/L2; the slice is written out once, coalesced.
-// Postings of a term are sorted by document, so the slice's sub-range is found by two block-uniform binary searches.
-constexpr int BM25_SLICE = 14336;   // 14336 fp64 accumulators = 112 KiB of the CU's 160 KiB LDS
+// LDS-resident accumulators AND length norms: one workgroup = (query, slice of BM25_SLICE documents).  The random read-modify-writes of
+// the posting walk hit LDS (ds_read_b64 / ds_write_b64) instead of HBM/L2, and so does the per-posting read of the document's length
+// norm k1 (1 - b + b |d| / avgdl) -- round 5: as a gather from the [N] table in L2 it was one 64-byte sector per posting, ~110 k of them
+// per query (the frequent terms of a Zipf vocabulary list most of the corpus); the slice's norms now come in once per workgroup,
+// coalesced.  The slice is written out once, coalesced.  Postings of a term are sorted by document, so the slice's sub-range is found by
+// two block-uniform binary searches (or read from the per-index table).
+constexpr int BM25_SLICE = 7168;    // 7168 fp64 accumulators + 7168 fp64 norms = 112 KiB of the CU's 160 KiB LDS
 
 __device__ __forceinline__ int64_t lower_bound_doc(const int32_t* __restrict__ pdoc, int64_t lo, int64_t hi, int doc) {
     while (lo < hi) {   // first e in [lo, hi) with pdoc[e] >= doc  (uniform: scalar loads)
@@ -37,14 +40,18 @@ __device__ __forceinline__ int64_t lower_bound_doc(const int32_t* __restrict__ p
 constexpr int BM25_TERMS = 256;     // query terms whose posting ranges are resolved per batch
 
 __global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
-    extern __shared__ __attribute__((aligned(16))) double acc[];          // [BM25_SLICE] accumulators
+    extern __shared__ __attribute__((aligned(16))) double acc[];          // [BM25_SLICE] accumulators | [BM25_SLICE] length norms
+    double* nrm = acc + BM25_SLICE;
     __shared__ int64_t s_e0[BM25_TERMS], s_e1[BM25_TERMS];
     __shared__ double s_w[BM25_TERMS];
     const int q = blockIdx.y;
     const int d0 = blockIdx.x * BM25_SLICE;
     const int d1 = (d0 + BM25_SLICE < a.N) ? d0 + BM25_SLICE : a.N;
     const int n = d1 - d0;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) acc[j] = 0.0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        acc[j] = 0.0;
+        nrm[j] = a.doc_norm ? a.doc_norm[d0 + j] : a.k1 * (1.0 - a.b + a.b * (double)a.doc_len[d0 + j] / a.avgdl);   // the sub-expression of bm25.py:154, once per document
+    }
     const int64_t p0 = a.qoff[q], p1 = a.qoff[q + 1];
     for (int64_t pb = p0; pb < p1; pb += BM25_TERMS) {
         const int nt = (int)((p1 - pb < BM25_TERMS) ? p1 - pb : BM25_TERMS);
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
             // vs 0.339 ms per 1024 queries)
             constexpr int U = 4;
             for (int64_t eb = e0; eb < e1; eb += (int64_t)blockDim.x * U) {
-                int doc[U]; double tf[U], kd[U];
+                int doc[U]; double tf[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int64_t e = eb + (int64_t)u * blockDim.x + threadIdx.x;
@@ -86,14 +93,9 @@ __global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int dj = doc[u] < 0 ? d0 : doc[u];
-                    kd[u] = a.doc_norm ? a.doc_norm[dj] : a.k1 * (1.0 - a.b + a.b * (double)a.doc_len[dj] / a.avgdl);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
                     if (doc[u] >= 0) {
                         const double num = w * (tf[u] * (a.k1 + 1.0));
-                        const double den = tf[u] + kd[u];
+                        const double den = tf[u] + nrm[doc[u] - d0];
                         acc[doc[u] - d0] = acc[doc[u] - d0] + num / den;   // postings of one term hit distinct documents: no race
                     }
                 }
@@ -162,7 +164,7 @@ extern "C" int fz_bm25_scores_f64_f32(const int64_t* toff, const int32_t* pdoc, 
     if (Q == 0 || N == 0) return FZ_OK;           // empty tensors carry null pointers
     if (!toff || !idf || !doc_len || !qoff || !scores) return FZ_ERR_ARG;
     Bm25Args a{toff, pdoc, ptf, idf, doc_len, doc_norm, slice_off, avgdl, k1, b, qoff, qterms, N, scores, lds, scores32, lds32};
-    constexpr size_t lds_bytes = (size_t)BM25_SLICE * sizeof(double);
+    constexpr size_t lds_bytes = 2 * (size_t)BM25_SLICE * sizeof(double);
     static unsigned long long lds_set = 0ull;
     if (int rc = raise_lds_limit((const void*)bm25_kernel, lds_bytes, lds_set)) return rc;
     dim3 grid((unsigned)((N + BM25_SLICE - 1) / BM25_SLICE), (unsigned)Q);

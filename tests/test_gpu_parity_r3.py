@@ -379,14 +379,15 @@ def test_bm25_slice_offsets_change_nothing_but_the_time(ops, oracle):
     bit for bit, on a corpus of more than two document slices with terms that live in one slice only, in none, or in all."""
     from fusion_amd.retrievers.bm25 import BM25
     rng = np.random.default_rng(12)
-    V, N = 300, 30_000                                            # three slices of 14,336 documents
+    V, N = 300, 30_000                                            # five slices of 7,168 documents
     p = 1.0 / np.arange(1, V + 1) ** 1.1; p /= p.sum()
     vocab = np.array([f"w{i}" for i in range(V)])
     docs = [" ".join(rng.choice(vocab, size=int(rng.integers(3, 30)), p=p)) for _ in range(N)]
     docs[5] += " onlyhere"; docs[20_000] += " onlythere onlythere"
     queries = ["w0 w1 onlyhere", "onlythere w7 w7 nowhere", "w299 w150", "nowhere"]
     ours = BM25(docs, 2.5, 0.2, device="cuda")
-    assert ours.slice_off is not None and tuple(ours.slice_off.shape) == (len(ours.vocab), 4)
+    slices = -(-N // int(ops._lib.lib().fz_bm25_slice_docs()))
+    assert slices >= 3 and ours.slice_off is not None and tuple(ours.slice_off.shape) == (len(ours.vocab), slices + 1)
     so = ours.slice_off.cpu().numpy(); toff = ours.toff.cpu().numpy()
     assert np.array_equal(so[:, 0], toff[:-1]) and np.array_equal(so[:, -1], toff[1:]) and np.all(np.diff(so, axis=1) >= 0)
     with_table = ours.scores(queries).cpu().numpy()

@@ -87,7 +87,7 @@ def test_workspace_planning_is_consistent():
     assert L.fz_topk_merge(None, None, 2, 1, 10, None, None, None) == ERR
     assert L.fz_topk_allgather(None, None, 1, 10, None, 2, None, None, None, 0, None) == ERR
     assert L.fz_bm25_scores_f64(None, None, None, None, None, None, None, 1.0, 2.5, 0.2, None, None, 1, 1, None, 1, None) == ERR
-    assert L.fz_bm25_slice_offsets(None, None, 5, 10, None, None) == ERR and L.fz_bm25_slice_docs() == 14336
+    assert L.fz_bm25_slice_offsets(None, None, 5, 10, None, None) == ERR and L.fz_bm25_slice_docs() == 7168
     assert L.fz_gold_ranks_f32(None, None, None, None, 2, 1, 1, 1, 1, None, None) == ERR
     assert L.fz_tune_metrics_f64(None, None, None, 1, None, None, None, 1, None, 1, 0, 0, 0, 1, 1, None, None) == ERR
     assert L.fz_attn_varlen_f32(None, 1, None, 1, 12, 64, 0.125, None, 1, None) == ERR
