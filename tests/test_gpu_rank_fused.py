@@ -262,3 +262,38 @@ def test_rows_the_fast_form_hands_to_the_generic_launch(ops, oracle, N):
     np.testing.assert_array_equal(rank.cpu().numpy(), e_rank)
     o2, s2, _ = ops.sort_rows_desc(ops.fuse_rank(rp, dev(lens), "bcf"), init_rank=rp[0], covers_all=True)
     assert torch.equal(order, o2) and torch.equal(sk, s2)
+
+
+@pytest.mark.parametrize("N", [700, 27942])
+def test_raw_c_abi_with_outputs_left_out(ops, oracle, N):
+    """fz_sort_rank_fused_desc through ctypes, as a non-Python host would call it, with outputs a caller may not want: no `order` (the kernel
+    then has nowhere to park the low sort words and forms them a second time), no `sorted_scores` (nothing parked, nothing stored), rank only."""
+    import ctypes as C
+    from fusion_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(N)
+    Q, S = 3, 3
+    ranks = [np.stack([rng.permutation(N) for _ in range(Q)]).astype(np.int32) for _ in range(S)]
+    lens = np.full((S, Q), N, dtype=np.int32)
+    rp = [plane(ops, r) for r in ranks]
+    ld = rp[0].stride(0) if Q > 1 else rp[0].shape[1]
+    ptrs = (C.c_void_p * S)(*[r.data_ptr() for r in rp])
+    lens_d = dev(lens)
+    nws = L.fz_sort_rank_fused_workspace_bytes(Q, N, ld)
+    ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+    f = oracle.fuse_rank(ranks, lens, "rrf")
+    o0 = np.argsort(ranks[0], axis=1, kind="stable").astype(np.int32)
+    e_order, e_sk, e_rank = oracle.sort_rows_desc(f, init_order=o0, want_rank=True)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for want in (("order",), ("scores",), ("rank",), ("scores", "rank"), ("order", "scores", "rank")):
+        order = torch.full((Q, ld), -7, dtype=torch.int32, device="cuda") if "order" in want else None
+        sk = torch.full((Q, ld), -7.0, dtype=torch.float64, device="cuda") if "scores" in want else None
+        rank = torch.full((Q, ld), -7, dtype=torch.int32, device="cuda") if "rank" in want else None
+        rc = L.fz_sort_rank_fused_desc(ptrs, p(lens_d), S, 0, None, p(rp[0]), None, Q, N, ld, p(order), p(sk), p(rank), p(ws), nws, st)
+        assert rc == 0, (want, rc)
+        torch.cuda.synchronize()
+        if order is not None: np.testing.assert_array_equal(order[:, :N].cpu().numpy(), e_order)
+        if sk is not None: np.testing.assert_array_equal(sk[:, :N].cpu().numpy(), e_sk)
+        if rank is not None: np.testing.assert_array_equal(rank[:, :N].cpu().numpy(), e_rank)
+    assert L.fz_sort_rank_fused_desc(ptrs, p(lens_d), S, 0, None, p(rp[0]), None, Q, N, ld, None, None, None, p(ws), nws - 1, st) == _lib.FZ_ERR_WORKSPACE

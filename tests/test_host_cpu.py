@@ -1,5 +1,6 @@
 """CPU-side tests (-m "not gpu"): the C-ABI library loads and exports every symbol the header declares (no compute
 call without a GPU), host logic of the drop-in module, and the N>1 collective path under gloo (world_size 2)."""
+import ctypes as C
 import json
 import os
 import re
@@ -74,6 +75,22 @@ def test_workspace_planning_is_consistent():
     assert L.fz_dot_scores_f32(None, 4, None, 4, -1, 1, 4, None, 1, None) == ERR
     assert L.fz_maxsim_f16(None, None, None, 0, 512, 1, 64, 1, 128, None, 1, None) == ERR
     assert L.fz_sort_rows_desc_placed(None, 32, None, None, 1, 1, 1, None, None, None, None, 0, None) == ERR
+    # round 5 (ABI 18): rank fusion in the final sort; rows, n, ld -> one flag per row (256-byte rounded) + one float64 row per row
+    for rows, n, ld in ((1, 1, 64), (195, 27942, 27968), (1024, 27942, 27968)):
+        assert L.fz_sort_rank_fused_workspace_bytes(rows, n, ld) == (rows * 4 + 255) // 256 * 256 + rows * ld * 8
+    assert L.fz_sort_rank_fused_workspace_bytes(0, 5, 64) == 0 and L.fz_sort_rank_fused_workspace_bytes(4, 70, 64) == 0
+    one = C.c_void_p(64)                                           # (never dereferenced: every call below fails its argument checks)
+    assert L.fz_sort_rank_fused_desc(None, None, 0, 0, None, None, None, 1, 1, 1, None, None, None, None, 0, None) == ERR        # S = 0
+    assert L.fz_sort_rank_fused_desc(None, None, 9, 0, None, None, None, 1, 1, 1, None, None, None, None, 0, None) == ERR        # S > 8
+    assert L.fz_sort_rank_fused_desc(None, None, 2, 7, None, None, None, 1, 1, 1, None, None, None, None, 0, None) == ERR        # method
+    assert L.fz_sort_rank_fused_desc(None, None, 2, 0, one, one, None, 1, 1, 1, None, None, None, None, 0, None) == ERR          # both sequences
+    assert L.fz_sort_rank_fused_desc(None, None, 2, 0, None, None, None, 1, 4, 2, None, None, None, None, 0, None) == ERR        # ld < n
+    assert L.fz_sort_rank_fused_desc(None, None, 2, 0, None, None, None, 1, 1, 1, None, None, None, None, 0, None) == ERR        # no rank planes
+    assert L.fz_sort_rank_fused_desc(None, None, 2, 0, None, None, None, 0, 1, 1, None, None, None, None, 0, None) == _lib.FZ_OK  # nothing to do
+    assert L.fz_rrf_terms_f64(-1, 1, None, None) == ERR and L.fz_rrf_terms_f64((1 << 20) + 1, 1, None, None) == ERR and L.fz_rrf_terms_f64(4, 1, None, None) == ERR
+    assert L.fz_rrf_terms_f64(0, 1, None, None) == _lib.FZ_OK
+    assert L.fz_bm25_scores_f64_f32(None, None, None, None, None, None, None, 1.0, 2.5, 0.2, None, None, 1, 1, None, 1, None, 1, None) == ERR
+    assert L.fz_bm25_scores_f64_f32(None, None, None, None, None, None, None, 1.0, 2.5, 0.2, None, None, 1, 4, one, 4, one, 2, None) == ERR   # lds32 < N
     assert L.fz_fuse_rank_f64(None, None, 0, 1, 1, 1, 0, None, None) == ERR
     assert L.fz_fuse_rank_f64(None, None, 99, 1, 1, 1, 0, None, None) == ERR
     assert L.fz_row_stats_f32(None, None, 1, 1, 1, 1, None, None, None) == ERR
