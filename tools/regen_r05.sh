@@ -9,6 +9,7 @@ step "bench Q=195"     200 python bench.py --queries 195 --no-configs > $O/bench
 step "bench mmarco n1" 400 python bench.py --workload mmarco --steps 3 --warmup 1 > $O/bench_mmarco_n1.json 2> $O/bench_mmarco_n1.err; cp bench_detail.json $O/bench_mmarco_n1_detail.json
 step "launcher 2 gloo" 400 env FUSION_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --rehearsal --mmarco-docs 2000000 --steps 2 --warmup 1 > $O/bench_launcher_2ranks_1gpu_gloo.json 2> $O/bench_launcher.err
 step "kernel bench"    300 python tools/bench_kernels.py > $O/kernel_bench.jsonl 2> $O/kernel_bench.err
+step "gemm query rows" 200 python tools/bench_gemm_q.py > $O/gemm_query_rows.jsonl 2> $O/gemm_query_rows.err
 step "profile bench"   600 bash tools/profile_bench.sh > $O/profile_bench.log 2>&1
 cp gpurun_out/hbm_traffic.json $O/ 2>/dev/null
 find gpurun_out/prof_stats -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
