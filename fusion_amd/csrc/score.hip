@@ -70,6 +70,9 @@ struct GemmArgs {
     int full, halves;          // tile ids < full are whole 128x128 tiles; then `halves` 128x64 half tiles (at most one per workgroup)
     int tail_ids, tail_row0;   // ids of the tiles of a last query block of 1..96 rows (0: none), which start at row tail_row0 ...
     int tail_rows;             // ... and are 32, 64 or 96 rows high
+    // straggler rows (round 5): the last 1..4 query rows beyond a multiple of 32 ride INSIDE the 64-row tail tiles as a 4-row SLAB (see
+    // gemm_stream's SLAB form); Q above counts the rows of the tiles only
+    int slab_row0, slab_rows;  // first straggler row, how many (0: none)
     // FILTER form (fz_dot_scores_filter_f32): no score plane; what beats a query's threshold goes to its candidate list
     const float* tau;          // [QB * 128]: tau[q] for q < Q, +inf beyond
     float* cand_s;             // [Q][cap]
@@ -92,15 +95,28 @@ enum { EPI_STORE = 0, EPI_FILTER = 1, EPI_SPLADE = 2 };
 // during the last two k-tiles of the tile before it, and its score stores drain under the next tile's MFMAs -- a workgroup
 // pays the pipeline fill once per launch, not once per tile.
 template <int BN, int MI /* 32-row MFMA blocks per wave */, int WN /* waves along the corpus side: 2 (2 x 2 waves) or 4 (1 x 4) */, bool RAGGED /* d is not a whole number of k-tile pairs */, int EPI,
-          bool FLAT = false /* tile id b = corpus columns [b BN, (b + 1) BN) of the row band at row_origin (the 7-row-block cover) */>
+          bool FLAT = false /* tile id b = corpus columns [b BN, (b + 1) BN) of the row band at row_origin (the 7-row-block cover) */,
+          int NSLAB = 0 /* the batch's last 1..8 rows ride along as NSLAB 4-row slabs on v_mfma_f32_4x4x1_16b_f32 (64-row tail tiles only) */>
 __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int first, const int end, const int step, const int qblocks, const int row_origin) {
     constexpr int WM = 4 / WN;           // waves along the query side
     constexpr int BMT = 32 * MI * WM;    // tile height: 128 (whole query blocks: 2 x 2 waves, MI = 2), 64 (MI = 1) or 32 (1 x 4 waves, MI = 1)
     constexpr int AROWS = BMT / 32;      // staging float4 per thread for the query tile
     constexpr int NI = BN / (32 * WN);   // 32x32 MFMA tiles per wave along N (wave tile = 32 MI x BN / WN)
     constexpr int BROWS = BN / 32;       // staging float4 per thread for the corpus tile
-    // [stage][A: 128 rows | B: BN rows][LDT]
-    constexpr int BUF = (BMT + BN) * LDT;
+    // Straggler rows as SLABS.  A batch a few rows over a multiple of 32 -- the LLeQA test split is 195 = 6 x 32 + 3, the dev
+    // split 201 = 6 x 32 + 9 -- paid a whole 32-row MFMA block for them.  v_mfma_f32_4x4x1_16b_f32 multiplies 16 independent 4 x 4 blocks with
+    // K = 1: with the SAME four query rows in every block's A operand and 64 different corpus columns in the B operands one instruction adds one k
+    // to 4 rows x 64 columns -- an eighth of a row block's work.  The stragglers ride inside the 64-row tail tiles (2 x 2 waves, wave tile 32 rows
+    // x 64 columns): their (up to 8) query rows are staged behind the corpus tile, the waves of the upper row pair read the corpus tile a second
+    // time as "lane = column" with every fragment group and issue that group's slab MFMAs BETWEEN its 32x32x2's (a dependent chain of 4x4x1's on its
+    // own stalls on every link: as a block behind the tile's MFMAs a slab cost a third of a k-tile instead of an eighth) in the tile stream's own
+    // k order -- 0, 4, 1, 5, 2, 6, 3, 7: lanes 0-31 of a 32x32x2 hold k, lanes 32-63 k + 4 -- so that a straggler's score is the same chain of
+    // fused multiply-adds, bit for bit.
+    constexpr bool SLAB = NSLAB > 0;
+    static_assert(!SLAB || (MI == 1 && WN == 2 && BN == 128 && EPI == EPI_STORE && !FLAT && NSLAB <= 2), "slabs ride in the 64-row tail tiles of the plain GEMM");
+    constexpr int SROWS = 4 * NSLAB;     // staged straggler rows
+    // [stage][A: 128 rows | B: BN rows | straggler rows][LDT]
+    constexpr int BUF = (BMT + BN + SROWS) * LDT;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w / WN, wc = w % WN;
 
@@ -139,6 +155,8 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
     const float* abase;
     const float* bbase;
     int32_t oa[AROWS], ob[BROWS];
+    [[maybe_unused]] const float* const sbase = g.A + (size_t)g.slab_row0 * g.lda;                      // the straggler rows: the same for every tile
+    [[maybe_unused]] const int32_t os = SLAB ? (min(srow, max(g.slab_rows, 1) - 1) * g.lda + sk) * 4 : 0;   // (threads of rows >= SROWS load a copy and store nothing)
     auto point_at = [&](int row0, int col0) {
         row0 = min(row0, g.Q - 1);         // (a half tile may start past the last corpus row)
         col0 = min(col0, g.N - 1);
@@ -150,7 +168,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
         for (int i = 0; i < BROWS; ++i) ob[i] = (min(srow + 32 * i, g.N - 1 - col0) * g.ldb + sk) * 4;
     };
     const int KT = ((g.d + 2 * BK - 1) / (2 * BK)) * 2;
-    struct Stage { float4 a[AROWS], b[BROWS]; };
+    struct Stage { float4 a[AROWS], b[BROWS]; float4 s; };
     // `edge` (compile time): this k-tile may reach past d -- only the last two of a tile can; all the others take the plain path
     auto gload = [&](Stage& r, int kt, auto edge) __attribute__((always_inline)) {
         const char* ab = reinterpret_cast<const char*>(abase + kt * BK);
@@ -161,6 +179,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
         for (int i = 0; i < AROWS; ++i) r.a[i] = *reinterpret_cast<const float4*>(ab + (ptrdiff_t)(oa[i] - back));
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) r.b[i] = *reinterpret_cast<const float4*>(bb + (ptrdiff_t)(ob[i] - back));
+        if constexpr (SLAB) r.s = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sbase + kt * BK) + (ptrdiff_t)(os - back));
     };
     auto sstore = [&](const Stage& r, int kt, auto edge) __attribute__((always_inline)) {   // kt: the k-tile the registers hold
         float* As = lds + (kt & 1) * BUF;
@@ -175,10 +194,17 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
         for (int i = 0; i < AROWS; ++i) *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDT + sk) = keep(r.a[i]);
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDT + sk) = keep(r.b[i]);
+        if constexpr (SLAB) { if (srow < SROWS) *reinterpret_cast<float4*>(Bs + (BN + srow) * LDT + sk) = keep(r.s); }
     };
 
     f32x16 acc[MI][NI];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] f32x4 sacc[SLAB ? NSLAB : 1];
     auto clear = [&]() {
+        if constexpr (SLAB) {
+#pragma unroll
+            for (int r = 0; r < NSLAB; ++r) sacc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -188,7 +214,7 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
     };
 
     // fragments of one group of 8 k's: lanes 0-31 hold k 0..3, lanes 32-63 k 4..7 (see the header)
-    struct Frag { float4 a[MI], b[NI]; };
+    struct Frag { float4 a[MI], b[NI]; float4 sb[SLAB ? 2 : 1], sa[SLAB ? NSLAB : 1][2]; };   // (SLAB: the group's corpus rows as lane = column, its slab rows)
     const int fr = lane & 31, fh = (lane >> 5) * 4;
     const int aoff = (wr * (32 * MI) + fr) * LDT + fh, boff = BMT * LDT + (wc * (BN / WN) + fr) * LDT + fh;
     auto fread = [&](Frag& f, int buf, int kg) __attribute__((always_inline)) {
@@ -198,6 +224,18 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
         for (int mi = 0; mi < MI; ++mi) f.a[mi] = *reinterpret_cast<const float4*>(As + mi * 32 * LDT);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) f.b[ni] = *reinterpret_cast<const float4*>(Bs + ni * 32 * LDT);
+        if constexpr (SLAB) {
+            if (wr == 0) {                                                   // (wave-uniform: the upper row pair's waves carry the slabs of their 64 columns)
+                const float* Bt = lds + buf * BUF + BMT * LDT;
+                const float* bl = Bt + (wc * 64 + lane) * LDT + kg * 8;      // lane = corpus column: its row of the tile
+                f.sb[0] = *reinterpret_cast<const float4*>(bl); f.sb[1] = *reinterpret_cast<const float4*>(bl + 4);
+#pragma unroll
+                for (int r = 0; r < NSLAB; ++r) {
+                    const float* al = Bt + (BN + 4 * r + (lane & 3)) * LDT + kg * 8;   // lane & 3 = row inside the slab
+                    f.sa[r][0] = *reinterpret_cast<const float4*>(al); f.sa[r][1] = *reinterpret_cast<const float4*>(al + 4);
+                }
+            }
+        }
     };
     auto fmma = [&](const Frag& f) __attribute__((always_inline)) {
 #pragma unroll
@@ -209,6 +247,15 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
                     const float av = kk == 0 ? f.a[mi].x : kk == 1 ? f.a[mi].y : kk == 2 ? f.a[mi].z : f.a[mi].w;
                     const float bv = kk == 0 ? f.b[ni].x : kk == 1 ? f.b[ni].y : kk == 2 ? f.b[ni].z : f.b[ni].w;
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
+                    if constexpr (SLAB) {
+                        if (wr == 0 && ni < NSLAB) {                         // slab ni's two k's of this step (k, then k + 4) behind a 32x32x2: its chain never waits
+                            const float4 a0 = f.sa[ni][0], a1 = f.sa[ni][1], b0 = f.sb[0], b1 = f.sb[1];
+                            const float x0 = kk == 0 ? a0.x : kk == 1 ? a0.y : kk == 2 ? a0.z : a0.w, y0 = kk == 0 ? b0.x : kk == 1 ? b0.y : kk == 2 ? b0.z : b0.w;
+                            const float x1 = kk == 0 ? a1.x : kk == 1 ? a1.y : kk == 2 ? a1.z : a1.w, y1 = kk == 0 ? b1.x : kk == 1 ? b1.y : kk == 2 ? b1.z : b1.w;
+                            sacc[ni] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, y0, sacc[ni], 0, 0, 0);
+                            sacc[ni] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1, y1, sacc[ni], 0, 0, 0);
+                        }
+                    }
                 }
     };
 
@@ -391,6 +438,17 @@ __device__ __forceinline__ void gemm_stream(const GemmArgs& g, float* lds, int f
                 }
             }
         } else {
+        if constexpr (SLAB) {
+            // C/D of the 4x4x1: register v = row v of the block, lane = 4 * block + column -> lane l holds column l of the wave's 64
+            const int c = ccol + wc * 64 + lane;
+            if (wr == 0 && c < g.N) {
+#pragma unroll
+                for (int r = 0; r < NSLAB; ++r)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (4 * r + v < g.slab_rows) g.C[(size_t)(g.slab_row0 + 4 * r + v) * g.ldc + c] = sacc[r][v];
+            }
+        }
         const bool whole = crow + BMT <= g.Q && ccol + BN <= g.N;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -441,7 +499,12 @@ __global__ __launch_bounds__(256, 2) void dot_scores_kernel(GemmArgs g) {
             if (t < g.tail_ids) {            // (workgroup-uniform)
                 __syncthreads();
                 if (g.tail_rows == 32) gemm_stream<128, 1, 4, RAGGED, EPI>(g, lds, t, g.tail_ids, G, 1, g.tail_row0);
-                else if (g.tail_rows == 64) gemm_stream<128, 1, 2, RAGGED, EPI>(g, lds, t, g.tail_ids, G, 1, g.tail_row0);
+                else if (g.tail_rows == 64) {
+                    if constexpr (EPI == EPI_STORE) {
+                        if (g.slab_rows > 0) gemm_stream<128, 1, 2, RAGGED, EPI, false, 1>(g, lds, t, g.tail_ids, G, 1, g.tail_row0);
+                        else gemm_stream<128, 1, 2, RAGGED, EPI>(g, lds, t, g.tail_ids, G, 1, g.tail_row0);
+                    } else gemm_stream<128, 1, 2, RAGGED, EPI>(g, lds, t, g.tail_ids, G, 1, g.tail_row0);
+                }
                 else gemm_stream<128, 3, 4, RAGGED, EPI>(g, lds, t, g.tail_ids, G, 1, g.tail_row0);
             }
         }
@@ -476,6 +539,16 @@ extern "C" int fz_normalize_rows_f32(const float* X, int rows, int d, int ldx, f
 }
 
 static int launch_gemm(GemmArgs& g, int epi, hipStream_t st) {
+    // the last 1..4 rows over a multiple of 32 ride as ONE slab inside the 64-row tail tiles: Q % 128 in 65 .. 68 (195: the LLeQA test batch).
+    // Measured (profiles/r05_gemm_slabs_ab.json): Q = 195 0.0907 -> 0.0867 ms (0.587 -> 0.614 of the fp32-MFMA peak), Q = 193 0.0888 -> 0.0852; two
+    // slabs (Q = 197 .. 200) bring nothing over the 7-row-block cover (0.629 vs 0.636), three (Q = 201) lose: those batches keep the cover.
+    static const bool slabs_on = [] { const char* e = getenv("FZ_GEMM_SLABS"); return !(e && e[0] == '0'); }();   // (A/B runs)
+    g.slab_rows = 0; g.slab_row0 = 0;
+    if (epi == EPI_STORE && slabs_on && g.Q % BM > 64 && g.Q % BM <= 68) {
+        g.slab_rows = g.Q % BM - 64;
+        g.slab_row0 = g.Q - g.slab_rows;
+        g.Q = g.slab_row0;                                 // the tiles see the rows before the stragglers only
+    }
     // rows -> whole 128-row query blocks + a last block in its own height class (32, 64 or 96 rows; more than 96: a padded whole block)
     int nfull = g.Q / BM;
     const int rem = g.Q % BM;

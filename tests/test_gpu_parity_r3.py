@@ -352,6 +352,11 @@ def test_dot_scores_do_not_depend_on_the_row_class(ops, d):
     assert torch.equal(S195[64:192], ops.dot_scores(Qn[64:192].contiguous(), Dn))       # ... and inside a whole 128-row block
     S211 = ops.dot_scores(Qn, Dn)                                    # 128 + 83: 64 + 32
     assert torch.equal(S211[:195], S195)
+    # round 5: Q % 128 in 65 .. 68 -- the stragglers ride as ONE 4-row slab (v_mfma_f32_4x4x1_16b_f32) inside the 64-row tail tiles: same bits
+    for q in (193, 194, 196):
+        assert torch.equal(ops.dot_scores(Qn[:q].contiguous(), Dn), S211[:q]), q
+    S67 = ops.dot_scores(Qn[128:195].contiguous(), Dn)               # 67 rows: a 64-row tail + a 3-row slab, no whole block in front
+    assert torch.equal(S67, S195[128:195])
     S137 = ops.dot_scores(Qn[:137].contiguous(), Dn)                 # 128 + 32 (9 rows used)
     assert torch.equal(S137, S195[:137])
     S16 = ops.dot_scores(Qn[:16].contiguous(), Dn)                   # a small batch: 32-row tiles only
@@ -362,7 +367,7 @@ def test_dot_scores_do_not_depend_on_the_row_class(ops, d):
     assert float((S195.double() - ref).abs().max()) <= 2e-6
 
 
-@pytest.mark.parametrize("Q", [3, 64, 65, 80, 81, 129, 144, 145, 195, 201, 209, 300, 1024 + 67])
+@pytest.mark.parametrize("Q", [3, 64, 65, 68, 69, 80, 81, 129, 144, 145, 193, 195, 196, 197, 200, 201, 208, 209, 300, 1024 + 67])
 def test_dot_scores_every_tiling_of_the_query_rows(ops, oracle, Q):
     g = torch.Generator(device="cuda").manual_seed(Q)
     N, d = 1283, 64
