@@ -579,7 +579,7 @@ def measure_configs(dev, N=27942):
                         shape=dict(Q=Q, N=N, S=2), **roof("fuse_rank_kernel", ms, Q * N * (2 * 4 + 8), "hbm")))
         ms_full = timeit_ms(lambda: Aggregator.fuse_device(two, "rrf", None, {}, {}), n=5)
         ms_top = timeit_ms(lambda: Aggregator.fuse_device(two, "rrf", None, {}, {}, topk=1000), n=5)
-        out.append(dict(config="1: Aggregator.fuse_device rrf BM25+DPR, topk=1000 (fz_select_topk_f + two 2k-key sorts; NOT what Aggregator.fuse returns) vs the full lists",
+        out.append(dict(config="1: Aggregator.fuse_device rrf BM25+DPR, topk=1000 (round 5: the fused full sort, cut -- cheaper than fuse + fz_select_topk_f + two 2k-key sorts) vs the full lists",
                         shape=dict(Q=Q, N=N, S=2, k=1000), ms=ms_top, ms_full_lists=ms_full, queries_per_s=Q / (ms_top * 1e-3)))
         if Q == 195:   # the 1771-vector sweep of hybrid.py:404-426 on the LLeQA test split size
             grid = weight_grid(names)

@@ -335,7 +335,8 @@ class Aggregator:
     # based promotion, the reference's own pinned environment (torch 2.1.2 / pandas 2.1.4 era): EVERY nsf product and sum is float64.
     # Scores differ by ~1e-8 relative; near-tied documents can swap.  Also switched on by FUSION_AMD_NUMPY1_PROMOTION=1.
     NUMPY1_PROMOTION = os.environ.get("FUSION_AMD_NUMPY1_PROMOTION", "0") == "1"
-    # fuse_device(topk=k): from this many queries on, float64 fused rows over full lists are SELECTED (ops.select_topk) instead of sorted
+    # fuse_device(topk=k): from this many queries on, float64 fused PLANES over full lists ('none' sums, np.float64 weights; rrf / bcf only
+    # for rows beyond one workgroup -- shorter ones are fused inside the sort, round 5) are SELECTED (ops.select_topk) instead of sorted
     # and cut; below it the selection's extra launches and its flag read cost more than the sort (bench.py: 0.26 vs 0.14 ms at Q = 195)
     SELECT_MIN_Q = 512
     last_topk_path = None     # "select" | "sort": which of the two the last fuse_device(topk=...) took (tests pin it)
@@ -379,9 +380,10 @@ class Aggregator:
         if method in ("bcf", "rrf"):
             lens = torch.stack([s.lens for s in S]).contiguous()
             # the fusion is the LOAD PHASE of the final sort (ops.sort_rank_fused: no float64 plane between two kernels) wherever one
-            # workgroup holds a row and the full lists are wanted; the top-k selection reads the fused plane, so it keeps the two calls
-            will_select = topk is not None and topk < N and all_full and Q >= cls.SELECT_MIN_Q
-            rank_fused_sort = 0 < N <= ops.sort_max_n(torch.float64) and Q > 0 and not will_select
+            # workgroup holds a row -- also when only the first k entries are wanted: the full fused sort (0.46 ms per 1024 x 27,942)
+            # now costs less than fuse + selection + two small sorts (0.50), so rrf / bcf lists are sorted and cut; longer rows keep
+            # the two calls (and the selection)
+            rank_fused_sort = 0 < N <= ops.sort_max_n(torch.float64) and Q > 0
             fused = None if rank_fused_sort else ops.fuse_rank([s.rank for s in S], lens, method)
         elif method == "nsf":
             if percentile_distributions is None:            # the reference calls .get() on it for every system (hybrid.py:213)

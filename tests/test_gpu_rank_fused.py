@@ -124,7 +124,7 @@ def test_rows_beyond_one_workgroup_are_refused_loudly(ops):
 @pytest.mark.parametrize("method", ["rrf", "bcf"])
 def test_aggregator_takes_the_fused_sort_and_matches_the_two_kernel_path(ops, oracle, full, method):
     """Aggregator.fuse_device: full lists and partial lists both run the one-kernel form (pinned via last_rank_fused_sort); the lists
-    equal the two-call form's; the top-k selection (Q >= SELECT_MIN_Q) keeps the fused plane."""
+    equal the two-call form's; a top-k request is the same sort, cut."""
     from fusion_amd.planes import RankedSystem
     from fusion_amd.retrievers.hybrid import Aggregator
     rng = np.random.default_rng(5)
@@ -146,7 +146,9 @@ def test_aggregator_takes_the_fused_sort_and_matches_the_two_kernel_path(ops, or
     np.testing.assert_array_equal(got.order.cpu().numpy(), o2.cpu().numpy())
     np.testing.assert_array_equal(got.scores.cpu().numpy(), s2.cpu().numpy())
     cut = Aggregator.fuse_device(systems, method, topk=100)
+    assert Aggregator.last_rank_fused_sort is True and Aggregator.last_topk_path == "sort"
     np.testing.assert_array_equal(cut.order.cpu().numpy(), o2.cpu().numpy()[:, :100])
+    np.testing.assert_array_equal(cut.scores.cpu().numpy(), s2.cpu().numpy()[:, :100])
 
 
 def test_full_size_property_sorted_and_permutation(ops):

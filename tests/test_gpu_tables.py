@@ -294,7 +294,10 @@ def test_fuse_device_topk_selection_path_equals_the_head_of_the_full_lists(ops, 
     w = {"a": 0.4, "b": 0.6}
     full = Aggregator.fuse_device(systems, method, norm, w, {})
     head = Aggregator.fuse_device(systems, method, norm, w, {}, topk=k)
-    assert Aggregator.last_topk_path == "select"
+    # round 5: rrf / bcf rows that one workgroup holds are SORTED (rank fusion in the sort's load phase: cheaper than fuse + select + two
+    # small sorts) and cut; the float64 'none' sums still take the selection
+    assert Aggregator.last_topk_path == ("select" if method == "nsf" else "sort")
+    assert Aggregator.last_rank_fused_sort is (method != "nsf")
     assert head.order.shape == (Q, k) and head.scores.dtype == full.scores.dtype == torch.float64
     np.testing.assert_array_equal(head.order.cpu().numpy(), full.order.cpu().numpy()[:, :k])
     np.testing.assert_array_equal(head.scores.cpu().numpy(), full.scores.cpu().numpy()[:, :k])
