@@ -45,6 +45,10 @@ ALLOWED = {
 @pytest.fixture(scope="module")
 def resources():
     res = kernel_resources.load()
+    if not res or "sort" not in res:   # objects from before the Makefile kept the reports (or a partial build): rebuild them once
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "fusion_amd", "csrc"), "-B", "-j4", "-s"])
+        res = kernel_resources.load()
     assert res, "no .res files next to the objects: build with `make -C fusion_amd/csrc` (the Makefile writes them)"
     flat = {}
     for f, ks in res.items():
