@@ -152,9 +152,9 @@ def test_aggregator_takes_the_fused_sort_and_matches_the_two_kernel_path(ops, or
 
 
 def test_full_size_property_sorted_and_permutation(ops):
-    """BASELINE size (Q = 256 of the 1024, N = 27,942, BM25-like + cosine-like rankings): the one-kernel form equals the two-kernel form,
-    every row is a permutation, the fused scores are non-increasing and equal 1/(61 + r_b) + 1/(61 + r_d) recomputed from the order."""
-    Q, N = 256, 27942
+    """BASELINE size (Q = 1024, N = 27,942: the bench step's shape; BM25-like + cosine-like rankings): the one-kernel form equals the
+    two-kernel form, every row is a permutation, the fused scores are non-increasing and equal 1/(61 + r_b) + 1/(61 + r_d) recomputed from the order."""
+    Q, N = 1024, 27942
     g = torch.Generator(device="cuda").manual_seed(3)
     b = torch.clamp(torch.randn((Q, N), generator=g, device="cuda") * 3 - 1, min=0).double()      # ~60 % exact zeros: ties by position
     d = torch.randn((Q, N), generator=g, device="cuda")
