@@ -64,6 +64,10 @@ def parse():
     p.add_argument("--no-encode", action="store_true", help="skip the transformer forward (score+fuse only; not the headline metric)")
     p.add_argument("--token-ids", action="store_true", help="start the step from token ids resident on the device (rounds 1-4) instead of from query strings")
     p.add_argument("--serial-tokenize", action="store_true", help="tokenise every step's batch on the main thread before launching it (no overlap with the device)")
+    p.add_argument("--require-tokenizer", action="store_true",
+                   help="fail instead of falling back to resident token ids when the `tokenizers` wheel (or the tokenizer file) is missing: the fallback "
+                        "changes what the headline measures (config.input / config.tokenizer_fallback say so)")
+    p.add_argument("--tokenizer-threads", type=int, default=None, help="workers of the tokenizer's rayon pool (RAYON_NUM_THREADS; default min(8, half the visible cores))")
     p.add_argument("--encoder-size", default="base", choices=["base", "tiny"])
     p.add_argument("--encode-buckets", type=int, default=8, help="length buckets for the query encoder (1 = pad everything to the batch maximum)")
     p.add_argument("--encode-mode", default="packed", choices=["packed", "fused", "hf"],
@@ -180,12 +184,19 @@ def build_lleqa(args, dev, rank):
         tok = None
         if not args.token_ids:
             try:
-                from fusion_amd.tokenization import SynthFrenchTokenizer
+                from fusion_amd.tokenization import SynthFrenchTokenizer, cap_host_threads
+                # the program's entry point sizes the tokenizer's (process-global) rayon pool, once, before its first use: left at every visible
+                # core it crowds out the thread that launches the GPU work (tokenization.cap_host_threads)
+                st["tokenizer_threads"] = cap_host_threads(args.tokenizer_threads, override=args.tokenizer_threads is not None)
                 tok = SynthFrenchTokenizer()
                 assert tok.vocab_size == enc.backbone.config.vocab_size
-            except Exception as ex:   # (a box without the `tokenizers` wheel: measure the rest rather than nothing -- and say so in `config.input`)
-                log(f"no tokenizer ({type(ex).__name__}: {ex}): the step starts from resident token ids")
+            except Exception as ex:   # (a box without the `tokenizers` wheel: measure the rest rather than nothing -- and say so in `config`)
+                if args.require_tokenizer:
+                    raise
+                log(f"WARNING: no tokenizer ({type(ex).__name__}: {ex}): the step starts from RESIDENT TOKEN IDS -- not the headline's definition "
+                    "(config.tokenizer_fallback = true; --require-tokenizer makes this an error)")
                 tok = None
+                st["tokenizer_fallback"] = f"{type(ex).__name__}: {ex}"[:120]
         if tok is None:         # rounds 1-4: the step starts from token ids already on the device
             ids, mask, qlen = synth_query_tokens(rng, Q, enc.backbone.config.vocab_size, enc.backbone.config.pad_token_id)
         else:                   # the step starts from STRINGS, as model.encode(queries) does (hybrid.py:101-102): synthetic French-like
@@ -1268,6 +1279,8 @@ def main():
                        "encode_in_step": not args.no_encode, "parallelism": f"query-sharded x{world}, corpus replicated",
                        "input": "query strings (tokenised on the host inside the timed step)" if host else "token ids resident on the device",
                        "tokenize_in_step": host is not None, "tokenize_overlapped_with_device": bool(host and host["overlapped"]),
+                       **({"tokenizer_fallback": True, "tokenizer_fallback_reason": st["tokenizer_fallback"]} if st.get("tokenizer_fallback") else {}),
+                       **({"tokenizer_threads": st["tokenizer_threads"]} if host and "tokenizer_threads" in st else {}),
                        **({"tokenize_ms": round(host["tokenize_ms"], 3), "h2d_ids_ms": round(host["h2d_ids_ms"], 4),
                            "ms_per_step_serial_tokenize": round(host.get("ms_per_step_serial_tokenize", float("nan")), 3)} if host else {})},
             "stages_ms": stages, "host": host,

@@ -211,14 +211,16 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     // fp64 key of the element at column `col` (re-derivable at any time from global memory: L2 / Infinity-Cache hits)
     auto key64 = [&](uint2 v) -> uint64_t { return desc_key_f64(__hiloint2double((int)v.y, (int)v.x)); };
     // FUSE: a key costs S divisions to form, and the fp64 form needs every key's words twice (high words for the passes, low words for
-    // the repair).  The low sort words of the load phase are parked in the LOW-HALF slots of this row's sorted-score output -- written by
-    // nobody before the output phase, indexed by the slot the thread itself loaded (it reads back what it wrote) -- instead of being
-    // formed a second time: 4 B out + 4 B in per key (L2 / Infinity Cache) for S divisions.
-    uint32_t* const stash = reinterpret_cast<uint32_t*>(a.order ? a.order + obase : nullptr);   // (the order output: see below)
-    // FUSE: a key costs S divisions to form, and the fp64 form needs every key's words twice.  The low sort words of the load phase are
-    // parked in this row's ORDER output -- written by nobody before the output phase, indexed by the column / slot the thread itself
-    // loaded (it reads back what it wrote; L2 / Infinity Cache) -- instead of being formed a second time.  Placed rows that do not fill
-    // the row (entries of `order` beyond the list belong to the caller) and calls without an order output form them again.
+    // the repair).  Scratch use of the row's two outputs, both written by nobody else before the output phase:
+    //   ORDER output (`stash`)      the LOW sort words of the load phase, indexed by the column / slot the thread itself loaded (it reads
+    //                               back what it wrote; 4 B out + 4 B in per key from L2 / Infinity Cache instead of S divisions), live
+    //                               until the low-word phase has published them through LDS (the barrier behind that loop);
+    //   SORTED-SCORE output (o_kw)  word p < lim = the HIGH half of the sorted key at rank p, parked compactly at the head of the row once the
+    //                               digit passes are done, live until the output phase has read ALL of them back (its s_waitcnt + barrier)
+    //                               and stores every entry as one 8-byte word.
+    // Placed rows that do not fill the row (entries of `order` beyond the list belong to the caller) and calls without an order output
+    // form the low words again instead of parking them.
+    uint32_t* const stash = reinterpret_cast<uint32_t*>(a.order ? a.order + obase : nullptr);
     const bool use_stash = FUSE && !GEN && stash != nullptr && (!irow || m == a.n_total);   // block-uniform
     // FUSE: the fused float64 scores of B columns (col < 0: not an element, its value is never used), in two halves so that callers can
     // put other work between them: fuse_issue = the rank loads of the FIRST round (N1 = 0, 1 or 2 systems from `s` on), fuse_finish =

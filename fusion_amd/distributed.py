@@ -110,6 +110,8 @@ class ShardedDenseIndex:
                     bs, bi = ops.topk_rows(S[:, :lo], k, id_base=self.id_base + c0)
                     stream = ops.TopkStream(bs, bi, seen=lo, cap=self.CAP)
                 stream.feed(S[:, lo:], self.id_base + c0 + lo); mark("shard_topk_stream")
+                if stream.unrepairable:   # a window of scores the stream does not hold overflowed: the rest of the streaming pass would be wasted
+                    break
             elif best_s is None:
                 best_s, best_i = ops.topk_rows(S, k, id_base=self.id_base + c0); mark("shard_topk_exact")
             else:   # exact path: per-chunk top-k, then merge two id-ascending lists (chunks arrive in id order)

@@ -79,6 +79,23 @@ def _stream(t: torch.Tensor):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+_RESERVED_WS: dict = {}
+
+
+def _reserved_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    """A workspace that a kernel RESERVES but practically never touches (the fused sort's plane for rows its fast form flags: rows x ld x 8
+    bytes, 229 MB at 1024 x 27,942), kept per (device, stream) and grown on demand instead of being taken from the allocator on every call
+    (ADVICE r5).  Safe because calls on one stream are ordered and the kernel initialises what it reads (its row flags) itself; another
+    stream gets its own buffer."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _RESERVED_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _RESERVED_WS.pop(key, None)
+        ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+        _RESERVED_WS[key] = ws
+    return ws
+
+
 def _ptr_array(ts):
     A = (C.c_void_p * len(ts))()
     for i, t in enumerate(ts):
@@ -377,7 +394,7 @@ def sort_rank_fused(ranks: list[torch.Tensor], lens: torch.Tensor, method: str, 
         _need(row_len.numel() == rows, f"sort_rank_fused(row_len): expected {rows} entries, got {row_len.numel()}")
     lib = _lib.lib()
     wsb = int(lib.fz_sort_rank_fused_workspace_bytes(rows, n, ld))
-    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    ws = _reserved_workspace(dev, wsb)
     check(lib.fz_sort_rank_fused_desc(_ptr_array(ranks), _ptr(lens), len(ranks), RANK_METHODS[method], _ptr(init_order), _ptr(init_rank),
                                       _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk), _ptr(rank), _ptr(ws), wsb, _stream(ranks[0])),
           "fz_sort_rank_fused_desc")
@@ -842,7 +859,8 @@ class TopkStream:
         self.windows_redone = 0
         self._pieces = []                # what the current window was fed with: ("scores", piece, id_base) | ("gemm", Qn, Dpiece, id_base)
         self._unheld = False             # ... and whether some of it was fed without being held (feed(hold=False))
-        self._ever_unheld = False        # an unheld window has been folded: the flag may carry ITS overflow, which no later redo can repair
+        self.unrepairable = False        # host latch: a window fed WITHOUT hold overflowed -- nothing the stream holds can repair it, the device
+                                         #   flag stays set and the caller redoes the search; later windows are neither read nor redone
         wsb = int(_lib.lib().fz_topk_fold_workspace_bytes(rows, k, cap))
         self._ws, self._wsb = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev), wsb
 
@@ -906,28 +924,33 @@ class TopkStream:
         check(_lib.lib().fz_topk_fold_f32(_ptr(self.best_s), _ptr(self.best_i), self.rows, self.k, _ptr(self.cand_s), _ptr(self.cand_i),
                                           _ptr(self.cand_len), self.cap, 1 if self.unordered else 0, _ptr(ns), _ptr(ni), _ptr(self.tau),
                                           _ptr(self.overflow), _ptr(self._ws), self._wsb, _stream(self.best_s)), "fz_topk_fold_f32")
-        if self.exact_on_overflow and not self._unheld and int(self.overflow.item()) != 0:
-            # a candidate list was cut short (or a tie run was too long to order): this window again, exactly, on top of the list as it
-            # stood before it -- per piece: scores -> fz_topk_rows_f32 -> merge (ties by ascending id, as everywhere)
-            ns, ni = self.best_s, self.best_i
-            for kind, *args in self._pieces:
-                if kind == "gemm":
-                    Qn_, piece, base = args
-                    sc = dot_scores(Qn_, piece)
-                else:
-                    sc, base = args
-                if sc.shape[1] == 0:
-                    continue
-                ps, pi = topk_rows(sc, self.k, id_base=base)
-                ns, ni = topk_merge(torch.stack([ns, ps]), torch.stack([ni, pi]))
-            self.tau.copy_(ns[:, self.k - 1])
-            self.cand_len.zero_()
-            if not self._ever_unheld:        # (else the flag may be an EARLIER, unheld window's: it stays set and the caller redoes the search)
+        # The device flag is read at the fold (one small device -> host read per window) for as long as the search can still come out
+        # exact: once an UNHELD window has overflowed the caller redoes the whole search anyway, so later windows are neither read nor
+        # redone (with one sticky device flag every later held window ran the full exact redo for nothing).  Every earlier
+        # overflow was either repaired (flag cleared below) or latched, so a non-zero flag here is THIS window's.
+        if self.exact_on_overflow and not self.unrepairable and int(self.overflow.item()) != 0:
+            if self._unheld:
+                self.unrepairable = True     # fed without hold: no exact redo for this window; the flag stays set
+            else:
+                # a candidate list was cut short (or a tie run was too long to order): this window again, exactly, on top of the list as
+                # it stood before it -- per piece: scores -> fz_topk_rows_f32 -> merge (ties by ascending id, as everywhere)
+                ns, ni = self.best_s, self.best_i
+                for kind, *args in self._pieces:
+                    if kind == "gemm":
+                        Qn_, piece, base = args
+                        sc = dot_scores(Qn_, piece)
+                    else:
+                        sc, base = args
+                    if sc.shape[1] == 0:
+                        continue
+                    ps, pi = topk_rows(sc, self.k, id_base=base)
+                    ns, ni = topk_merge(torch.stack([ns, ps]), torch.stack([ni, pi]))
+                self.tau.copy_(ns[:, self.k - 1])
+                self.cand_len.zero_()
                 self.overflow.zero_()
-            self.windows_redone += 1
-        self._ever_unheld = self._ever_unheld or self._unheld
+                self.windows_redone += 1
         self._pieces.clear()
-        self._unheld = False                 # (an overflow of that window has left the flag set: it is never cleared again)
+        self._unheld = False
         self.best_s, self.best_i = ns, ni
         self.seen += self.pending
         self.pending = 0

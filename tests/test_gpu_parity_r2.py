@@ -644,6 +644,37 @@ def test_topk_stream_flags_candidate_overflow(ops):
     assert not torch.isnan(rs).any()
 
 
+@pytest.mark.gpu
+def test_topk_stream_overflow_latch(ops):
+    """(a) a HELD window that overflows after a clean unheld one is repaired exactly and the flag is clear again; (b) once an
+    UNHELD window has overflowed the search is the caller's to redo: the flag stays set, later held windows are neither read nor redone."""
+    rows, n, k, head = 3, 60_000, 50, 4096
+    # descending head and middle (nothing beats the thresholds), then an ascending tail that overflows every window
+    flat = torch.arange(rows * n, device="cuda", dtype=torch.float32).reshape(rows, n)
+    S = -flat.clone()
+    S[:, 30_000:] = flat[:, 30_000:]
+    S = ops.as_plane(S.contiguous())
+    bs, bi = ops.topk_rows(S[:, :head], k)
+    # (a) clean unheld window, then held windows that overflow
+    st = ops.TopkStream(bs, bi, seen=head, cap=500)
+    st.feed(S[:, head:30_000], head)
+    st.fold()
+    assert not st.unrepairable and st.windows_redone == 0
+    st.feed(S[:, 30_000:], 30_000, hold=True)
+    rs, ri, flag = st.result()
+    es, ei = ops.topk_rows(S, k)
+    assert st.windows_redone >= 1 and int(flag.item()) == 0 and not st.unrepairable
+    assert torch.equal(rs, es) and torch.equal(ri, ei)
+    # (b) the overflow happens in an unheld window: latched; the held windows behind it cost no redo
+    st = ops.TopkStream(bs, bi, seen=head, cap=500)
+    st.feed(S[:, head:45_000], head)
+    st.fold()
+    assert st.unrepairable
+    st.feed(S[:, 45_000:], 45_000, hold=True)
+    _, _, flag = st.result()
+    assert int(flag.item()) == 1 and st.windows_redone == 0
+
+
 # ---- percentile-rank / NCE: the windowed nearest-entry look-up against the plain first-argmin ------------------------------------------
 def _nearest_first_argmin(tab, x):
     """hybrid.py:272-275 in NumPy: index of the FIRST minimum of |tab - x| computed in float32 (NaN distances: argmin's rule)."""

@@ -225,6 +225,7 @@ def test_placed_sequence_that_does_not_fill_the_row(ops, oracle, N):
 def test_encode_from_strings_with_overlapped_tokenisation_equals_encode_from_ids():
     """DenseEncoder.encode(strings) -- sub-batch i + 1 tokenised (the 32,005-piece synthetic-French BPE) on a host thread
     while sub-batch i runs the padding-free forward -- equals the forward over ids tokenised up front in the caller's thread."""
+    pytest.importorskip("tokenizers", reason="the synthetic-French BPE needs the optional `tokenizers` wheel (requirements.txt)")
     from fusion_amd import encoders
     from fusion_amd.synth_text import FrenchLike
     enc = encoders.random_init("dpr", device="cuda", size="base", seed=0, tokenizer="synth-fr")

@@ -42,13 +42,35 @@ ALLOWED = {
 }
 
 
+def _need_tool(name):
+    import shutil
+    path = shutil.which(name) or (os.path.join("/opt/rocm/lib/llvm/bin", name) if os.path.exists(os.path.join("/opt/rocm/lib/llvm/bin", name)) else None)
+    if path is None:
+        pytest.skip(f"{name} is not on this machine: the resource / disassembly checks need the ROCm toolchain")
+    return path
+
+
 @pytest.fixture(scope="module")
-def resources():
+def resources(tmp_path_factory):
+    """The per-kernel reports of the SHIPPED build (fusion_amd/csrc/*.res).  If they are missing (objects from before the Makefile kept
+    them, or a partial build) the sources are compiled once more into a TEMPORARY directory -- never into the tree: a test session does
+    not rebuild the library it is testing -- and without hipcc the checks are skipped with a message."""
     res = kernel_resources.load()
-    if not res or "sort" not in res:   # objects from before the Makefile kept the reports (or a partial build): rebuild them once
+    if not res or "sort" not in res:
+        import shutil
         import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "fusion_amd", "csrc"), "-B", "-j4", "-s"])
-        res = kernel_resources.load()
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        if not os.path.exists(hipcc):
+            pytest.skip("no .res reports next to the objects and no hipcc to make them: run `make -C fusion_amd/csrc` where ROCm is installed")
+        out = str(tmp_path_factory.mktemp("res"))
+        src = os.path.join(ROOT, "fusion_amd", "csrc")
+        flags = "-O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -Rpass-analysis=kernel-resource-usage".split()
+        for f in sorted(os.listdir(src)):
+            if f.endswith(".hip"):
+                r = subprocess.run([hipcc, *flags, "-c", os.path.join(src, f), "-o", os.path.join(out, f[:-4] + ".o")], capture_output=True, text=True)
+                assert r.returncode == 0, r.stderr[-2000:]
+                open(os.path.join(out, f[:-4] + ".res"), "w").write(r.stderr)
+        res = kernel_resources.load(out)
     assert res, "no .res files next to the objects: build with `make -C fusion_amd/csrc` (the Makefile writes them)"
     flat = {}
     for f, ks in res.items():
@@ -74,9 +96,11 @@ def test_hot_kernel_holds_no_spilled_register(resources, name):
 def test_allow_listed_spills_stay_within_their_measured_bounds(resources, name):
     max_spill, max_scratch, _, _, why = ALLOWED[name]
     r = resources[name]
-    assert 0 < r["vgpr_spill"] <= max_spill and r["scratch"] <= max_scratch, (
-        f"{name}: {r['vgpr_spill']} spilled VGPRs / {r['scratch']} B scratch; allowed {max_spill} / {max_scratch} because: {why}.  "
-        "0 spills now?  Move it to NO_SPILL.")
+    assert r["vgpr_spill"] <= max_spill and r["scratch"] <= max_scratch, (
+        f"{name}: {r['vgpr_spill']} spilled VGPRs / {r['scratch']} B scratch; allowed {max_spill} / {max_scratch} because: {why}")
+    if r["vgpr_spill"] == 0:   # a compiler that stops spilling it is good news, not a failure
+        import warnings
+        warnings.warn(f"{name} no longer spills: move it from ALLOWED to NO_SPILL in tests/test_kernel_resources_cpu.py")
 
 
 def test_the_dot_product_and_encoder_kernels_do_not_spill(resources):
@@ -88,6 +112,9 @@ def test_the_dot_product_and_encoder_kernels_do_not_spill(resources):
 @pytest.mark.parametrize("obj,name", [("sort.o", "sort_rows_kernel<1024, 28, 1, false, 0>"), ("tables.o", "fuse_nsf_bigtab_kernel<false, 1, 1>"),
                                       ("sort.o", "sort_rows_kernel<1024, 28, 2, false, 1>"), ("sort.o", "sort_rows_kernel<1024, 28, 2, false, 2>")])
 def test_where_the_scratch_accesses_sit(obj, name, tmp_path):
+    _need_tool("llvm-objdump"); _need_tool("c++filt")
+    if not os.path.exists(os.path.join(ROOT, "fusion_amd", "csrc", obj)):
+        pytest.skip(f"fusion_amd/csrc/{obj} is not built here (run `make -C fusion_amd/csrc`): nothing shipped to disassemble")
     listing = spill_locator.disassemble(os.path.join(ROOT, "fusion_amd", "csrc", obj), str(tmp_path))
     import subprocess
     bodies = spill_locator.kernels(listing)
@@ -113,6 +140,9 @@ def test_table_swap_waits_for_exactly_the_requests_it_counts():
     the shipped object: walking back from every such wait to the DMA loop, the vector-memory instructions in between are exactly ILV
     `global_load_dwordx4`."""
     import subprocess
+    _need_tool("llvm-objdump")
+    if not os.path.exists(os.path.join(ROOT, "fusion_amd", "csrc", "tables.o")):
+        pytest.skip("fusion_amd/csrc/tables.o is not built here (run `make -C fusion_amd/csrc`)")
     listing = spill_locator.disassemble(os.path.join(ROOT, "fusion_amd", "csrc", "tables.o"))
     bodies = spill_locator.kernels(listing)
     checked = 0

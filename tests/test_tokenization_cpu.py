@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+pytest.importorskip("tokenizers", reason="the synthetic-French BPE needs the optional `tokenizers` wheel (requirements.txt)")
+
 from fusion_amd import encoders
 from fusion_amd.synth_text import FrenchLike
 from fusion_amd.tokenization import SynthFrenchTokenizer, prefetch
