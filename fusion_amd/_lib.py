@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FUSION_AMD_LIB: another build of the same library (the host-sanitized one of `make -C fusion_amd/csrc hostasan`); same ABI check applies
 LIB_PATH = os.environ.get("FUSION_AMD_LIB") or os.path.join(_HERE, "libfusion_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 FZ_OK, FZ_ERR_ARG, FZ_ERR_UNSUPPORTED, FZ_ERR_HIP, FZ_ERR_WORKSPACE = 0, -1, -2, -3, -4
 NORMS = {"min-max": 1, "z-score": 2, "arctan": 3, "percentile-rank": 4, "normal-curve-equivalent": 5}
@@ -89,6 +89,7 @@ _PROTOS = {
     "fz_bm25_slice_offsets": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "fz_bm25_scores_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "fz_bm25_scores_f64_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "fz_tfidf_scores_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
     "fz_tune_max_gold": (_i, []),
     "fz_gold_ranks_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fz_gold_ranks_f64w": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

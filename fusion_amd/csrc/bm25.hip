@@ -19,6 +19,7 @@ struct Bm25Args {
     int N; double* scores; int lds;
     float* scores32; int lds32;   // nullable: the same scores rounded to float32 (torch.tensor(scores, dtype=float32), hybrid.py:255), written
                                   //   from the same LDS accumulators -- the separate plane-sized conversion pass (fz_f64_to_f32) goes away
+    int tfidf;                    // 1: TFIDF.score (bm25.py:108-115): score += tf * idf -- no length norm, no k1 / b (fz_tfidf_scores_f64)
 };
 
 // LDS-resident accumulators AND length norms: one workgroup = (query, slice of BM25_SLICE documents).  The random read-modify-writes of
@@ -39,6 +40,7 @@ __device__ __forceinline__ int64_t lower_bound_doc(const int32_t* __restrict__ p
 
 constexpr int BM25_TERMS = 256;     // query terms whose posting ranges are resolved per batch
 
+template <bool TFIDF>   // TFIDF: score += tf * idf (bm25.py:114) -- its own instantiation, so that the BM25 walk is the code it was
 __global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
     extern __shared__ __attribute__((aligned(16))) double acc[];          // [BM25_SLICE] accumulators | [BM25_SLICE] length norms
     double* nrm = acc + BM25_SLICE;
@@ -50,7 +52,8 @@ __global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
     const int n = d1 - d0;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         acc[j] = 0.0;
-        nrm[j] = a.doc_norm ? a.doc_norm[d0 + j] : a.k1 * (1.0 - a.b + a.b * (double)a.doc_len[d0 + j] / a.avgdl);   // the sub-expression of bm25.py:154, once per document
+        if constexpr (!TFIDF)
+            nrm[j] = a.doc_norm ? a.doc_norm[d0 + j] : a.k1 * (1.0 - a.b + a.b * (double)a.doc_len[d0 + j] / a.avgdl);   // the sub-expression of bm25.py:154, once per document
     }
     const int64_t p0 = a.qoff[q], p1 = a.qoff[q + 1];
     for (int64_t pb = p0; pb < p1; pb += BM25_TERMS) {
@@ -94,9 +97,14 @@ __global__ __launch_bounds__(1024) void bm25_kernel(Bm25Args a) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (doc[u] >= 0) {
-                        const double num = w * (tf[u] * (a.k1 + 1.0));
-                        const double den = tf[u] + nrm[doc[u] - d0];
-                        acc[doc[u] - d0] = acc[doc[u] - d0] + num / den;   // postings of one term hit distinct documents: no race
+                        double term;
+                        if constexpr (TFIDF) term = tf[u] * w;             // bm25.py:114: score += tf * idf
+                        else {
+                            const double num = w * (tf[u] * (a.k1 + 1.0));
+                            const double den = tf[u] + nrm[doc[u] - d0];
+                            term = num / den;
+                        }
+                        acc[doc[u] - d0] = acc[doc[u] - d0] + term;        // postings of one term hit distinct documents: no race
                     }
                 }
             }
@@ -127,6 +135,8 @@ __global__ void bm25_doc_norms_kernel(const int32_t* __restrict__ doc_len, int N
 }  // namespace fz
 
 using namespace fz;
+
+static int bm25_launch(const Bm25Args& a, int Q, void* stream);
 
 extern "C" int fz_bm25_doc_norms_f64(const int32_t* doc_len, int N, double avgdl, double k1, double b, double* out, void* stream) {
     if (N < 0) return FZ_ERR_ARG;
@@ -163,12 +173,32 @@ extern "C" int fz_bm25_scores_f64_f32(const int64_t* toff, const int32_t* pdoc, 
     if (Q < 0 || N < 0 || lds < N || (scores32 && lds32 < N)) return FZ_ERR_ARG;
     if (Q == 0 || N == 0) return FZ_OK;           // empty tensors carry null pointers
     if (!toff || !idf || !doc_len || !qoff || !scores) return FZ_ERR_ARG;
-    Bm25Args a{toff, pdoc, ptf, idf, doc_len, doc_norm, slice_off, avgdl, k1, b, qoff, qterms, N, scores, lds, scores32, lds32};
+    return bm25_launch(Bm25Args{toff, pdoc, ptf, idf, doc_len, doc_norm, slice_off, avgdl, k1, b, qoff, qterms, N, scores, lds, scores32, lds32, 0}, Q, stream);
+}
+
+// TFIDF.score (bm25.py:108-115): score(q, d) = sum over the query's terms, in query order, of tf(t, d) * idf(t) in float64 -- the same
+// posting walk without the length norm (the idf table is the caller's: TFIDF's is log10((N + 1) / (df + 1)), bm25.py:86-88).
+extern "C" int fz_tfidf_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf, const int64_t* slice_off,
+                                   const int64_t* qoff, const int32_t* qterms, int Q, int N, double* scores, int lds, float* scores32, int lds32,
+                                   void* stream) {
+    if (Q < 0 || N < 0 || lds < N || (scores32 && lds32 < N)) return FZ_ERR_ARG;
+    if (Q == 0 || N == 0) return FZ_OK;
+    if (!toff || !idf || !qoff || !scores) return FZ_ERR_ARG;
+    return bm25_launch(Bm25Args{toff, pdoc, ptf, idf, nullptr, nullptr, slice_off, 1.0, 0.0, 0.0, qoff, qterms, N, scores, lds, scores32, lds32, 1}, Q, stream);
+}
+
+static int bm25_launch(const Bm25Args& a, int Q, void* stream) {
+    const int N = a.N;
     constexpr size_t lds_bytes = 2 * (size_t)BM25_SLICE * sizeof(double);
-    static unsigned long long lds_set = 0ull;
-    if (int rc = raise_lds_limit((const void*)bm25_kernel, lds_bytes, lds_set)) return rc;
+    static unsigned long long lds_set[2] = {0ull, 0ull};
     dim3 grid((unsigned)((N + BM25_SLICE - 1) / BM25_SLICE), (unsigned)Q);
-    bm25_kernel<<<grid, 1024, lds_bytes, as_stream(stream)>>>(a);
+    if (a.tfidf) {
+        if (int rc = raise_lds_limit((const void*)bm25_kernel<true>, lds_bytes, lds_set[1])) return rc;
+        bm25_kernel<true><<<grid, 1024, lds_bytes, as_stream(stream)>>>(a);
+    } else {
+        if (int rc = raise_lds_limit((const void*)bm25_kernel<false>, lds_bytes, lds_set[0])) return rc;
+        bm25_kernel<false><<<grid, 1024, lds_bytes, as_stream(stream)>>>(a);
+    }
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

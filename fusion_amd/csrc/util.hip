@@ -27,7 +27,7 @@ extern "C" const char* fz_strerror(int status) {
     }
 }
 extern "C" int fz_last_hip_error(void) { return g_last_hip_error; }
-extern "C" int fz_abi_version(void) { return 18; }
+extern "C" int fz_abi_version(void) { return 19; }
 
 extern "C" int fz_fill_i32(int32_t* p, size_t count, int32_t value, void* stream) {
     if (!p && count) return FZ_ERR_ARG;

@@ -1023,6 +1023,26 @@ def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float
     return (out, out32) if want_f32 else out
 
 
+def tfidf_scores(toff, pdoc, ptf, idf, qoff, qterms, Q: int, N: int, slice_off: torch.Tensor | None = None, want_f32: bool = False):
+    """TF-IDF scores [Q, N] float64 (TFIDF.score, bm25.py:108-115: sum over the query's terms, in query order, of tf * idf); want_f32: also
+    their float32 rounding from the same launch."""
+    dev = idf.device
+    for t, dt, what in ((toff, torch.int64, "toff"), (pdoc, torch.int32, "pdoc"), (ptf, torch.int32, "ptf"), (idf, torch.float64, "idf"),
+                        (qoff, torch.int64, "qoff"), (qterms, torch.int32, "qterms")):
+        _need(_dev(t, dt, f"tfidf_scores({what})").is_contiguous(), f"tfidf_scores({what}) must be contiguous")
+    _need(toff.numel() == idf.numel() + 1 and pdoc.numel() == ptf.numel() and qoff.numel() == Q + 1,
+          "tfidf_scores: toff must hold V + 1 offsets for idf's V terms, pdoc / ptf one entry per posting, qoff Q + 1 offsets")
+    if slice_off is not None:
+        NS = max(1, -(-int(N) // int(_lib.lib().fz_bm25_slice_docs())))
+        _need(_dev(slice_off, torch.int64, "tfidf_scores(slice_off)").is_contiguous() and tuple(slice_off.shape) == (idf.numel(), NS + 1),
+              f"tfidf_scores(slice_off): expected a contiguous [{idf.numel()}, {NS + 1}] table (ops.bm25_slice_offsets)")
+    out = torch.empty((max(Q, 1), max(round_up(N, _PAD), _PAD)), dtype=torch.float64, device=dev)[:Q, :N]
+    out32 = alloc_plane(Q, N, torch.float32, dev) if want_f32 else None
+    check(_lib.lib().fz_tfidf_scores_f64(_ptr(toff), _ptr(pdoc), _ptr(ptf), _ptr(idf), _ptr(slice_off), _ptr(qoff), _ptr(qterms), Q, N,
+                                         _ptr(out), _ld(out), _ptr(out32), _ld(out32) if want_f32 else 0, _stream(idf)), "fz_tfidf_scores_f64")
+    return (out, out32) if want_f32 else out
+
+
 # ---------------------------------------------------------------------------------------
 # A3, sparse form: SPLADE cosine scoring over an inverted index
 # ---------------------------------------------------------------------------------------

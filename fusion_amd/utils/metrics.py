@@ -85,13 +85,16 @@ def gold_rank_tables(n_gold: np.ndarray):
     return table, idcg, names
 
 
-def metrics_from_gold_ranks(ranks: np.ndarray, n_gold: np.ndarray, list_len: np.ndarray) -> list[dict]:
+def metrics_from_gold_ranks(ranks: np.ndarray, n_gold: np.ndarray, list_len: np.ndarray, recall_ks=None, only=None) -> list[dict]:
     """All metrics of run_evaluation (hybrid.py:24-42) from the 0-based ranks of the gold documents.
     ranks [W, Q, G] int64 (np.iinfo(int64).max = never retrieved), n_gold [Q] = len(ground_truths) as the reference
     divides by it, list_len [Q] = length of the fused list.  Same per-query formulas and summation order as
     metrics.py:72-136; means over queries use an exactly rounded sum (statistics.mean differs by <= 1 ulp).
     Everything is laid out [gold, query, weight vector] so that every slice below is contiguous (W = 1771 in the 4-system
-    sweep: this function, not the counting kernel, would otherwise dominate the sweep)."""
+    sweep: this function, not the counting kernel, would otherwise dominate the sweep).
+    recall_ks: the recall cut-offs (default: run_evaluation's); only: the metric names to compute and return (default: all) -- the BM25
+    grid search (bm25.py:223) evaluates recall@{10,100,200,500,1000} and r-precision only."""
+    want = (lambda name: True) if only is None else (lambda name: name in set(only))
     W, Q, G = ranks.shape
     INF = np.iinfo(np.int64).max
     r = np.ascontiguousarray(np.sort(ranks, axis=2).transpose(2, 1, 0))   # [G, Q, W], ascending gold ranks per (q, w)
@@ -101,25 +104,33 @@ def metrics_from_gold_ranks(ranks: np.ndarray, n_gold: np.ndarray, list_len: np.
     top = len(table) - 1
     idcg = idcg[:, None]
     per_query: dict[str, np.ndarray] = {}                                 # each [Q, W]
-    for k in RECALL_KS:
-        per_query[f"recall@{k}"] = (r < k).sum(0) / ng                    # r < k implies retrieved
+    for k in (RECALL_KS if recall_ks is None else recall_ks):
+        if want(f"recall@{k}"):
+            per_query[f"recall@{k}"] = (r < k).sum(0) / ng                # r < k implies retrieved
     for k in MAP_KS:
+        if not want(f"map@{k}"):
+            continue
         ap = np.zeros((Q, W))
         for i in range(G):                                                # i-th gold hit sits at rank r[i]: precision = (i+1)/(rank+1)
             ok = r[i] < k
             ap = ap + np.where(ok, (i + 1) / (np.where(ok, r[i], 0).astype(np.float64) + 1.0), 0.0)
         per_query[f"map@{k}"] = ap / ng
     for k in MRR_KS:
+        if not want(f"mrr@{k}"):
+            continue
         ok = r[0] < k
         per_query[f"mrr@{k}"] = np.where(ok, 1.0 / (np.where(ok, r[0], 0).astype(np.float64) + 1.0), 0.0)
     for k in NDCG_KS:
+        if not want(f"ndcg@{k}"):
+            continue
         head = (r == 0).sum(0).astype(np.float64)                         # relevances[0]
         tail = np.zeros((Q, W))
         for i in range(G):                                                # sum(...) for positions >= 1, in rank order
             ok = (r[i] >= 1) & (r[i] < k)
             tail = tail + np.where(ok, table[np.minimum(r[i], top)], 0.0)
         per_query[f"ndcg@{k}"] = (head + tail) / idcg
-    per_query["r-precision"] = (r < n_gold[None, :, None]).sum(0) / ng
+    if want("r-precision"):
+        per_query["r-precision"] = (r < n_gold[None, :, None]).sum(0) / ng
     # mean over the queries with an exactly rounded sum, all (metric, weight vector) pairs at once: error-free TwoSum
     # accumulation (hi + lo carries the sum to ~106 bits; all terms are >= 0), one rounding at the end -- what
     # math.fsum(row) / Q gives, without 15 * W Python-level calls

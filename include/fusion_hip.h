@@ -330,6 +330,14 @@ int fz_bm25_scores_f64_f32(const int64_t* toff, const int32_t* pdoc, const int32
                            const double* doc_norm, const int64_t* slice_off, double avgdl, double k1, double b, const int64_t* qoff,
                            const int32_t* qterms, int Q, int N, double* scores, int lds, float* scores32, int lds32, void* stream);
 
+/* TFIDF.score (bm25.py:108-115), the base class of the reference's lexical retrievers: scores[q][j] (fp64) = sum over the query's terms,
+ * in query order, of tf(t, d) * idf(t) -- the same posting walk without the length norm.  idf [V] is the caller's table (TFIDF's is
+ * log10((N + 1) / (df + 1)), bm25.py:86-88; AtireBM25 hands that table to fz_bm25_scores_f64 instead, bm25.py:170-172).  slice_off,
+ * scores32: as above, both nullable.  (ABI 19) */
+int fz_tfidf_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf, const int64_t* slice_off,
+                        const int64_t* qoff, const int32_t* qterms, int Q, int N, double* scores, int lds, float* scores32, int lds32,
+                        void* stream);
+
 /* ---- N1: weight-grid sweep of the linear fusion, hybrid.py:404-426 ------------------------ */
 /* Fused ranks of the gold documents for W weight vectors at once, without fusing or sorting:
  * out_ranks[w][q][g] = #{docs that precede gold g in the list Aggregator.fuse(method='nsf') would return with

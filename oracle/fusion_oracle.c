@@ -540,3 +540,22 @@ int fzo_bm25_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t*
     }
     return FZO_OK;
 }
+
+/* TFIDF.score (bm25.py:108-115): score += tf * idf, term by term in query order from 0.0 (tf an int, idf a float: one rounding
+ * per product).  The idf table is the caller's (TFIDF: log10((N + 1) / (df + 1)), bm25.py:86-88). */
+int fzo_tfidf_scores_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf, const int64_t* qoff,
+                         const int32_t* qterms, int Q, int N, double* scores, int lds) {
+    if (!toff || !idf || !qoff || !scores || Q < 0 || N < 0 || lds < N) return FZO_ERR_ARG;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int q = 0; q < Q; ++q) {
+        double* row = scores + (size_t)q * lds;
+        for (int j = 0; j < N; ++j) row[j] = 0.0;
+        for (int64_t p = qoff[q]; p < qoff[q + 1]; ++p) {
+            int32_t t = qterms[p];
+            if (t < 0) continue; /* tf = 0, idf = 0: adds 0 */
+            double w = idf[t];
+            for (int64_t e = toff[t]; e < toff[t + 1]; ++e) row[pdoc[e]] += (double)ptf[e] * w;
+        }
+    }
+    return FZO_OK;
+}

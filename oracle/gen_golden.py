@@ -294,6 +294,72 @@ def gen_bm25(BM25):
         json.dump(out, f)
 
 
+def gen_bm25_family(_unused=None):
+    """The rest of the reference's lexical module (bm25.py): TFIDF (:33-127) and AtireBM25 (:164-173) through search_all, and the three
+    things bm25.py's main() does with BM25 -- driven piece by piece, because main() itself cannot run (it downloads its data, :185-212,
+    and its grid loop dies on its first row: `scores.pop('recall')` raises KeyError with today's Metrics, :235, and DataFrame.append is
+    gone from pandas 2, :236):
+      * the k1 x b grid of :221-233: update_params -> search_all(top_k=1000) -> idx2id -> Metrics(recall_at_k=[10,100,200,500,1000]);
+        the k1 = 0 column is left out: with np.float64 parameters a document lacking a query term scores 0/0 = NaN there (:154) and the
+        reference then sorts NaN keys -- an artefact of timsort's comparison sequence, not a ranking (cf. D16);
+      * the evaluation of :246-252 (k1 = 2.5, b = 0.2, the LLeQA preset of run_bm25.sh:24-25);
+      * the negatives of :254-261."""
+    import itertools
+    import src.retrievers.bm25 as ref
+    from src.utils.metrics import Metrics
+    rng = np.random.default_rng(2024)
+    V, N, Q = 400, 1100, 10
+    vocab = np.array([f"m{i}" for i in range(V)])
+    p = 1.0 / np.arange(1, V + 1) ** 1.1
+    p /= p.sum()
+    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(3, 60)), p=p)) for _ in range(N)]
+    queries = [" ".join(rng.choice(vocab, size=int(rng.integers(2, 9)), p=p)) for _ in range(Q - 3)]
+    queries += ["m0 m0 m5 m5 m5", "horsvocab m7 inconnu", "m399 m398 m1"]
+    ids = [1000 + 3 * i for i in range(N)]                                   # idx2id (bm25.py:214): dataset ids are not positions
+    qids = [70 + q for q in range(Q)]
+    gold = [sorted(int(x) for x in rng.choice(ids, size=int(rng.integers(1, 4)), replace=False)) for _ in range(Q)]
+    # make the gold findable: every gold document gets its query's terms appended
+    for q, gl in enumerate(gold):
+        for g in gl:
+            docs[ids.index(g)] += " " + queries[q]
+    idx2id = dict(enumerate(ids))
+    out = {"docs": docs, "queries": queries, "ids": ids, "qids": qids, "gold": gold}
+
+    def lists(m, top_k):
+        return [[[int(x["corpus_id"]), float(x["score"])] for x in r] for r in m.search_all(queries, top_k=top_k)]
+    t = ref.TFIDF(corpus=docs)
+    out["tfidf"] = {"repr": repr(t), "idf": {w: float(t.idf[w]) for w in sorted(t.idf)}, "results": lists(t, 50), "vocab_sorted_head": t.get_vocab()[:5]}
+    a = ref.AtireBM25(corpus=docs, k1=1.2, b=0.75)
+    out["atire"] = {"repr": repr(a), "k1": 1.2, "b": 0.75, "results": lists(a, 50)}
+    # the grid (bm25.py:221-233)
+    evaluator = Metrics(recall_at_k=[10, 100, 200, 500, 1000])
+    retriever = ref.BM25(corpus=docs, k1=0., b=0.)
+    k1_range = np.arange(0., 8.5, 0.5)
+    b_range = np.arange(0., 1.1, 0.1)
+    rows = []
+    for k1, b in itertools.product(*[k1_range, b_range]):
+        if k1 == 0.0:
+            continue
+        retriever.update_params(k1, b)
+        ranked = retriever.search_all(queries, top_k=1000)
+        ranked = [[idx2id.get(x["corpus_id"]) for x in results] for results in ranked]
+        sc = evaluator.compute_all_metrics(all_ground_truths=gold, all_results=ranked)
+        rows.append({"k1": float(k1), "b": float(b), **{k: float(v) for k, v in sc.items()}})
+    out["grid"] = {"k1_range": [float(x) for x in k1_range], "b_range": [float(x) for x in b_range], "rows": rows}
+    # evaluation + negatives at the LLeQA preset
+    m = ref.BM25(corpus=docs, k1=2.5, b=0.2)
+    ranked = [[idx2id.get(x["corpus_id"]) for x in r] for r in m.search_all(queries, top_k=1000)]
+    ev = Metrics(recall_at_k=[5, 10, 20, 50, 100, 200, 500, 1000], map_at_k=[10, 100], mrr_at_k=[10, 100], ndcg_at_k=[10, 100])
+    out["evaluation"] = {k: float(v) for k, v in ev.compute_all_metrics(all_ground_truths=gold, all_results=ranked).items()}
+    neg = {}
+    for q_id, truths_i, preds_i in zip(qids, gold, ranked):
+        neg[q_id] = [y for y in preds_i if y not in truths_i][:10]
+    out["negatives"] = {str(k): v for k, v in sorted(neg.items())}
+    out["top1000_head"] = [r[:20] for r in ranked]
+    with open(os.path.join(OUT, "bm25_family.json"), "w") as f:
+        json.dump(out, f)
+
+
 def gen_metrics(Metrics):
     rng = np.random.default_rng(7)
     cases = []
@@ -665,11 +731,11 @@ def main():
                          ("similarity", gen_similarity, BaseModel), ("search", gen_search, BaseModel),
                          ("splade_pool", gen_splade_pool, SPLADE), ("tune", gen_tune, Aggregator), ("analysis", gen_analysis, Aggregator),
                          ("unsorted", gen_unsorted, Aggregator), ("fullrow", gen_fullrow, Aggregator), ("pr28k", gen_pr28k, Aggregator),
-                         ("tune10k", gen_tune10k, Aggregator)]:
+                         ("tune10k", gen_tune10k, Aggregator), ("bm25_family", gen_bm25_family, None)]:
         if not only or key in only:
             fn(arg)
     print("wrote", len(names), "fuse fixtures + kat_fuse.json, bm25.json, metrics.json, sim_*.npz, search_*.npz, splade_pool_*.npz, "
-          "tune_*.npz, analysis_*.npz, unsorted_fuse.json, fuse_fullrow_*.npz, pr28k_*.npz, tune10k_*.npz ->", os.path.normpath(OUT))
+          "tune_*.npz, analysis_*.npz, unsorted_fuse.json, fuse_fullrow_*.npz, pr28k_*.npz, tune10k_*.npz, bm25_family.json ->", os.path.normpath(OUT))
 
 
 if __name__ == "__main__":

@@ -396,8 +396,8 @@ class BM25:
                 d = post[self.vocab[w]]
                 d[i] = d.get(i, 0) + 1
         df = np.array([len(p) for p in post], dtype=np.int64)
-        # bm25.py:145-147  log10((N - df + 0.5)/(df + 0.5))
-        self.idf = np.array([math.log10((self.N - int(x) + 0.5) / (int(x) + 0.5)) for x in df], dtype=np.float64)
+        self.df = df
+        self.idf = np.array([self._compute_idf(int(x)) for x in df], dtype=np.float64)
         self.doc_len = np.array([len(t) for t in toks], dtype=np.int32)
         self.avgdl = float(mean(self.doc_len.tolist()))  # bm25.py:138 statistics.mean
         self.toff = np.zeros(V + 1, dtype=np.int64)
@@ -410,6 +410,14 @@ class BM25:
                 self.pdoc[o + k] = dj
                 self.ptf[o + k] = tf
 
+    TFIDF_SCORE = False
+
+    def _compute_idf(self, df: int) -> float:
+        return math.log10((self.N - df + 0.5) / (df + 0.5))          # bm25.py:145-147
+
+    def update_params(self, k1: float, b: float) -> None:              # bm25.py:158-161
+        self.k1, self.b = k1, b
+
     def scores(self, queries: list[str]) -> np.ndarray:
         qt = [[self.vocab.get(w, -1) for w in q.split()] for q in queries]
         qoff = np.zeros(len(qt) + 1, dtype=np.int64)
@@ -417,6 +425,9 @@ class BM25:
         qterms = np.array([t for x in qt for t in x] or [0], dtype=np.int32)
         Q = len(queries)
         out = np.empty((Q, self.N), dtype=np.float64)
+        if self.TFIDF_SCORE:
+            _chk(lib().fzo_tfidf_scores_f64(_p(self.toff), _p(self.pdoc), _p(self.ptf), _p(self.idf), _p(qoff), _p(qterms), Q, self.N, _p(out), self.N), "tfidf")
+            return out
         _chk(lib().fzo_bm25_scores_f64(_p(self.toff), _p(self.pdoc), _p(self.ptf), _p(self.idf), _p(self.doc_len),
                                        C.c_double(self.avgdl), C.c_double(self.k1), C.c_double(self.b), _p(qoff), _p(qterms),
                                        Q, self.N, _p(out), self.N), "bm25")
@@ -428,6 +439,25 @@ class BM25:
         order, sk = sort_rows_desc(sc)
         return [[{"corpus_id": int(order[q, r]), "score": float(sk[q, r])} for r in range(min(top_k, self.N))]
                 for q in range(len(queries))]
+
+
+class TFIDF(BM25):
+    """TFIDF (bm25.py:33-127): score += tf * idf with idf = log10((N + 1) / (df + 1)) (bm25.py:86-88, 108-115).  (In the reference BM25
+    derives from TFIDF; the restatement shares the index building the other way round.)"""
+    TFIDF_SCORE = True
+
+    def __init__(self, corpus: list[str]):
+        super().__init__(corpus, 0.0, 0.0)
+
+    def _compute_idf(self, df: int) -> float:
+        return math.log10((self.N + 1) / (df + 1))
+
+
+class AtireBM25(BM25):
+    """AtireBM25 (bm25.py:164-173): BM25's score with TFIDF's idf."""
+
+    def _compute_idf(self, df: int) -> float:
+        return math.log10((self.N + 1) / (df + 1))
 
 
 # ---------------------------------------------------------------------------------------

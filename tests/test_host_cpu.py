@@ -105,6 +105,11 @@ def test_workspace_planning_is_consistent():
     assert L.fz_topk_allgather(None, None, 1, 10, None, 2, None, None, None, 0, None) == ERR
     assert L.fz_bm25_scores_f64(None, None, None, None, None, None, None, 1.0, 2.5, 0.2, None, None, 1, 1, None, 1, None) == ERR
     assert L.fz_bm25_slice_offsets(None, None, 5, 10, None, None) == ERR and L.fz_bm25_slice_docs() == 7168
+    # ABI 19: TF-IDF scoring (bm25.py:108-115) -- null planes, ld < N, empty problems
+    assert L.fz_tfidf_scores_f64(None, None, None, None, None, None, None, 1, 1, None, 1, None, 0, None) == ERR
+    assert L.fz_tfidf_scores_f64(None, None, None, None, None, None, None, 1, 4, one, 2, None, 0, None) == ERR      # lds < N
+    assert L.fz_tfidf_scores_f64(None, None, None, None, None, None, None, 1, 4, one, 4, one, 2, None) == ERR       # lds32 < N
+    assert L.fz_tfidf_scores_f64(None, None, None, None, None, None, None, 0, 4, None, 4, None, 0, None) == 0       # Q = 0: nothing to do
     assert L.fz_gold_ranks_f32(None, None, None, None, 2, 1, 1, 1, 1, None, None) == ERR
     assert L.fz_tune_metrics_f64(None, None, None, 1, None, None, None, 1, None, 1, 0, 0, 0, 1, 1, None, None) == ERR
     assert L.fz_attn_varlen_f32(None, 1, None, 1, 12, 64, 0.125, None, 1, None) == ERR
