@@ -307,7 +307,7 @@ def step_lleqa(st, ev=None):
         B = ops.bm25_scores(b["toff"], b["pdoc"], b["ptf"], b["idf"], b["doc_len"], b["avgdl"], 2.5, 0.2, b["qoff"], b["qterms"], Q, N,
                             doc_norm=b["doc_norm"], slice_off=b["slice_off"])
         if ev: ev.mark("bm25_score")
-        o_b, _, r_b = ops.sort_rows_desc(B, want_keys=False, want_rank=True)
+        o_b, _, r_b = ops.sort_rows_desc(B, want_keys=False, want_rank=True, lexical=True)   # (what BM25.search_device calls: a lexical ranker's rows)
         if ev: ev.mark("bm25_rank")
         return B, o_b, r_b
 

@@ -49,6 +49,8 @@ _PROTOS = {
     "fz_sort_max_n_f64": (_i, []),
     "fz_sort_workspace_bytes": (_sz, [_i, _i, _i]),
     "fz_sort_bucket_rank_rows": (_i, [_vp, _i]),
+    "fz_sort_zero_compact_rows": (_i, [_vp, _i]),
+    "fz_sort_rows_desc_lexical": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_sort_rows_desc": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_sort_rows_desc_placed": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fz_sort_rank_fused_workspace_bytes": (_sz, [_i, _i, _i]),

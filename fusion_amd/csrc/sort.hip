@@ -58,6 +58,8 @@ struct SortArgs {
     const int32_t* stats_len;    // nullable [rows]: the statistics cover the first stats_len[row] entries of the SORTED list (a ranking
                                  //   truncated to its top-k: PLAID-style short lists, return_topk); fp32 keys only
     int bucket_rank;             // 1 = rows of a 1024-thread workgroup are ordered by the bucket ranking where it applies (set by the launcher)
+    int zero_compact;            // 1 = float64 rows that are mostly exact zeros leave their zeros out of the ordering phases (ZC; set by the launcher)
+    int expect_zeros;            // the caller expects such rows (fz_sort_rows_desc_lexical): the launcher picks the SORT_ROWS_ZC instantiation
     // FUSE (fz_sort_rank_fused_desc): there is no key plane -- the float64 key of column j is the rank fusion of hybrid.py:248-252,301-304,
     // formed on load from the S rank planes exactly as fuse_rank_kernel (fuse.hip) forms it: 0.0 + sum over the systems, in system order, of
     // 1/(60 + r + 1) (rrf) or (n - r + 1)/n (bcf) over the systems that list the document (r >= 0); -inf when none does
@@ -72,6 +74,8 @@ struct SortArgs {
 // rows the bucket ranking ordered | of those, rows whose neighbour check swapped a pair back | rows it gave up on after starting
 // (ties, a crowd at the floor, an overfull bucket, a check it could not settle).  Read by fz_sort_bucket_rank_rows (tests, tools).
 __device__ unsigned long long g_bucket_rank_rows[3];
+// rows whose zeros were compacted away | rows that were looked at and kept whole (too few zeros).  Read by fz_sort_zero_compact_rows.
+__device__ unsigned long long g_zero_compact_rows[2];
 
 // Bucket ranking (see sort_rows_kernel): fine / coarse bucket counts and the words of LDS its tables take in the counter area.
 constexpr int BR_FINE = 16384, BR_COARSE = 1024, BR_WORDS = BR_FINE / 2 + BR_COARSE + 1024;   // + one bit per slot (bucket starts)
@@ -129,8 +133,13 @@ __global__ __launch_bounds__(256) void fuse_flagged_rows_kernel(SortArgs a) {
 // pointers and flags that otherwise stay live from the prologue to the output phase (they were the shipped hot kernels' spills):
 //   SORT_ANY   every feature (chunked long rows, segmented top-k lists, column / id maps, id outputs);
 //   SORT_ROWS  whole rows of one plane: the rankers' sorts and the final order (identity / gathered / placed sequence, statistics);
-//   SORT_FUSE  SORT_ROWS whose float64 keys are formed from rank planes on load (fz_sort_rank_fused_desc), no statistics.
-enum { SORT_ANY = 0, SORT_ROWS = 1, SORT_FUSE = 2 };
+//   SORT_FUSE  SORT_ROWS whose float64 keys are formed from rank planes on load (fz_sort_rank_fused_desc), no statistics;
+//   SORT_ROWS_ZC  SORT_ROWS for float64 rows the caller expects to be mostly exact zeros (a lexical ranker's scores:
+//              fz_sort_rows_desc_lexical): the zeros stay out of the ordering phases (ZC below).  Its own instantiation because the
+//              code that serves it costs a row WITHOUT zeros ~5 % (measured: one bit per key in the load phase, a scalar branch per
+//              four items in every loop of the ordering phases, a handful of block-uniform branches) -- rows nobody expects zeros in
+//              keep the SORT_ROWS kernel as it was.
+enum { SORT_ANY = 0, SORT_ROWS = 1, SORT_FUSE = 2, SORT_ROWS_ZC = 3 };
 template <int T, int E, int KW, bool GEN, int MODE = SORT_ANY>
 __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     constexpr bool FUSE = MODE == SORT_FUSE, LEAN = MODE != SORT_ANY;
@@ -139,6 +148,19 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     static_assert(!(FUSE && GEN), "rows the fused fast form flags are sorted by the plain generic form from a materialised score row");
     constexpr int NW = T / 64;
     constexpr uint32_t SENT = 0xffffffffu;
+    // ZC -- ZERO COMPACTION (round 6; float64 rows of one plane: BM25's ranking sort).  A lexical score row is mostly EXACT ZEROS (documents
+    // that share no term with the query: ~60 % of the LLeQA-shaped bench rows), and a zero needs no sorting: its place in the list is
+    // (keys above zero) + (zeros before it in sequence order).  When at least 3/8 of a row of >= 4,096 keys are +-0.0 the load phase's keys
+    // are compacted -- the non-zero keys move, in sequence order, into a COMPACT striped layout of Ee = ceil(non-zeros / T) items per thread
+    // (rounded up to 4) -- and the digit passes, the run detection, the low-word hand-over and the repair run over Ee items instead of E:
+    // their cost is per item slot, whatever the slot holds.  The output phase puts sorted non-zero slot r at list position r (r < P = keys
+    // above zero) or r + Z, and every zero at P + its index among the zeros; same stable permutation, bit for bit (a zero ties with nothing
+    // but zeros, and those keep their order).  1024 x 27,942 BM25-like rows, 60 % zeros: 0.46 -> 0.2x ms (tools/bench_sort_zeros.py).
+    constexpr bool ZC = KW == 2 && !GEN && MODE == SORT_ROWS_ZC && T == 1024 && E >= 16;
+    [[maybe_unused]] int Ee = E;                  // items per thread in the ordering phases (ZC rows that were compacted; else E)
+    // Loops over the items of the COMPACT layout stop at Ee (a multiple of 4: one scalar branch per four items; ~1 % on a row that kept its
+    // zeros.  Instantiating the ordering phases once per path instead -- compacted / whole -- made hipcc spill 176 registers: measured, not kept).
+#define ITEM_GUARD(i) if constexpr (ZC) { if ((((i) & 3) == 0) && (i) >= Ee) break; }
     constexpr int LG = (KW == 2) ? 7 : 14;         // global loads in flight per thread before the first use (one HBM latency per group)
     constexpr int LGF = FUSE ? 4 : LG;             // ... in the gathered / plain load phase (FUSE: the per-key sums need the registers)
     constexpr int WALK = 16;                        // longest equal-high-word run the fp64 repair re-sorts in place
@@ -166,6 +188,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     m_row = m_row < 0 ? 0 : (m_row > a.n_total ? a.n_total : m_row);
     int m = m_row - c0;
     m = m < 0 ? 0 : (m > a.chunk_len ? a.chunk_len : m);
+    const int m_all = m;          // (ZC: `m` becomes the number of non-zero keys for the ordering phases; the output phase works on the whole list)
     // statistics by-product (block-uniform): over the whole list from the load phase, or -- stats_len -- over the first slen entries
     // of the sorted list from the registers of the output phase
     const bool st_on = !FUSE && a.row_stats && (LEAN || a.chunks == 1);
@@ -297,8 +320,10 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         }
     };
 
-    if (threadIdx.x < 8) misc[8 + threadIdx.x] = (threadIdx.x == 1 || threadIdx.x == 3) ? 0xffffffffu : 0u;  // [8] = or, [9] = and of the sort words; [10] = max, [11] = min, [12] .. [15] = sums (bucket ranking)
+    if (threadIdx.x < 8) misc[8 + threadIdx.x] = (threadIdx.x == 1 || threadIdx.x == 3) ? 0xffffffffu : 0u;  // [8] = or, [9] = and of the sort words; [10] = max, [11] = min, [12] .. [15] = sums (bucket ranking); ZC: [10] = or, [11] = and of the NON-ZERO keys' words, [12] = keys above zero
     uint32_t orw = 0, andw = 0xffffffffu;
+    [[maybe_unused]] uint32_t zm = 0u;                                 // ZC: bit i = this thread's item i holds +-0.0
+    const bool zc_try = ZC && a.zero_compact && !irow && !init_row && m >= 4096 && a.order;   // block-uniform (the order output: where the low words are parked)
     if (irow) {
         // placed sequence: column j sits at sequence position init_rank[j].  Keys and positions are read coalesced by
         // column; the sort word, then the payload, are scattered to exch[position] and read back in striped order -- the
@@ -451,6 +476,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
                     const uint64_t k64 = key64(make_uint2(lo_t[i - i0], hi_t[KW == 2 ? i - i0 : 0]));
                     kw = (uint32_t)(k64 >> (GEN ? 0 : 32));
                     if constexpr (FUSE && !GEN) { if (use_stash && ok) stash[(slot0 + i * 64)] = (uint32_t)k64; }
+                    if constexpr (ZC) zm |= (uint32_t)(ok && ((hi_t[i - i0] << 1) | lo_t[i - i0]) == 0u) << i;   // +-0.0 (all the load phase pays for ZC)
                 }
                 ks[i] = ok ? kw : SENT;
                 orw |= ok ? kw : 0u; andw &= ok ? kw : 0xffffffffu;
@@ -486,12 +512,100 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { orw |= __shfl_xor(orw, o, 64); andw &= __shfl_xor(andw, o, 64); }
     if (lane == 0) { atomicOr(&misc[8], orw); atomicAnd(&misc[9], andw); }
+    if constexpr (ZC) {
+        if (zc_try) {   // (block-uniform) per wave: zeros | non-zero keys << 16 -> misc[16 + w]
+            int nin = (m - slot0 + 63) >> 6;                   // this thread's items inside the row (identity sequence: slot < m)
+            nin = nin < 0 ? 0 : (nin > E ? E : nin);
+            const uint32_t zt = (uint32_t)__popc(zm);
+            uint32_t pk = zt | (((uint32_t)nin - zt) << 16);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) pk += __shfl_xor(pk, o, 64);
+            if (lane == 0) misc[16 + w] = pk;
+        }
+    }
     __syncthreads();
-    const uint32_t diff = misc[8] ^ misc[9];          // bits that vary among the REAL keys: a digit without any is skipped
+    uint32_t diff = misc[8] ^ misc[9];                // bits that vary among the REAL keys: a digit without any is skipped
     // Slots beyond the sequence hold the all-ones sentinel and take part in the wave ballots: a bit may only be left out
     // of the match when it is constant over the sentinels too, i.e. constant ONE.
-    const bool has_sent = irow || init_row || m < T * E;
-    const uint32_t diff_match = has_sent ? ~misc[9] : diff;
+    bool has_sent = irow || init_row || m < T * E;
+    uint32_t diff_match = has_sent ? ~misc[9] : diff;
+    // ZC: the row's zeros leave the ordering phases (see the note at ZC's definition)
+    [[maybe_unused]] int zc_Z = 0, zc_P = 0, zc_zbase = 0, zc_nzbase = 0;   // zeros in the row | keys above zero | zeros / non-zero keys in the waves before this one
+    [[maybe_unused]] bool compacted = false;                    // block-uniform
+    if constexpr (ZC) {
+        if (zc_try) {
+            uint32_t nz_all = 0, z_all = 0, nz_before = 0, z_before = 0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const uint32_t c = misc[16 + ww];
+                z_all += c & 0xffffu; nz_all += c >> 16;
+                if (ww < w) { z_before += c & 0xffffu; nz_before += c >> 16; }
+            }
+            if (nz_all > 0u && z_all * 8u >= (uint32_t)m * 3u) {
+                compacted = true;
+                zc_Z = (int)z_all; zc_zbase = (int)z_before; zc_nzbase = (int)nz_before;
+                Ee = (((int)nz_all + T - 1) / T + 3) & ~3;
+                // The non-zero keys, in sequence order, to COMPACT positions: (non-zero keys of the waves before) + (of this wave's earlier
+                // items) + (of the lanes below).  High sort words through LDS; the LOW sort words -- the ordering phases need them once more,
+                // after the digit passes -- are formed again here, while the row is still warm in L2 (the whole-row form re-reads all of it
+                // from the Infinity Cache / HBM a hundred microseconds later), and parked by compact position in the row's ORDER output,
+                // which nobody writes before the output phase.  The payload of the ordering phases is the compact position itself: the
+                // columns are handed over once, at the end.
+                uint32_t run = nz_before;
+                SLOT_FRESH();
+#pragma unroll
+                for (int i0 = 0; i0 < E; i0 += 7) {
+                    uint32_t lo_t[7], hi_t[7], pos_t[7];
+#pragma unroll
+                    for (int i = i0; i < (i0 + 7 < E ? i0 + 7 : E); ++i) {
+                        const int p = slot0 + i * 64;
+                        const bool mv = p < m && !((zm >> i) & 1u);
+                        const unsigned long long bal = __ballot(mv);
+                        const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                        run += (uint32_t)__popcll(bal);
+                        pos_t[i - i0] = mv ? pos : 0xffffffffu;
+                        const uint2 v = kd[mv ? p : 0];
+                        lo_t[i - i0] = v.x; hi_t[i - i0] = v.y;
+                        if (mv) exch[pos] = ks[i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = i0; i < (i0 + 7 < E ? i0 + 7 : E); ++i)
+                        if (pos_t[i - i0] != 0xffffffffu) stash[pos_t[i - i0]] = (uint32_t)key64(make_uint2(lo_t[i - i0], hi_t[i - i0]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+                slot0 = w * Ee * 64 + lane;                    // from here to the output phase: the compact layout
+                m = (int)nz_all;
+                uint32_t orz = 0u, andz = 0xffffffffu, pth = 0u;   // or / and of the non-zero keys' words; keys above zero (sign bit of the sort word clear: NaN, +x, +denormal)
+                SLOT_FRESH();
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    ITEM_GUARD(i)
+                    const int p = slot0 + i * 64;
+                    const bool in = p < m;
+                    const uint32_t kw = exch[in ? p : 0];
+                    ks[i] = in ? kw : SENT;
+                    meta[i] = in ? (uint32_t)p : 0xffffu;       // payload = compact position
+                    orz |= in ? kw : 0u; andz &= in ? kw : 0xffffffffu; pth += (in && (int)kw >= 0) ? 1u : 0u;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    orz |= __shfl_xor(orz, o, 64); andz &= __shfl_xor(andz, o, 64); pth += __shfl_xor(pth, o, 64);
+                }
+                if (lane == 0) { atomicOr(&misc[10], orz); atomicAnd(&misc[11], andz); atomicAdd(&misc[12], pth); }
+                __syncthreads();
+                zc_P = (int)misc[12];
+                const uint32_t orn = misc[10], andn = misc[11];
+                diff = orn ^ andn;
+                has_sent = m < T * Ee;
+                diff_match = has_sent ? ~andn : diff;
+            }
+            if (threadIdx.x == 0) atomicAdd(&g_zero_compact_rows[compacted ? 0 : 1], 1ull);
+        }
+    }
+    // ZC, compacted row: sorted non-zero slot p stands at list position p (above zero) or p + Z (below zero): where its outputs go
+    [[maybe_unused]] auto fpos = [&](int p) -> int { if constexpr (ZC) return (compacted && p >= zc_P) ? p + zc_Z : p; else return p; };
 
     // One stable LSD pass over the 8-bit digit at `shift` of ks (which travels with the payload).
     // dmask: the digit's bits that vary over the row.
@@ -505,6 +619,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             SLOT_FRESH();
 #pragma unroll
             for (int i = 0; i < E; ++i) {
+                ITEM_GUARD(i)
                 const uint32_t kw = ks[i];
                 const uint32_t d = (kw >> shift) & 0xffu;
                 // wave64 match-any on the digit's VARYING bits (a bit that is constant over the row cannot separate peers;
@@ -559,6 +674,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
+            ITEM_GUARD(i)
             uint32_t kw = ks[i];
             asm volatile("" : "+v"(kw));  // recompute the digit here instead of keeping &my[d] alive per item
             const uint32_t d = (kw >> shift) & 0xffu;
@@ -572,6 +688,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
+            ITEM_GUARD(i)
             ks[i] = exch[(slot0 + i * 64)];
             if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
@@ -579,6 +696,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
+            ITEM_GUARD(i)
             exch[meta[i] >> 16] = meta[i] & 0xffffu;
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
@@ -586,6 +704,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
+            ITEM_GUARD(i)
             meta[i] = exch[(slot0 + i * 64)];
             if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
@@ -595,19 +714,19 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     auto permute_to_meta_hi = [&]() __attribute__((always_inline)) {
         SLOT_FRESH();
 #pragma unroll
-        for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) exch[meta[i] >> 16] = ks[i];
+        for (int i = 0; i < E; ++i) { ITEM_GUARD(i) if ((slot0 + i * 64) < m) exch[meta[i] >> 16] = ks[i]; }
         __syncthreads();
         SLOT_FRESH();
 #pragma unroll
-        for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) ks[i] = exch[(slot0 + i * 64)];
+        for (int i = 0; i < E; ++i) { ITEM_GUARD(i) if ((slot0 + i * 64) < m) ks[i] = exch[(slot0 + i * 64)]; }
         __syncthreads();
         SLOT_FRESH();
 #pragma unroll
-        for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) exch[meta[i] >> 16] = meta[i] & 0xffffu;
+        for (int i = 0; i < E; ++i) { ITEM_GUARD(i) if ((slot0 + i * 64) < m) exch[meta[i] >> 16] = meta[i] & 0xffffu; }
         __syncthreads();
         SLOT_FRESH();
 #pragma unroll
-        for (int i = 0; i < E; ++i) if ((slot0 + i * 64) < m) meta[i] = exch[(slot0 + i * 64)];
+        for (int i = 0; i < E; ++i) { ITEM_GUARD(i) if ((slot0 + i * 64) < m) meta[i] = exch[(slot0 + i * 64)]; }
         __syncthreads();
     };
     // fp64: (re)load one key word of every slot's element from global memory, by payload (a gather; rare paths only)
@@ -979,16 +1098,17 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         uint32_t* runbits = cnt;   // [T*E/32]: bit (p & 31) of word p >> 5 = "slot p has the same high word as slot p-1"
         SLOT_FRESH();
 #pragma unroll
-        for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = ks[i];
+        for (int i = 0; i < E; ++i) { ITEM_GUARD(i) exch[(slot0 + i * 64)] = ks[i]; }
         __syncthreads();
         SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
+            ITEM_GUARD(i)
             const int p = (slot0 + i * 64);
             const bool ps = p > 0 && p < m && exch[p - 1] == ks[i];
             contm |= (uint32_t)ps << i;
             const unsigned long long bal = __ballot(ps);
-            if (lane == 0) { runbits[(w * E + i) * 2] = (uint32_t)bal; runbits[(w * E + i) * 2 + 1] = (uint32_t)(bal >> 32); }
+            if (lane == 0) { runbits[(w * Ee + i) * 2] = (uint32_t)bal; runbits[(w * Ee + i) * 2 + 1] = (uint32_t)(bal >> 32); }
             // the sorted key's high half is final now (the repair only moves keys inside runs of EQUAL high words)
             const uint32_t asc = ~ks[i];
             const bool nan = ks[i] == 0u;           // every NaN maps to the all-zero key; no other key has a zero high word
@@ -997,13 +1117,40 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             // the sorted score's HIGH half is final here, its low half only after the repair: parked COMPACTLY at the head of the row's
             // score output (word p; whole lines) and stored together with the low half as one 8-byte store in the output phase -- two
             // strided 4-byte passes over the row wrote every line of it twice (2 x 229 MB per 1024 x 27,942 batch, rocprofv3 WRITE_SIZE)
-            if (o_kw && p < lim) o_kw[p] = nan ? 0x7ff80000u : (sgn ? (asc & 0x7fffffffu) : ~asc);
+            bool parked = false;
+            if constexpr (ZC) {
+                if (compacted) {   // (block-uniform: a scalar branch, nothing for a row that kept its zeros)
+                    parked = true;
+                    const int f = p >= zc_P ? p + zc_Z : p;
+                    if (o_kw && p < m && f < lim) o_kw[f] = nan ? 0x7ff80000u : (sgn ? (asc & 0x7fffffffu) : ~asc);
+                }
+            }
+            if (!parked) { if (o_kw && p < lim) o_kw[p] = nan ? 0x7ff80000u : (sgn ? (asc & 0x7fffffffu) : ~asc); }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         // ---- low words: re-derived by the thread that loaded the element, published under its payload ----
         constexpr int LGG = 4;   // (7 in flight measured the same)
-        if (use_stash) {         // FUSE: the low sort words parked by the load phase, by the slot this thread loaded
+        bool zc_low = false;     // block-uniform
+        if constexpr (ZC) {
+            if (compacted) {     // the low words the compaction parked, by compact position: each thread its own slots (coalesced), published under them
+                zc_low = true;
+                SLOT_FRESH();
+#pragma unroll
+                for (int i0 = 0; i0 < E; i0 += 4) {
+                    if (i0 >= Ee) break;
+                    uint32_t lw[4];
+#pragma unroll
+                    for (int i = i0; i < (i0 + 4 < E ? i0 + 4 : E); ++i) { const int p = slot0 + i * 64; lw[i - i0] = stash[p < m ? p : 0]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = i0; i < (i0 + 4 < E ? i0 + 4 : E); ++i) { const int p = slot0 + i * 64; if (p < m) exch[p] = lw[i - i0]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (zc_low) {
+        } else if (use_stash) {         // FUSE: the low sort words parked by the load phase, by the slot this thread loaded
             SLOT_FRESH();
 #pragma unroll
             for (int i0 = 0; i0 < E; i0 += 7) {
@@ -1038,7 +1185,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
                 int pay, col;   // payload this slot was loaded with, and its column in the row
                 if (irow) { pay = p < a.n_total ? p : -1; col = pay; }
                 else if (init_row) { col = p < m ? init_row[c0 + p] : -1; col = (unsigned)col < (unsigned)a.n_total ? col : -1; pay = col; }
-                else { pay = p < m ? p : -1; col = pay < 0 ? -1 : c0 + pay; }
+                else { pay = p < m_all ? p : -1; col = pay < 0 ? -1 : c0 + pay; }
                 pay_t[i - i0] = pay;
                 if constexpr (FUSE) col_t[i - i0] = col;
                 else { const uint2 v = kd[elem(col < 0 ? c0 : col)]; lo_t[i - i0] = v.x; hi_t[i - i0] = v.y; }
@@ -1063,6 +1210,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
+            ITEM_GUARD(i)
             const uint32_t py = meta[i] & 0xffffu;
             ks[i] = py != 0xffffu ? exch[py] : SENT;     // from here on ks = the LOW key word
             if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
@@ -1086,9 +1234,10 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         uint32_t* biglist = cnt + 2 * NWORDS;
         int8_t* delta = reinterpret_cast<int8_t*>(cnt + NW * 256);   // [T*E] bytes
         const int t = threadIdx.x;
+        const int nwords = T * Ee / 32;                        // runbits words the run detection wrote (ZC: the compact layout's)
         SLOT_FRESH();
 #pragma unroll
-        for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = ks[i];
+        for (int i = 0; i < E; ++i) { ITEM_GUARD(i) exch[(slot0 + i * 64)] = ks[i]; }
         {
             uint32_t* d32 = reinterpret_cast<uint32_t*>(delta);
 #pragma unroll
@@ -1104,6 +1253,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
+            ITEM_GUARD(i)
             const int p = (slot0 + i * 64);
             const bool cont = (contm >> i) & 1u;
             if (__ballot(cont) == 0ull) continue;              // wave-uniform: nobody in this item continues a run
@@ -1128,8 +1278,8 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
                     const int e0 = h + 1;
                     int wd = e0 >> 5;
                     uint32_t z = ~runbits[wd] & ~((1u << (e0 & 31)) - 1u);
-                    while (z == 0u && wd + 1 < NWORDS) { ++wd; z = ~runbits[wd]; }
-                    const int L = (z ? wd * 32 + __builtin_ctz(z) : NWORDS * 32) - h;
+                    while (z == 0u && wd + 1 < nwords) { ++wd; z = ~runbits[wd]; }
+                    const int L = (z ? wd * 32 + __builtin_ctz(z) : nwords * 32) - h;
                     if (L == 2) { delta[h] = 1; delta[h + 1] = -1; }             // a dirty pair: swap
                     else if (L <= WALK + 1) {                                     // stable counting sort by one thread
                         for (int x = 0; x < L; ++x) {
@@ -1175,6 +1325,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
             SLOT_FRESH();
 #pragma unroll
             for (int i = 0; i < E; ++i) {
+                ITEM_GUARD(i)
                 const int p = (slot0 + i * 64);
                 const int d = p < m ? (int)delta[p] : 0x7f;
                 const uint32_t np = d == 0x7f ? (uint32_t)p : (d == 0x7e ? exch[p] : (uint32_t)(p + d));
@@ -1186,6 +1337,34 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         }
     }
 
+    if constexpr (ZC) {
+        if (compacted) {
+            // the ordering phases carried compact positions: the columns behind them, once.  The threads that loaded the row name their
+            // non-zero items' columns by compact position (the compaction's own count, again), the sorted slots pick theirs up.
+            uint32_t run = (uint32_t)zc_nzbase;
+            const int s_full = w * E * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int col = s_full + i * 64;
+                const bool mv = col < m_all && !((zm >> i) & 1u);
+                const unsigned long long bal = __ballot(mv);
+                const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                run += (uint32_t)__popcll(bal);
+                if (mv) exch[pos] = (uint32_t)col;
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            SLOT_FRESH();
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                ITEM_GUARD(i)
+                const uint32_t py = meta[i] & 0xffffu;
+                meta[i] = py != 0xffffu ? exch[py] : 0xffffu;
+            }
+            __syncthreads();
+        }
+    }
+
     // ---- statistics by-product (block-uniform).  min / max of a list sorted by score are its two ends (a NaN sorts first and makes both
     // NaN, as torch.min / torch.max do): the columns of entries 0 and slen - 1 go through LDS, thread 0 reads their values back (L2 hits).
     // A ranking cut to its first slen entries also takes its mean / unbiased std here: the sorted words go to LDS by rank and are summed by
@@ -1194,10 +1373,31 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
+            ITEM_GUARD(i)
             const int p = (slot0 + i * 64);
             const uint32_t col = (meta[i] & 0xffffu) + ((!init_row && !irow) ? (uint32_t)c0 : 0u);
-            if (p == 0) misc[17] = col;
-            if (p == slen - 1) misc[18] = col;
+            if constexpr (ZC) {
+                if (p < m && fpos(p) == 0) misc[17] = col;
+                if (p < m && fpos(p) == slen - 1) misc[18] = col;
+            } else {
+                if (p == 0) misc[17] = col;
+                if (p == slen - 1) misc[18] = col;
+            }
+        }
+        if constexpr (ZC) {   // a list end that is one of the compacted zeros: the thread that loaded that zero names its column (+0.0 or -0.0: the
+            if (compacted && (zc_P == 0 || (slen - 1 >= zc_P && slen - 1 < zc_P + zc_Z))) {   // value the whole-row form would read there)
+                int zrun = zc_P + zc_zbase;
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const bool zb = (zm >> i) & 1u;
+                    const unsigned long long bal = __ballot(zb);
+                    const int f = zrun + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    zrun += (int)__popcll(bal);
+                    const uint32_t col = (uint32_t)(w * E * 64 + i * 64 + lane);
+                    if (zb && f == 0) misc[17] = col;
+                    if (zb && f == slen - 1) misc[18] = col;
+                }
+            }
         }
         double x0 = 0.0;
         const bool pre = KW == 1 && st_prefix;
@@ -1248,19 +1448,27 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
     // rank = inverse permutation.  Scattering it straight to HBM costs as much as the four radix passes
     // (27,942 random 4-byte writes per row); it is inverted in LDS instead and stored coalesced.
     const bool rank_via_lds = o_rank && !cmap && (LEAN || a.chunks == 1);   // block-uniform
-    const bool full_row = (m == a.n_total) && !init_row && !irow;   // a gathered/placed sequence may skip columns
+    const bool full_row = (m_all == a.n_total) && !init_row && !irow;   // a gathered/placed sequence may skip columns
+    if constexpr (ZC) slot0 = w * E * 64 + lane;       // (the pre-fill covers the row's COLUMNS: the full layout)
     if (rank_via_lds && !full_row) {
         SLOT_FRESH();
 #pragma unroll
         for (int i = 0; i < E; ++i) exch[(slot0 + i * 64)] = 0xffffffffu;   // columns outside the sequence
         __syncthreads();
     }
+    if constexpr (ZC) slot0 = w * Ee * 64 + lane;      // (the sorted entries: the layout of the ordering phases)
     [[maybe_unused]] uint32_t hiw[(KW == 2 && !GEN) ? E : 1];
     if constexpr (KW == 2 && !GEN) {
         if (o_kw) {   // (block-uniform) the parked high halves back -- ALL of them, then a barrier: the 8-byte stores below land on the words they were parked in
             SLOT_FRESH();
 #pragma unroll
-            for (int i = 0; i < E; ++i) { const int p = (slot0 + i * 64); hiw[i] = o_kw[p < lim ? p : 0]; }
+            for (int i = 0; i < E; ++i) {
+                ITEM_GUARD(i)
+                const int p = (slot0 + i * 64);
+                int f = p < lim ? p : 0;
+                if constexpr (ZC) { if (compacted) { const int g = p >= zc_P ? p + zc_Z : p; f = (p < m && g < lim) ? g : 0; } }   // (block-uniform branch)
+                hiw[i] = o_kw[f];
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -1268,7 +1476,9 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         SLOT_FRESH();
 #pragma unroll
     for (int i = 0; i < E; ++i) {
-        const int p = (slot0 + i * 64);
+        ITEM_GUARD(i)
+        int p = (slot0 + i * 64);                              // the sorted slot = the list position ...
+        if constexpr (ZC) { if (compacted) p = p >= m ? lim : (p >= zc_P ? p + zc_Z : p); }   // ... (compacted row, block-uniform branch: the zeros stand in between)
         if (p < lim) {
             int col = (int)(meta[i] & 0xffffu);
             if (!init_row && !irow) col += c0;
@@ -1286,6 +1496,29 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
         }
         if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (ZC) {
+        slot0 = w * E * 64 + lane;                             // back to the columns
+        if (compacted) {
+            // the zeros: list position = (keys above zero) + (zeros before this one in sequence order); value +0.0 (desc_key maps -0.0 there too)
+            int zrun = zc_P + zc_zbase;
+            SLOT_FRESH();
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const bool zb = (zm >> i) & 1u;
+                const unsigned long long bal = __ballot(zb);
+                const int p = zrun + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                zrun += (int)__popcll(bal);
+                if (zb && p < lim) {
+                    const int col = slot0 + i * 64;            // (identity sequence, whole rows: the column is the slot)
+                    if (o_order) o_order[p] = col;
+                    if (o_kw) reinterpret_cast<uint2*>(o_kw)[p] = make_uint2(0u, 0u);
+                    if (rank_via_lds) exch[col] = (uint32_t)p;
+                    else if (o_rank) o_rank[col] = p;
+                }
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
     if (rank_via_lds) {
         __syncthreads();
         SLOT_FRESH();
@@ -1301,6 +1534,7 @@ __global__ __launch_bounds__(T) void sort_rows_kernel(SortArgs a) {
 }
 
 #undef SLOT_FRESH
+#undef ITEM_GUARD
 
 // pad the tail of top-k outputs with (-inf, -1)
 __global__ void topk_pad_kernel(float* out_scores, int64_t* out_ids, int rows, int k, int have) {
@@ -1579,7 +1813,7 @@ static int launch_cfg(const SortArgs& a, int prows, hipStream_t st) {
     constexpr size_t lds = SortLds<T, E, KW>::bytes;
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
     static unsigned long long lds_set = 0ull, lds_set_gen = 0ull;   // per (T,E,KW,FUSE) instantiation
-    constexpr int GEN_MODE = MODE == SORT_FUSE ? (T == 1024 ? SORT_ROWS : SORT_ANY) : MODE;   // flagged rows of the fused form: the plain generic kernel
+    constexpr int GEN_MODE = (MODE == SORT_FUSE || MODE == SORT_ROWS_ZC) ? (T == 1024 ? SORT_ROWS : SORT_ANY) : MODE;   // flagged rows of the fused / zero-compacting form: the plain generic kernel
     if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, KW, false, MODE>, lds, lds_set)) return rc;
     if constexpr (KW == 2)
         if (int rc = raise_lds_limit((const void*)sort_rows_kernel<T, E, 2, true, GEN_MODE>, lds, lds_set_gen)) return rc;
@@ -1588,6 +1822,7 @@ static int launch_cfg(const SortArgs& a, int prows, hipStream_t st) {
     {   // FZ_SORT_BUCKET_RANK=0: digit passes only (A/B runs, tests of the two forms against each other)
         const char* e = getenv("FZ_SORT_BUCKET_RANK");
         b.bucket_rank = (e && e[0] == '0') ? 0 : 1;
+        b.zero_compact = 1;   // (FZ_SORT_ZERO_COMPACT=0 keeps the launcher from picking the SORT_ROWS_ZC instantiation at all: launch_sort)
     }
     sort_rows_kernel<T, E, KW, false, MODE><<<prows, T, lds, st>>>(b);
     FZ_LAUNCH_CHECK();
@@ -1621,6 +1856,12 @@ static int launch_sort(const SortArgs& a, int kw, int prows, int n_chunk, hipStr
         // float64 keys: the lean form holds no spilled register (120 VGPRs; SORT_ANY: 9 spilled) and measures 2.5 % (plain rows) to
         // 7 % (placed rows) faster.  float32 keys stay on SORT_ANY unless FZ_SORT_LEAN=1: hipcc schedules their lean form into MORE
         // spills (122, sixteen reloads inside the pass loop) and it measures 15 % slower (profiles/r05_sort_modes_ab.json)
+        const char* zenv = getenv("FZ_SORT_ZERO_COMPACT");   // =0: the plain instantiation for everybody (A/B runs, tests of the two forms; read per launch)
+        const bool zc_env = !(zenv && zenv[0] == '0');
+        if (kw == 2 && a.expect_zeros && zc_env && a.order && !a.init_order && !a.init_rank) {   // a lexical ranker's rows: the zero-compacting instantiation
+            if (c.E == 16) return launch_cfg<1024, 16, 2, SORT_ROWS_ZC>(a, prows, st);
+            if (c.E == 28) return launch_cfg<1024, 28, 2, SORT_ROWS_ZC>(a, prows, st);
+        }
         if (kw == 2 && c.E == 16) return launch_cfg<1024, 16, 2, SORT_ROWS>(a, prows, st);
         if (kw == 2 && c.E == 28) return launch_cfg<1024, 28, 2, SORT_ROWS>(a, prows, st);
         if (kw == 1 && lean_env == 1 && c.E == 28) return launch_cfg<1024, 28, 1, SORT_ROWS>(a, prows, st);
@@ -1794,6 +2035,19 @@ extern "C" int fz_sort_bucket_rank_rows(uint64_t* counts3, int reset) {
     return FZ_OK;
 }
 
+extern "C" int fz_sort_zero_compact_rows(uint64_t* counts2, int reset) {
+    if (counts2) {
+        unsigned long long h[2];
+        FZ_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_zero_compact_rows), sizeof h));
+        counts2[0] = (uint64_t)h[0]; counts2[1] = (uint64_t)h[1];
+    }
+    if (reset) {
+        const unsigned long long z[2] = {0ull, 0ull};
+        FZ_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_zero_compact_rows), z, sizeof z));
+    }
+    return FZ_OK;
+}
+
 extern "C" int fz_sort_max_n(void) { return 35840; }   // single-workgroup rows (the fast path), fp32 keys; fp64 keys: 28672.  Longer rows: chunk-sort + merge
 extern "C" int fz_sort_max_n_f64(void) { return 28672; }
 
@@ -1874,6 +2128,28 @@ extern "C" int fz_sort_rows_desc(const void* keys, int key_bits, const int32_t* 
     a.out_row_stride = ld; a.out_chunk_stride = 0; a.out_limit = n;
     if (key_bits == 64) { if (!workspace || workspace_bytes < fz_sort_workspace_bytes(64, rows, n)) return FZ_ERR_WORKSPACE; a.row_flags = (int32_t*)workspace; }
     return launch_sort(a, key_bits / 32, rows, n, as_stream(stream));
+}
+
+// A lexical ranker's rows (BM25 / TF-IDF scores, bm25.py:100-106: every document that shares no term with the query scores exactly 0.0): the
+// same stable descending sort of float64 rows in the identity sequence, through the instantiation that leaves a row's zeros out of the
+// ordering phases when they are at least 3/8 of its >= 4,096 keys (ZC in sort_rows_kernel).  Same outputs, bit for bit, as fz_sort_rows_desc.
+extern "C" int fz_sort_rows_desc_lexical(const double* keys, const int32_t* row_len, int rows, int n, int ld, int32_t* order, double* sorted_keys,
+                                         int32_t* rank, float* row_stats, void* workspace, size_t workspace_bytes, void* stream) {
+    if (rows < 0 || n < 0 || ld < n) return FZ_ERR_ARG;
+    if (rows == 0 || n == 0) return FZ_OK;
+    if (!keys) return FZ_ERR_ARG;
+    if (n > 28672 || n <= 8192)   // rows of other workgroup sizes: nothing to gain, the general entry point
+        return fz_sort_rows_desc(keys, 64, nullptr, row_len, rows, n, ld, order, sorted_keys, rank, row_stats, nullptr, workspace, workspace_bytes, stream);
+    SortArgs a{};
+    a.keys = keys; a.row_len = row_len;
+    a.n_total = n; a.key_row_stride = ld; a.seg_len = n; a.seg_stride = 0;
+    a.chunks = 1; a.chunk_len = n;
+    a.order = order; a.sorted_keys = sorted_keys; a.rank = rank; a.row_stats = row_stats; a.stats_rows = rows;
+    a.out_row_stride = ld; a.out_chunk_stride = 0; a.out_limit = n;
+    a.expect_zeros = 1;
+    if (!workspace || workspace_bytes < fz_sort_workspace_bytes(64, rows, n)) return FZ_ERR_WORKSPACE;
+    a.row_flags = (int32_t*)workspace;
+    return launch_sort(a, 2, rows, n, as_stream(stream));
 }
 
 extern "C" int fz_sort_rows_desc_placed(const void* keys, int key_bits, const int32_t* init_rank, const int32_t* row_len, int rows,

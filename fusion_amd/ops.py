@@ -215,7 +215,8 @@ def sort_max_n(dtype=torch.float32) -> int:
 
 def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, row_len: torch.Tensor | None = None,
                    want_order=True, want_keys=True, want_rank=False, init_rank: torch.Tensor | None = None,
-                   stats_out: torch.Tensor | None = None, stats_len: torch.Tensor | None = None, covers_all: bool = False):
+                   stats_out: torch.Tensor | None = None, stats_len: torch.Tensor | None = None, covers_all: bool = False,
+                   lexical: bool = False):
     """Stable descending row sort (Python sorted(reverse=True): bm25.py:104, hybrid.py:306).
     Incoming sequence: identity (default), `init_order` (column at each sequence position) or `init_rank`
     (sequence position of each column: a rank plane; read coalesced, the fast form).
@@ -225,7 +226,9 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
     by-product of the sort (identity / init_order sequences, rows that fit one workgroup); stats_len [rows] int32 restricts the
     statistics to the first stats_len[row] entries of the sorted list (a ranking cut to its top-k; fp32 keys only).
     covers_all: the caller vouches that the incoming sequence holds every column of every row (init_rank is a full ranking's rank
-    plane, no row_len): the outputs are then written in full and need no -1 / -inf pre-fill (two plane-sized fill launches)."""
+    plane, no row_len): the outputs are then written in full and need no -1 / -inf pre-fill (two plane-sized fill launches).
+    lexical: the rows are a lexical ranker's float64 scores (BM25 / TF-IDF: mostly exact zeros) in the identity sequence -> the
+    zero-compacting instantiation (fz_sort_rows_desc_lexical); same outputs, bit for bit."""
     _dev(keys, None, "sort_rows_desc(keys)")
     if keys.dtype not in (torch.float32, torch.float64):
         raise TypeError("keys must be float32 or float64")
@@ -278,6 +281,10 @@ def sort_rows_desc(keys: torch.Tensor, init_order: torch.Tensor | None = None, r
             _need(stats_out is not None, "sort_rows_desc(stats_len) needs stats_out")
             _dev(stats_len, torch.int32, "sort_rows_desc(stats_len)")
             _need(stats_len.numel() == rows and stats_len.is_contiguous(), f"sort_rows_desc(stats_len): need {rows} contiguous lengths")
+        if lexical and bits == 64 and init_order is None and stats_len is None and order is not None:
+            check(lib.fz_sort_rows_desc_lexical(_ptr(keys), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk), _ptr(rank), _ptr(stats_out),
+                                                _ptr(ws), wsb, _stream(keys)), "fz_sort_rows_desc_lexical")
+            return order, sk, rank
         check(lib.fz_sort_rows_desc(_ptr(keys), bits, _ptr(init_order), _ptr(row_len), rows, n, ld, _ptr(order), _ptr(sk),
                                     _ptr(rank), _ptr(stats_out), _ptr(stats_len), _ptr(ws), wsb, _stream(keys)), "fz_sort_rows_desc")
     return order, sk, rank
@@ -290,6 +297,15 @@ def sort_bucket_rank_rows(reset: bool = False) -> tuple[int, int, int]:
     c = (ctypes.c_uint64 * 3)()
     check(_lib.lib().fz_sort_bucket_rank_rows(ctypes.cast(c, ctypes.c_void_p), 1 if reset else 0), "fz_sort_bucket_rank_rows")
     return int(c[0]), int(c[1]), int(c[2])
+
+
+def sort_zero_compact_rows(reset: bool = False) -> tuple[int, int]:
+    """(float64 rows whose exact zeros were left out of the ordering phases, eligible rows that had too few zeros) on the current device since
+    the last reset (fz_sort_zero_compact_rows; synchronises the device: tests and tools)."""
+    import ctypes
+    c = (ctypes.c_uint64 * 2)()
+    check(_lib.lib().fz_sort_zero_compact_rows(ctypes.cast(c, ctypes.c_void_p), 1 if reset else 0), "fz_sort_zero_compact_rows")
+    return int(c[0]), int(c[1])
 
 
 def select_topk(fused: torch.Tensor, pos: torch.Tensor | None, k: int, cap: int | None = None):

@@ -107,7 +107,8 @@ class TFIDF:
         stats4 = None   # mean | std | min | max of every list's float32 scores: by-products of the ranking sort (rows that fit one workgroup)
         if N <= ops.sort_max_n(torch.float64) and Q > 0:
             stats4 = torch.empty((4, Q), dtype=torch.float32, device=self.device)
-        order, _, rank = ops.sort_rows_desc(sc64, want_keys=False, want_rank=True, stats_out=stats4)   # ranks from the float64 scores, ties -> ascending index
+        # ranks from the float64 scores, ties -> ascending index; lexical: most of a row is exact zeros, which the sort leaves out of its passes
+        order, _, rank = ops.sort_rows_desc(sc64, want_keys=False, want_rank=True, stats_out=stats4, lexical=True)
         lens = torch.full((Q,), N, dtype=torch.int32, device=self.device)
         # float32 plane for the normalisations (torch.tensor(scores, dtype=float32), hybrid.py:255), written by the scoring kernel from
         # the accumulators it holds (no conversion pass); the float64 scores stay for the 'none' passthrough, which keeps BM25's Python
@@ -214,7 +215,7 @@ class BM25(TFIDF):
         got = torch.empty((len(combos), Q, G), dtype=torch.int32, device=self.device)
         for w, (k1, b) in enumerate(combos):
             self.update_params(k1, b)
-            _, _, rank = ops.sort_rows_desc(self.scores(queries), want_keys=False, want_rank=True)
+            _, _, rank = ops.sort_rows_desc(self.scores(queries), want_keys=False, want_rank=True, lexical=True)
             got[w] = torch.gather(rank, 1, gp_dev)
         self.update_params(*keep)
         ranks = got.cpu().numpy().astype(np.int64)

@@ -111,6 +111,19 @@ size_t fz_sort_workspace_bytes(int key_bits, int rows, int n);
  * counts3[1] = of those, rows that needed a swapped pair put back, counts3[2] = rows that started on it and were handed to the digit
  * passes; reset != 0 clears the counters.  Synchronises the device (tests and tools only). */
 int fz_sort_bucket_rank_rows(uint64_t* counts3, int reset);
+/* Round 6 (ABI 19): the ranking sort of a LEXICAL system (bm25.py:100-106: BM25 / TF-IDF score every document, and every document that
+ * shares no term with the query scores exactly 0.0 -- most of a corpus).  fz_sort_rows_desc(keys, 64, NULL, ...) for float64 rows in the
+ * identity sequence, through an instantiation in which a row of 8,193 .. 28,672 columns at least 3/8 of whose >= 4,096 keys are +-0.0 leaves
+ * the zeros out of the ordering phases: the non-zero keys are compacted into fewer items per thread, sorted, and written around the block
+ * of zeros, which keep their sequence order (csrc/sort.hip, ZC).  Same stable permutation and outputs, bit for bit, whatever the rows hold;
+ * a row without zeros costs ~5 % more here than through fz_sort_rows_desc, a row of 60 % zeros 20 % less, of 80 % a third less -- which is why
+ * the caller says what its rows are.  Needs the order output (its row doubles as scratch); other shapes take fz_sort_rows_desc's path.
+ * FZ_SORT_ZERO_COMPACT=0 in the environment turns the instantiation off (A/B runs).  fz_sort_zero_compact_rows: counts2[0] = rows compacted on
+ * the current device since the last reset, counts2[1] = rows that went through it with too few zeros; reset != 0 clears.  Synchronises the
+ * device (tests and tools only). */
+int fz_sort_rows_desc_lexical(const double* keys, const int32_t* row_len, int rows, int n, int ld, int32_t* order, double* sorted_keys,
+                              int32_t* rank, float* row_stats, void* workspace, size_t workspace_bytes, void* stream);
+int fz_sort_zero_compact_rows(uint64_t* counts2, int reset);
 /* row_stats (nullable, [4][rows] fp32): mean | UNBIASED standard deviation | min | max of each list's values as float32 (fp64 keys
  * rounded first) -- torch.mean / torch.std / torch.min / torch.max of hybrid.py:254-262, a by-product of having the row in
  * registers (min and max of a sorted list are its two ends; a NaN sorts first and makes both NaN): with them min-max and z-score
