@@ -113,6 +113,44 @@ def case_sort_bucket(rng):
     return f"bucket-range sort rows={rows} n={n} kind={kind} mode={mode}"
 
 
+def case_sort_lexical(rng):
+    """float64 rows in the zero compaction's range (8,193 .. 28,672 columns) through fz_sort_rows_desc_lexical: a random share of exact
+    zeros (of either sign) around BM25-like scores -- positive heavy tails with repeated values, a share of negative ones (idf <= 0),
+    denormals under zero's high key word, specials, runs of keys under one high key word (the repair in the compact layout), ragged
+    lengths, any subset of the outputs, statistics -- against the oracle and against the plain instantiation."""
+    rows = int(rng.integers(1, 5))
+    n = int(rng.integers(8193, 28673))
+    k = rng.gamma(rng.uniform(0.3, 2.0), rng.uniform(0.1, 8.0), (rows, n)) + 10.0 ** rng.uniform(-6, 0)
+    if rng.random() < 0.5: k = np.where(rng.random((rows, n)) < 0.4, np.round(k, int(rng.integers(0, 3))), k)
+    if rng.random() < 0.4: k = np.where(rng.random((rows, n)) < rng.uniform(0, 0.5), -k * rng.uniform(0.01, 1.0), k)
+    for r in range(rows):
+        zf = rng.choice([0.0, 0.3, 0.375, 0.4, 0.6, 0.8, 0.97, 1.0])
+        zi = rng.random(n) < zf
+        k[r, zi] = np.where(rng.random(int(zi.sum())) < 0.2, -0.0, 0.0)
+        if rng.random() < 0.3:
+            j = rng.choice(n, size=int(rng.integers(1, 40)), replace=False)
+            k[r, j] = 5e-324 * rng.integers(1, 1000, len(j)) * rng.choice([1.0, -1.0])
+        if rng.random() < 0.3:
+            j = rng.choice(n, size=int(rng.integers(2, 2500)), replace=False)
+            k[r, j] = 3.0 + rng.permutation(len(j)) * np.finfo(np.float64).eps * 2       # one high key word, shuffled low words
+        if rng.random() < 0.2:
+            k[r, rng.integers(0, n)] = rng.choice([np.inf, -np.inf, np.nan])
+    lens = rng.integers(0, n + 1, rows).astype(np.int32) if rng.random() < 0.3 else None
+    want_keys, want_rank, stats = rng.random() < 0.5, rng.random() < 0.7, rng.random() < 0.5
+    kp = plane(k.astype(np.float64))
+    st = torch.empty((4, rows), dtype=torch.float32, device="cuda") if stats else None
+    st2 = torch.empty((4, rows), dtype=torch.float32, device="cuda") if stats else None
+    rl = None if lens is None else dev(lens)
+    o, sk, r_ = ops.sort_rows_desc(kp, row_len=rl, want_keys=want_keys, want_rank=want_rank, stats_out=st, lexical=True)
+    o2, sk2, r2 = ops.sort_rows_desc(kp, row_len=rl, want_keys=want_keys, want_rank=want_rank, stats_out=st2)
+    eo, esk, er = oracle.sort_rows_desc(k.astype(np.float64), row_len=lens, want_rank=True)
+    np.testing.assert_array_equal(o.cpu().numpy(), eo); assert torch.equal(o, o2)
+    if want_keys: np.testing.assert_array_equal(sk.cpu().numpy(), esk); assert torch.equal(sk.view(torch.int64), sk2.view(torch.int64))
+    if want_rank: np.testing.assert_array_equal(r_.cpu().numpy(), er); assert torch.equal(r_, r2)
+    if stats: assert torch.equal(st.view(torch.int32), st2.view(torch.int32))
+    return f"lexical sort rows={rows} n={n} lens={lens is not None} keys={want_keys} rank={want_rank} stats={stats}"
+
+
 def case_placed(rng):
     N, Q = int(rng.integers(1, 6000)), int(rng.integers(1, 4))
     planes, ranks, orders, lens = systems(rng, 1, Q, N, rng.random() < 0.5)
@@ -726,7 +764,7 @@ def case_empty(rng):
     return f"empty batches n={n}"
 
 
-CASES = [case_encoder, case_lists, case_empty, case_rank_fused, case_rank_fused, case_sort, case_sort_bucket, case_sort_bucket, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
+CASES = [case_encoder, case_lists, case_empty, case_rank_fused, case_rank_fused, case_sort, case_sort_bucket, case_sort_bucket, case_sort_lexical, case_sort_lexical, case_placed, case_fuse, case_fuse, case_topk, case_cos, case_attn, case_layernorm, case_maxsim, case_bm25, case_tune,
          case_topk_stream, case_segments, case_fused_search, case_sort_stats, case_select, case_splade_head, case_fuse_ranked, case_maxsim, case_f16_kernels, case_encoder_amp, case_rerun, case_rerun, case_sparse, case_tables, case_tables]
 
 
@@ -757,6 +795,7 @@ def main():
     torch.cuda.synchronize()
     print(f"OK: {n} random cases in {time.time() - t0:.0f} s (seed {a.seed}): {counts}")
     print("row sort, bucket ranking: rows ordered | of those with a pair swapped back | rows handed to the digit passes =", ops.sort_bucket_rank_rows())
+    print("row sort, zero compaction: rows compacted | rows that went through the instantiation whole =", ops.sort_zero_compact_rows())
 
 
 if __name__ == "__main__":
