@@ -77,6 +77,7 @@ def parse():
     p.add_argument("--no-gemm-tuning", action="store_true",
                    help="leave the encoder's fp32 Linears to the library heuristics instead of PyTorch TunableOp (fusion_amd/tuned/gemm_gfx950.csv)")
     p.add_argument("--two-kernel-fuse", action="store_true", help="round 4's step: fz_fuse_rank_f64 then fz_sort_rows_desc_placed on its float64 plane (A/B against the fused sort)")
+    p.add_argument("--bm25-per-posting-expression", action="store_true", help="rounds 1-5's BM25 scoring: the float64 expression per (query, posting) instead of the per-index posting-value table (A/B)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-configs", action="store_true", help="skip the configs_measured block (configs 2-5 timed live after the headline region)")
     p.add_argument("--no-one-gpu-reference", action="store_true",
@@ -234,12 +235,15 @@ def build_lleqa(args, dev, rank):
                       qoff=torch.from_numpy(qoff).to(dev), qterms=torch.from_numpy(qterms).to(dev))
     st["bm25"]["doc_norm"] = ops.bm25_doc_norms(st["bm25"]["doc_len"], st["bm25"]["avgdl"], 2.5, 0.2)   # per index, like the idf table
     st["bm25"]["slice_off"] = ops.bm25_slice_offsets(st["bm25"]["toff"], st["bm25"]["pdoc"], N)         # ditto
+    # ditto: every posting's whole BM25 term for this index and (k1, b) -- what BM25._doc_norm keeps next to the norms (round 6)
+    st["bm25"]["pval"] = ops.bm25_posting_values(st["bm25"]["toff"], st["bm25"]["pdoc"], st["bm25"]["ptf"], st["bm25"]["idf"], st["bm25"]["doc_norm"], 2.5)
     st["lens2"] = torch.full((2, Q), N, dtype=torch.int32, device=dev)
     st["Q"], st["N"], st["d"] = Q, N, d
     st["buckets"] = args.encode_buckets
     st["encode_mode"] = args.encode_mode
     st["overlap"] = args.overlap_bm25
     st["two_kernel_fuse"] = args.two_kernel_fuse
+    st["bm25_expr"] = args.bm25_per_posting_expression
     st["host"] = dict(idf=idf, toff=toff, pd=pd, tf=tf, lens=lens, qoff=qoff, qterms=qterms)
     st["bm25_postings"] = int(df[qterms].sum())     # postings the batch's query terms touch (terms repeat: bm25.py:152 does not de-duplicate)
     return st
@@ -305,7 +309,7 @@ def step_lleqa(st, ev=None):
 
     def bm25_branch():
         B = ops.bm25_scores(b["toff"], b["pdoc"], b["ptf"], b["idf"], b["doc_len"], b["avgdl"], 2.5, 0.2, b["qoff"], b["qterms"], Q, N,
-                            doc_norm=b["doc_norm"], slice_off=b["slice_off"])
+                            doc_norm=b["doc_norm"], slice_off=b["slice_off"], pval=None if st.get("bm25_expr") else b["pval"])
         if ev: ev.mark("bm25_score")
         o_b, _, r_b = ops.sort_rows_desc(B, want_keys=False, want_rank=True, lexical=True)   # (what BM25.search_device calls: a lexical ranker's rows)
         if ev: ev.mark("bm25_rank")

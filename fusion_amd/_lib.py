@@ -91,6 +91,8 @@ _PROTOS = {
     "fz_bm25_slice_offsets": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "fz_bm25_scores_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "fz_bm25_scores_f64_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "fz_bm25_posting_values_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _d, _vp, _vp]),
+    "fz_bm25_scores_pv_f64_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
     "fz_tfidf_scores_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
     "fz_tune_max_gold": (_i, []),
     "fz_gold_ranks_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -1015,10 +1015,26 @@ def bm25_slice_offsets(toff: torch.Tensor, pdoc: torch.Tensor, N: int) -> torch.
 
 
 def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float, qoff, qterms, Q: int, N: int,
-                doc_norm: torch.Tensor | None = None, slice_off: torch.Tensor | None = None, want_f32: bool = False):
+                doc_norm: torch.Tensor | None = None, slice_off: torch.Tensor | None = None, want_f32: bool = False,
+                pval: torch.Tensor | None = None):
     """BM25 scores [Q, N] float64 (bm25.py:149-156).  want_f32: also the float32 rounding of the same scores (the plane the normalisations
-    read, hybrid.py:255), written by the same launch -> (float64 plane, float32 plane)."""
+    read, hybrid.py:255), written by the same launch -> (float64 plane, float32 plane).  pval: the posting-value table of this index for
+    this (k1, b) (bm25_posting_values): the walk then adds tabulated terms instead of dividing per posting -- same bits."""
     dev = idf.device
+    if pval is not None:
+        for t, dt, what in ((toff, torch.int64, "toff"), (pdoc, torch.int32, "pdoc"), (pval, torch.float64, "pval"), (qoff, torch.int64, "qoff"),
+                            (qterms, torch.int32, "qterms")):
+            _need(_dev(t, dt, f"bm25_scores({what})").is_contiguous(), f"bm25_scores({what}) must be contiguous")
+        _need(pval.numel() == pdoc.numel() and qoff.numel() == Q + 1, "bm25_scores: pval must hold one value per posting and qoff Q + 1 offsets")
+        if slice_off is not None:
+            NS = max(1, -(-int(N) // int(_lib.lib().fz_bm25_slice_docs())))
+            _need(_dev(slice_off, torch.int64, "bm25_scores(slice_off)").is_contiguous() and tuple(slice_off.shape) == (toff.numel() - 1, NS + 1),
+                  f"bm25_scores(slice_off): expected a contiguous [{toff.numel() - 1}, {NS + 1}] table (ops.bm25_slice_offsets)")
+        out = torch.empty((max(Q, 1), max(round_up(N, _PAD), _PAD)), dtype=torch.float64, device=dev)[:Q, :N]
+        out32 = alloc_plane(Q, N, torch.float32, dev) if want_f32 else None
+        check(_lib.lib().fz_bm25_scores_pv_f64_f32(_ptr(toff), _ptr(pdoc), _ptr(pval), _ptr(slice_off), _ptr(qoff), _ptr(qterms), Q, N, _ptr(out),
+                                                   _ld(out), _ptr(out32), _ld(out32) if want_f32 else 0, _stream(pval)), "fz_bm25_scores_pv_f64_f32")
+        return (out, out32) if want_f32 else out
     for t, dt, what in ((toff, torch.int64, "toff"), (pdoc, torch.int32, "pdoc"), (ptf, torch.int32, "ptf"), (idf, torch.float64, "idf"),
                         (doc_len, torch.int32, "doc_len"), (qoff, torch.int64, "qoff"), (qterms, torch.int32, "qterms")):
         _need(_dev(t, dt, f"bm25_scores({what})").is_contiguous(), f"bm25_scores({what}) must be contiguous")
@@ -1037,6 +1053,19 @@ def bm25_scores(toff, pdoc, ptf, idf, doc_len, avgdl: float, k1: float, b: float
                                             float(k1), float(b), _ptr(qoff), _ptr(qterms), Q, N, _ptr(out), _ld(out), _ptr(out32),
                                             _ld(out32) if want_f32 else 0, _stream(idf)), "fz_bm25_scores_f64_f32")
     return (out, out32) if want_f32 else out
+
+
+def bm25_posting_values(toff, pdoc, ptf, idf, doc_norm, k1: float) -> torch.Tensor:
+    """[nnz] float64: every posting's BM25 term idf * (tf (k1 + 1)) / (tf + doc_norm[d]) (bm25.py:154) for the (k1, b) doc_norm was made
+    with -- per index, like the idf table (fz_bm25_posting_values_f64); bm25_scores(pval=...) then only adds."""
+    for t, dt, what in ((toff, torch.int64, "toff"), (pdoc, torch.int32, "pdoc"), (ptf, torch.int32, "ptf"), (idf, torch.float64, "idf"),
+                        (doc_norm, torch.float64, "doc_norm")):
+        _need(_dev(t, dt, f"bm25_posting_values({what})").is_contiguous(), f"bm25_posting_values({what}) must be contiguous")
+    _need(toff.numel() == idf.numel() + 1 and pdoc.numel() == ptf.numel(), "bm25_posting_values: toff [V + 1], idf [V], pdoc / ptf [nnz] expected")
+    out = torch.empty(pdoc.numel(), dtype=torch.float64, device=idf.device)
+    check(_lib.lib().fz_bm25_posting_values_f64(_ptr(toff), _ptr(pdoc), _ptr(ptf), _ptr(idf), _ptr(doc_norm), idf.numel(), pdoc.numel(), float(k1),
+                                                _ptr(out), _stream(idf)), "fz_bm25_posting_values_f64")
+    return out
 
 
 def tfidf_scores(toff, pdoc, ptf, idf, qoff, qterms, Q: int, N: int, slice_off: torch.Tensor | None = None, want_f32: bool = False):

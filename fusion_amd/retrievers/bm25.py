@@ -159,8 +159,11 @@ class BM25(TFIDF):
     """bm25.py:129-161: score(q, d) = sum of idf * tf (k1 + 1) / (tf + k1 (1 - b + b |d| / avgdl)), idf = log10((N - df + .5) / (df + .5))
     (can be <= 0), avgdl = statistics.mean(doc_len)."""
 
+    USE_POSTING_VALUES = True   # False: the per-posting expression (fz_bm25_scores_f64_f32): A/B runs and tests of the two forms
+
     def __init__(self, corpus: list[str], k1: float, b: float, device="cuda"):
         self.k1, self.b = k1, b
+        self._pval = None
         super().__init__(corpus, device=device)
         self.avgdl = float(mean(self.doc_len_host.tolist())) if self.corpus_size else 0.0   # bm25.py:138
         self._norm_key, self._norm = None, None
@@ -176,15 +179,19 @@ class BM25(TFIDF):
         key = (float(self.k1), float(self.b))
         if self._norm_key != key:
             self._norm = ops.bm25_doc_norms(self.doc_len, self.avgdl, self.k1, self.b)
+            # every posting's whole term idf * (tf (k1 + 1)) / (tf + norm_d) for this (k1, b): per index, like the idf table -- the scoring
+            # walk then only adds (no float64 division per (query, posting)); same bits
+            self._pval = ops.bm25_posting_values(self.toff, self.pdoc, self.ptf, self.idf, self._norm, self.k1) if self.pdoc.numel() else None
             self._norm_key = key
         return self._norm
 
     def scores(self, queries: list[str], want_f32: bool = False):
         """[Q, N] float64 plane (want_f32: and its float32 rounding, from the same launch); query terms are NOT de-duplicated (bm25.py:152)."""
         qoff, flat = self._query_csr(queries)
+        norm = self._doc_norm()
         return ops.bm25_scores(self.toff, self.pdoc, self.ptf, self.idf, self.doc_len, self.avgdl, self.k1, self.b,
                                qoff, flat, len(queries), self.corpus_size,
-                               doc_norm=self._doc_norm(), slice_off=self.slice_off, want_f32=want_f32)
+                               doc_norm=norm, slice_off=self.slice_off, want_f32=want_f32, pval=self._pval if self.USE_POSTING_VALUES else None)
 
     # -- the grid search of bm25.py:221-237 on the device --------------------------------------------------------------
     def tune(self, queries: list[str], labels: list[list], ids=None, k1_range=None, b_range=None,

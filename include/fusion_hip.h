@@ -330,7 +330,7 @@ int fz_topk_allgather(const float* local_scores, const int64_t* local_ids, int Q
  * sub-expression, computed once per document instead of once per posting. */
 int fz_bm25_doc_norms_f64(const int32_t* doc_len, int N, double avgdl, double k1, double b, double* out, void* stream);
 /* slice_off (nullable): per-index table [V][NS + 1] int64, NS = ceil(N / fz_bm25_slice_docs()): the first posting of term t whose document
- * is >= s * fz_bm25_slice_docs() (entry NS = toff[t + 1]), from fz_bm25_slice_offsets -- a workgroup scores one (query, document slice) and
+ * is >= s * fz_bm25_slice_docs() (entry NS = toff[t + 1]), from fz_bm25_slice_offsets (a GRAIN of 3,584 documents; a workgroup scores one (query, slice of one or two grains)) -- a workgroup
  * otherwise finds every query term's posting sub-range by two binary searches of ~15 dependent loads each. */
 int fz_bm25_slice_docs(void);
 int fz_bm25_slice_offsets(const int64_t* toff, const int32_t* pdoc, int V, int N, int64_t* out, void* stream);
@@ -343,6 +343,16 @@ int fz_bm25_scores_f64_f32(const int64_t* toff, const int32_t* pdoc, const int32
                            const double* doc_norm, const int64_t* slice_off, double avgdl, double k1, double b, const int64_t* qoff,
                            const int32_t* qterms, int Q, int N, double* scores, int lds, float* scores32, int lds32, void* stream);
 
+/* Round 6 (ABI 19): the posting-value table.  For a given index and (k1, b) every posting has ONE term value
+ *   pval[e] = idf_t * (tf_e * (k1 + 1)) / (tf_e + doc_norm[d_e])      (float64, the expression order of bm25.py:154)
+ * -- idf, tf and the length norm are all the index's, nothing in it depends on the query.  fz_bm25_posting_values_f64 tabulates it once
+ * (like the idf table; once per (k1, b) of a grid search), fz_bm25_scores_pv_f64_f32 is fz_bm25_scores_f64_f32 whose walk only ADDS the
+ * tabulated terms, in query order: the same planes, bit for bit, without a float64 division per (query, posting) -- most of the scoring
+ * kernel's time (1024 queries x 27,942 documents: 0.33 -> 0.1x ms).  doc_norm: fz_bm25_doc_norms_f64 (required here). */
+int fz_bm25_posting_values_f64(const int64_t* toff, const int32_t* pdoc, const int32_t* ptf, const double* idf, const double* doc_norm,
+                               int V, int64_t nnz, double k1, double* out, void* stream);
+int fz_bm25_scores_pv_f64_f32(const int64_t* toff, const int32_t* pdoc, const double* pval, const int64_t* slice_off, const int64_t* qoff,
+                              const int32_t* qterms, int Q, int N, double* scores, int lds, float* scores32, int lds32, void* stream);
 /* TFIDF.score (bm25.py:108-115), the base class of the reference's lexical retrievers: scores[q][j] (fp64) = sum over the query's terms,
  * in query order, of tf(t, d) * idf(t) -- the same posting walk without the length norm.  idf [V] is the caller's table (TFIDF's is
  * log10((N + 1) / (df + 1)), bm25.py:86-88; AtireBM25 hands that table to fz_bm25_scores_f64 instead, bm25.py:170-172).  slice_off,

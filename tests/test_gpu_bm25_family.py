@@ -145,3 +145,26 @@ def test_driver_end_to_end(tmp_path, oracle):
     w = docs[3].split()[0]
     assert tf[w][3] == docs[3].split().count(w) and dfc[w] == sum(1 for d in docs if w in d.split())
     assert idf[w] == om.idf[om.vocab[w]] and type(dfc).__name__ == "Counter"
+
+
+def test_posting_value_table_gives_the_same_bits(oracle):
+    """Round 6: BM25 scoring that ADDS tabulated posting terms (fz_bm25_posting_values_f64 + fz_bm25_scores_pv_f64_f32) == the per-posting
+    float64 expression (fz_bm25_scores_f64_f32) == the oracle, bit for bit: five 7,168-document slices, repeated / unknown / no query terms,
+    negative idf (a term in more than half of the documents), after update_params (a new table per (k1, b)), the float32 plane too."""
+    from fusion_amd.retrievers.bm25 import BM25
+    rng = np.random.default_rng(41)
+    vocab = np.array([f"w{i}" for i in range(1500)])
+    p = 1.0 / np.arange(1, 1501); p /= p.sum()
+    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(5, 120)), p=p)) for _ in range(30_011)]
+    queries = [" ".join(rng.choice(vocab, size=int(rng.integers(1, 12)), p=p)) for _ in range(30)] + ["", "zzz w1 w1", "w0 w0 w0"]
+    m = BM25(docs, 2.5, 0.2)
+    assert float(m.idf_host.min()) < 0.0
+    for k1, b in ((2.5, 0.2), (0.9, 0.4), (0.0, 0.7), (8.0, 1.0)):
+        m.update_params(k1, b)
+        m.USE_POSTING_VALUES = True
+        a64, a32 = m.scores(queries, want_f32=True)
+        assert m._pval is not None and m._pval.numel() == m.pdoc.numel()
+        m.USE_POSTING_VALUES = False
+        b64, b32 = m.scores(queries, want_f32=True)
+        assert torch.equal(a64.view(torch.int64), b64.view(torch.int64)) and torch.equal(a32.view(torch.int32), b32.view(torch.int32))
+        np.testing.assert_array_equal(a64.cpu().numpy(), oracle.BM25(docs, k1, b).scores(queries))

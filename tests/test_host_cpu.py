@@ -104,7 +104,19 @@ def test_workspace_planning_is_consistent():
     assert L.fz_topk_merge(None, None, 2, 1, 10, None, None, None) == ERR
     assert L.fz_topk_allgather(None, None, 1, 10, None, 2, None, None, None, 0, None) == ERR
     assert L.fz_bm25_scores_f64(None, None, None, None, None, None, None, 1.0, 2.5, 0.2, None, None, 1, 1, None, 1, None) == ERR
-    assert L.fz_bm25_slice_offsets(None, None, 5, 10, None, None) == ERR and L.fz_bm25_slice_docs() == 7168
+    assert L.fz_bm25_slice_offsets(None, None, 5, 10, None, None) == ERR and L.fz_bm25_slice_docs() == 3584
+    # ABI 19: the posting-value table and the scoring walk over it
+    assert L.fz_bm25_posting_values_f64(None, None, None, None, None, 3, 5, 2.5, None, None) == ERR
+    assert L.fz_bm25_posting_values_f64(None, None, None, None, None, -1, 5, 2.5, None, None) == ERR
+    assert L.fz_bm25_posting_values_f64(None, None, None, None, None, 0, 0, 2.5, None, None) == 0
+    assert L.fz_bm25_scores_pv_f64_f32(None, None, None, None, None, None, 1, 1, None, 1, None, 0, None) == ERR
+    assert L.fz_bm25_scores_pv_f64_f32(None, None, None, None, None, None, 1, 4, one, 2, None, 0, None) == ERR      # lds < N
+    assert L.fz_bm25_scores_pv_f64_f32(None, None, None, None, None, None, 0, 4, None, 4, None, 0, None) == 0
+    # ABI 19: the lexical ranking sort
+    assert L.fz_sort_rows_desc_lexical(None, None, 1, 4, 2, None, None, None, None, None, 0, None) == ERR             # ld < n
+    assert L.fz_sort_rows_desc_lexical(None, None, 1, 20000, 20000, None, None, None, None, None, 0, None) == ERR     # no keys
+    assert L.fz_sort_rows_desc_lexical(None, None, 0, 20000, 20000, None, None, None, None, None, 0, None) == 0
+    assert L.fz_sort_rows_desc_lexical(one, None, 1, 20000, 20000, one, None, None, None, None, 0, None) == _lib.FZ_ERR_WORKSPACE
     # ABI 19: TF-IDF scoring (bm25.py:108-115) -- null planes, ld < N, empty problems
     assert L.fz_tfidf_scores_f64(None, None, None, None, None, None, None, 1, 1, None, 1, None, 0, None) == ERR
     assert L.fz_tfidf_scores_f64(None, None, None, None, None, None, None, 1, 4, one, 2, None, 0, None) == ERR      # lds < N
