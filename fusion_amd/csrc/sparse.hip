@@ -6,13 +6,18 @@
 //      score[d] = sum over the query's non-zero terms t, in ascending t, of q_t * w_{t,d}
 // i.e. the same products as the dense contraction minus the exact zeros (adding +0.0 to a float32 sum changes nothing: SPLADE weights are
 // >= 0), summed in vocabulary order with one rounding per product and per add (the dense MFMA form fuses them): equal within ~1e-7 relative.
-// One workgroup = (query, slice of SP_SLICE documents): float32 accumulators in LDS (the whole LLeQA corpus is one slice), the postings of
+// One workgroup = (query, slice of SP_SLICE documents): float32 accumulators in LDS, the postings of
 // one term touch distinct documents (no atomics), terms one after the other (barrier): bit-reproducible.  Structure of bm25.hip's kernel.
 #include "common.h"
 
 namespace fz {
 
-constexpr int SP_SLICE = 28672;     // fp32 accumulators: 112 KiB of the CU's 160 KiB LDS
+// 7,168 fp32 accumulators (28 KiB) and 512 threads per workgroup: four workgroups per CU.  A SPLADE query's walk is a few dozen short posting
+// lists with a barrier each; independent workgroups fill each other's waits (round 6, measured per 1024 x 27,942: 28,672 documents x 1024
+// threads -- the whole corpus in one workgroup -- 0.275 ms, 14,336 x 1024 0.220, 14,336 x 512 0.258, 7,168 x 256 0.246, 3,584 x 256 0.196,
+// 7,168 x 512 0.202)
+constexpr int SP_SLICE = 7168;
+constexpr int SP_THREADS = 512;
 constexpr int SP_TERMS = 256;       // query terms whose posting ranges are resolved per batch
 
 struct SparseArgs {
@@ -116,7 +121,7 @@ extern "C" int fz_sparse_dot_f32(const int64_t* toff, const int32_t* pdoc, const
     static unsigned long long lds_set = 0ull;
     if (int rc = raise_lds_limit((const void*)sparse_dot_kernel, lds_bytes, lds_set)) return rc;
     dim3 grid((unsigned)((N + SP_SLICE - 1) / SP_SLICE), (unsigned)Q);
-    sparse_dot_kernel<<<grid, 1024, lds_bytes, as_stream(stream)>>>(a);
+    sparse_dot_kernel<<<grid, SP_THREADS, lds_bytes, as_stream(stream)>>>(a);
     FZ_LAUNCH_CHECK();
     return FZ_OK;
 }

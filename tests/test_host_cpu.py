@@ -131,7 +131,7 @@ def test_workspace_planning_is_consistent():
     assert L.fz_attn_varlen_f16_amp(None, 1, None, 1, 12, 64, 0.125, None, 1, None) == ERR
     assert L.fz_add_layernorm_x16(None, 1, None, 1, None, None, 1e-5, 1, 768, None, 1, None, 0, None) == ERR
     assert L.fz_gelu_f16(None, None, 8, None) == ERR
-    assert L.fz_sparse_dot_f32(None, None, None, None, None, None, None, 1, 1, None, 1, None) == ERR and L.fz_sparse_slice_docs() == 28672
+    assert L.fz_sparse_dot_f32(None, None, None, None, None, None, None, 1, 1, None, 1, None) == ERR and L.fz_sparse_slice_docs() == 7168
     assert L.fz_sparse_slice_offsets(None, None, 5, 10, None, None) == ERR
     assert L.fz_segment_mean_f32(None, 1, None, 1, 768, None, 1, None) == ERR
 
