@@ -373,7 +373,8 @@ def algorithmic_work(st):
         "dpr_score": dict(kernel="dot_scores_kernel (+ normalize_rows)", bound="mfma_f32", work=2.0 * Q * N * d),
         "dpr_rank": dict(kernel="sort_rows_kernel (f32 keys)", bound="hbm", work=e * (4 + 4 + 4)),
         # BM25: every touched posting read once (doc id + tf, 8 B) + the fp64 score plane written once
-        "bm25_score": dict(kernel="bm25_kernel", bound="hbm", work=st.get("bm25_postings", 0) * 8 + e * 8),
+        # (round 6: doc id + the posting's tabulated float64 term, 12 B; rounds 1-5: doc id + tf, 8 B)
+        "bm25_score": dict(kernel="bm25_kernel", bound="hbm", work=st.get("bm25_postings", 0) * (8 if st.get("bm25_expr") else 12) + e * 8),
         "bm25_rank": dict(kernel="sort_rows_kernel (f64 keys)", bound="hbm", work=e * (8 + 4 + 4)),
     })
     if st.get("two_kernel_fuse"):
@@ -509,6 +510,25 @@ def measure_configs(dev, N=27942):
         out.append(dict(config="2: DPR full ranking", shape=dict(Q=Q, N=N), **roof("sort_rows_kernel (f32 keys)", ms, Q * N * 12, "hbm"),
                         ms_digit_passes=ms_digits, rows_bucket_ranked=br[0], rows_pair_swapped_back=br[1], rows_handed_to_digit_passes=br[2]))
     del Dn, Qn
+
+    # -- config 1's lexical side: the ranking sort of BM25-like float64 rows as a function of their share of EXACT zeros (documents that share
+    #    no term with the query; the bench step's own synthetic index keeps its stop-word-like terms, so its rows hold ~2 % zeros) -- the
+    #    zero-compacting instantiation (fz_sort_rows_desc_lexical, what BM25.search_device calls) against the plain one, same rows, same outputs
+    Bz = ops.alloc_plane(1024, N, torch.float64, dev)
+    for zf in (0.0, 0.4, 0.6, 0.8):
+        x = torch.distributions.Gamma(0.8, 0.25).sample((1024, N)).to(dev).double() + 0.01
+        x[torch.rand((1024, N), generator=g, device=dev) < zf] = 0.0
+        Bz.copy_(x); del x
+        ms_lex = timeit_ms(lambda: ops.sort_rows_desc(Bz, want_keys=False, want_rank=True, lexical=True), n=10)
+        ms_plain = timeit_ms(lambda: ops.sort_rows_desc(Bz, want_keys=False, want_rank=True), n=10)
+        ops.sort_zero_compact_rows(reset=True)
+        a_ = ops.sort_rows_desc(Bz, want_keys=False, want_rank=True, lexical=True)
+        zc = ops.sort_zero_compact_rows(reset=True)
+        b_ = ops.sort_rows_desc(Bz, want_keys=False, want_rank=True)
+        out.append(dict(config="1: BM25 ranking sort vs the rows' share of exact zeros", shape=dict(Q=1024, N=N, zero_share=zf),
+                        **roof("sort_rows_kernel<SORT_ROWS_ZC> (f64 keys, zero compaction)", ms_lex, 1024 * N * 16, "hbm"), ms_plain_instantiation=ms_plain,
+                        rows_compacted=zc[0], rows_kept_whole=zc[1], outputs_equal=bool(torch.equal(a_[0], b_[0]) and torch.equal(a_[2], b_[2]))))
+    del Bz
 
     log("configs: DPR done")
     # -- config 3: ColBERT MaxSim, Q = 195, L_q = 64, L_d ~ clip(N(300,120),16,512), dim 128, fp16 unit-norm tokens ---
