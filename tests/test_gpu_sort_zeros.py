@@ -181,3 +181,14 @@ def test_bm25_search_device_takes_the_compacting_sort(ops, oracle):
     eo, ek = oracle.sort_rows_desc(oracle.BM25(docs, 2.5, 0.2).scores(queries))
     np.testing.assert_array_equal(rs.order.cpu().numpy(), eo)
     np.testing.assert_array_equal(rs.list_scores().cpu().numpy(), ek)
+
+
+def test_a_compacted_row_the_fast_form_cannot_finish_goes_to_the_generic_launch(ops, oracle):
+    """More than 2,048 keys under one high key word, out of order in their low words: the compacted row is flagged after its low words were
+    parked in the order output -- the generic eight-pass launch rewrites every output of that row; its neighbours stay compacted."""
+    rng = np.random.default_rng(31)
+    n = 27942
+    K = bm25_like(rng, 3, n, 0.6)
+    j = rng.choice(n, size=3000, replace=False)
+    K[1, j] = 3.0 + rng.permutation(3000) * np.finfo(np.float64).eps * 2
+    check(ops, oracle, K, stats=True, expect=(3, 0))
