@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32, dense
 MFMA_F16_PEAK_TF = 2500.0      # v_mfma_f32_32x32x16_f16, dense
 METRIC = "queries/sec end-to-end (encode+score+fuse), LLeQA test; recall@500 parity"
-TRAFFIC_PROFILES = ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
+TRAFFIC_PROFILES = ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
 # the stages of the step that ARE the path's kernels (scoring, ranking, fusion behind the C ABI).  The bench line's
 # `roofline` names the one of THESE that takes the most time per step; the encoder's kernels (HIP and vendor) stay in `roofline_all`.
 PATH_STAGES = ("dpr_score", "dpr_rank", "bm25_score", "bm25_rank", "fuse_rrf", "final_order")
@@ -391,7 +391,7 @@ def profiled_traffic(stage, st):
     shape it was collected on, otherwise None.  Returns (bytes, source file)."""
     if (st["Q"], st["N"], st["d"]) != (1024, 27942, 768):
         return None, None
-    pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1,", "bm25_rank": "sort_rows_kernel<1024, 28, 2, false, 1>",
+    pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1,", "bm25_rank": "sort_rows_kernel<1024, 28, 2, false, 3>",   # (round 6: the lexical instantiation; r05 profiles: <..., 1>)
             "final_order": "sort_rows_kernel<1024, 28, 2, false, 2>", "fuse_rrf": "fuse_rank_kernel", "bm25_score": "bm25_kernel", "encode_attn": "attn_varlen_kernel",
             "encode_gelu": "gelu_kernel", "encode_ln": "add_layernorm_kernel"}
     for name in TRAFFIC_PROFILES:
@@ -399,8 +399,11 @@ def profiled_traffic(stage, st):
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:
             continue
+        pat = pats.get(stage, "\0")
+        if stage == "bm25_rank" and not name.startswith("r06"):
+            pat = "sort_rows_kernel<1024, 28, 2, false, 1>"
         for k, v in t.items():
-            if k != "_note" and pats.get(stage, "\0") in k:
+            if k != "_note" and pat in k:
                 return v.get("hbm_bytes_corrected"), f"profiles/{name}"
     return None, None
 
