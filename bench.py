@@ -245,6 +245,10 @@ def build_lleqa(args, dev, rank):
     st["two_kernel_fuse"] = args.two_kernel_fuse
     st["bm25_expr"] = args.bm25_per_posting_expression
     st["host"] = dict(idf=idf, toff=toff, pd=pd, tf=tf, lens=lens, qoff=qoff, qterms=qterms)
+    # which instantiation of the ranking sort BM25.search_device would ask for: its host-side estimate of the rows' share of exact zeros
+    from fusion_amd.retrievers.bm25 import LEXICAL_MIN_ZERO_SHARE, expected_zero_share
+    st["bm25_zero_share_estimate"] = expected_zero_share(df, N, [qterms[qoff[q]:qoff[q + 1]].tolist() for q in range(Q)])
+    st["bm25_lexical"] = st["bm25_zero_share_estimate"] >= LEXICAL_MIN_ZERO_SHARE
     st["bm25_postings"] = int(df[qterms].sum())     # postings the batch's query terms touch (terms repeat: bm25.py:152 does not de-duplicate)
     return st
 
@@ -311,7 +315,7 @@ def step_lleqa(st, ev=None):
         B = ops.bm25_scores(b["toff"], b["pdoc"], b["ptf"], b["idf"], b["doc_len"], b["avgdl"], 2.5, 0.2, b["qoff"], b["qterms"], Q, N,
                             doc_norm=b["doc_norm"], slice_off=b["slice_off"], pval=None if st.get("bm25_expr") else b["pval"])
         if ev: ev.mark("bm25_score")
-        o_b, _, r_b = ops.sort_rows_desc(B, want_keys=False, want_rank=True, lexical=True)   # (what BM25.search_device calls: a lexical ranker's rows)
+        o_b, _, r_b = ops.sort_rows_desc(B, want_keys=False, want_rank=True, lexical=st["bm25_lexical"])   # (as BM25.search_device: the zero-compacting instantiation when the rows are expected to be mostly zeros)
         if ev: ev.mark("bm25_rank")
         return B, o_b, r_b
 
@@ -391,7 +395,7 @@ def profiled_traffic(stage, st):
     shape it was collected on, otherwise None.  Returns (bytes, source file)."""
     if (st["Q"], st["N"], st["d"]) != (1024, 27942, 768):
         return None, None
-    pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1,", "bm25_rank": "sort_rows_kernel<1024, 28, 2, false, 3>",   # (round 6: the lexical instantiation; r05 profiles: <..., 1>)
+    pats = {"dpr_score": "dot_scores_kernel", "dpr_rank": "sort_rows_kernel<1024, 28, 1,", "bm25_rank": "sort_rows_kernel<1024, 28, 2, false, 1>",
             "final_order": "sort_rows_kernel<1024, 28, 2, false, 2>", "fuse_rrf": "fuse_rank_kernel", "bm25_score": "bm25_kernel", "encode_attn": "attn_varlen_kernel",
             "encode_gelu": "gelu_kernel", "encode_ln": "add_layernorm_kernel"}
     for name in TRAFFIC_PROFILES:
@@ -400,8 +404,8 @@ def profiled_traffic(stage, st):
         except OSError:
             continue
         pat = pats.get(stage, "\0")
-        if stage == "bm25_rank" and not name.startswith("r06"):
-            pat = "sort_rows_kernel<1024, 28, 2, false, 1>"
+        if stage == "bm25_rank" and st.get("bm25_lexical"):
+            pat = "sort_rows_kernel<1024, 28, 2, false, 3>"      # (the zero-compacting instantiation)
         for k, v in t.items():
             if k != "_note" and pat in k:
                 return v.get("hbm_bytes_corrected"), f"profiles/{name}"
@@ -1303,6 +1307,7 @@ def main():
                                    f"{'CamemBERT-base-shaped fp32 query encoder (random init; ' + st.get('encode_mode', '') + ' forward' + ('' if args.no_gemm_tuning or st.get('encode_mode') != 'packed' else ', hipBLASLt solutions recorded with TunableOp') + ') + ' if not args.no_encode else 'NO encoder + '}"
                                    "fp32-MFMA cos-sim + BM25(f64) + full stable ranking + RRF(f64) + final order",
                        "queries_per_gpu": Q, "corpus": N, "dim": d, "fusion": "rrf", "systems": ["bm25", "dpr"],
+                       "bm25_rows_zero_share_estimate": round(st["bm25_zero_share_estimate"], 4), "bm25_rank_sort": "lexical (zero-compacting)" if st["bm25_lexical"] else "plain",
                        "encode_in_step": not args.no_encode, "parallelism": f"query-sharded x{world}, corpus replicated",
                        "input": "query strings (tokenised on the host inside the timed step)" if host else "token ids resident on the device",
                        "tokenize_in_step": host is not None, "tokenize_overlapped_with_device": bool(host and host["overlapped"]),

@@ -38,6 +38,22 @@ from .. import ops
 from ..planes import RankedSystem
 
 
+LEXICAL_MIN_ZERO_SHARE = 0.3   # expected share of exact zeros per row from which the ranking sort's zero-compacting instantiation is asked for
+
+
+def expected_zero_share(df: np.ndarray, n_docs: int, query_terms: list[list[int]]) -> float:
+    """Mean over the queries of prod over a query's DISTINCT in-vocabulary terms of (1 - df_t / N): the share of documents expected to hold
+    none of its terms (terms taken as independent) -- i.e. to score exactly 0.0.  Host arithmetic on the index's df table, no device work."""
+    if not query_terms or n_docs <= 0:
+        return 0.0
+    miss = 1.0 - df.astype(np.float64) / float(n_docs)
+    tot = 0.0
+    for terms in query_terms:
+        t = np.unique(np.asarray([x for x in terms if x >= 0], dtype=np.int64))
+        tot += float(np.prod(miss[t])) if t.size else 1.0
+    return tot / len(query_terms)
+
+
 class TFIDF:
     """bm25.py:33-127: score(q, d) = sum over q.split(), in order, of tf(t, d) * idf(t), idf = log10((N + 1) / (df + 1))."""
 
@@ -72,6 +88,7 @@ class TFIDF:
         # where every term's postings cross the document slices one workgroup scores: per index, like the idf table
         self.slice_off = ops.bm25_slice_offsets(self.toff, self.pdoc, self.corpus_size) if self.device.type == "cuda" and V > 0 else None
         self._qcache = None
+        self.zero_share_estimate = 0.0   # of the last list of queries (set by _query_csr)
 
     def __repr__(self):
         return f"{self.__class__.__name__}".lower()                       # bm25.py:45-46: names the pickles of save_indexes
@@ -93,6 +110,7 @@ class TFIDF:
         flat = np.array([t for x in qt for t in x] or [0], dtype=np.int32)
         qoff_d, flat_d = torch.from_numpy(qoff).to(self.device), torch.from_numpy(flat).to(self.device)
         self._qcache = (queries, qoff_d, flat_d)
+        self.zero_share_estimate = expected_zero_share(self.df_host, self.corpus_size, qt)
         return qoff_d, flat_d
 
     def scores(self, queries: list[str], want_f32: bool = False):
@@ -107,8 +125,10 @@ class TFIDF:
         stats4 = None   # mean | std | min | max of every list's float32 scores: by-products of the ranking sort (rows that fit one workgroup)
         if N <= ops.sort_max_n(torch.float64) and Q > 0:
             stats4 = torch.empty((4, Q), dtype=torch.float32, device=self.device)
-        # ranks from the float64 scores, ties -> ascending index; lexical: most of a row is exact zeros, which the sort leaves out of its passes
-        order, _, rank = ops.sort_rows_desc(sc64, want_keys=False, want_rank=True, stats_out=stats4, lexical=True)
+        # ranks from the float64 scores, ties -> ascending index.  lexical: when the batch's rows are expected to be mostly exact zeros (documents
+        # that share no term with the query) the sort's zero-compacting instantiation orders only the non-zero keys -- a host-side ESTIMATE picks
+        # the instantiation (it costs rows without zeros 1-7 %), the kernel decides row by row from the actual count; same outputs either way
+        order, _, rank = ops.sort_rows_desc(sc64, want_keys=False, want_rank=True, stats_out=stats4, lexical=self.zero_share_estimate >= LEXICAL_MIN_ZERO_SHARE)
         lens = torch.full((Q,), N, dtype=torch.int32, device=self.device)
         # float32 plane for the normalisations (torch.tensor(scores, dtype=float32), hybrid.py:255), written by the scoring kernel from
         # the accumulators it holds (no conversion pass); the float64 scores stay for the 'none' passthrough, which keeps BM25's Python
@@ -222,7 +242,7 @@ class BM25(TFIDF):
         got = torch.empty((len(combos), Q, G), dtype=torch.int32, device=self.device)
         for w, (k1, b) in enumerate(combos):
             self.update_params(k1, b)
-            _, _, rank = ops.sort_rows_desc(self.scores(queries), want_keys=False, want_rank=True, lexical=True)
+            _, _, rank = ops.sort_rows_desc(self.scores(queries), want_keys=False, want_rank=True, lexical=self.zero_share_estimate >= LEXICAL_MIN_ZERO_SHARE)
             got[w] = torch.gather(rank, 1, gp_dev)
         self.update_params(*keep)
         ranks = got.cpu().numpy().astype(np.int64)

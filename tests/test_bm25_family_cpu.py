@@ -117,3 +117,12 @@ def test_preprocessing_without_spacy_is_an_error_not_a_no_op():
             bm25.preprocess(["Le chat dort."])
     else:
         assert bm25.preprocess(["Le chat dort 3 fois."])[0].islower()
+
+
+def test_expected_zero_share_picks_the_ranking_sort():
+    """The host-side estimate behind `lexical=`: per query prod over its DISTINCT known terms of (1 - df / N), averaged."""
+    from fusion_amd.retrievers.bm25 import LEXICAL_MIN_ZERO_SHARE, expected_zero_share
+    df = np.array([5, 0, 10, 1])
+    assert expected_zero_share(df, 10, [[0, 0, 1], [2], [-1], []]) == pytest.approx((0.5 + 0.0 + 1.0 + 1.0) / 4)
+    assert expected_zero_share(df, 10, []) == 0.0 and expected_zero_share(df, 0, [[0]]) == 0.0
+    assert expected_zero_share(np.array([998, 3]), 1000, [[0, 1]]) < LEXICAL_MIN_ZERO_SHARE < expected_zero_share(np.array([998, 3]), 1000, [[1, 1]])

@@ -192,3 +192,18 @@ def test_a_compacted_row_the_fast_form_cannot_finish_goes_to_the_generic_launch(
     j = rng.choice(n, size=3000, replace=False)
     K[1, j] = 3.0 + rng.permutation(3000) * np.finfo(np.float64).eps * 2
     check(ops, oracle, K, stats=True, expect=(3, 0))
+
+
+def test_queries_with_frequent_terms_keep_the_plain_sort(ops):
+    """A vocabulary that keeps its stop-word-like terms (the bench step's synthetic index): nearly every document shares a term with every
+    query, BM25.search_device expects no zeros and asks for the plain instantiation -- nothing goes through the compacting one."""
+    from fusion_amd.retrievers.bm25 import BM25, LEXICAL_MIN_ZERO_SHARE
+    rng = np.random.default_rng(37)
+    vocab = np.array([f"w{i}" for i in range(3000)])
+    p = 1.0 / np.arange(1, 3001) ** 1.05; p /= p.sum()
+    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(60, 200)), p=p)) for _ in range(9000)]
+    queries = [" ".join(rng.choice(vocab, size=8, p=p)) for _ in range(6)]
+    m = BM25(docs, 2.5, 0.2)
+    ops.sort_zero_compact_rows(reset=True)
+    m.search_device(queries)
+    assert m.zero_share_estimate < LEXICAL_MIN_ZERO_SHARE and ops.sort_zero_compact_rows(reset=True) == (0, 0)
