@@ -139,14 +139,48 @@ class TFIDF:
 
     def ranked_positions(self, queries: list[str], top_k: int, budget_bytes: int = 48 << 30) -> np.ndarray:
         """[Q, min(top_k, N)] corpus positions of the first top_k entries of every ranked list (what the driver keeps of search_all,
-        bm25.py:248-249), the queries taken in chunks whose planes (float64 + float32 scores, order, rank: 20 B per pair) fit the budget:
-        an mMARCO-sized corpus (8.8 M passages) takes ~270 queries at a time."""
+        bm25.py:248-249), the queries taken in chunks whose planes fit the budget.  A corpus that fits one workgroup's row (28,672 documents)
+        is ranked in full (search_device); a longer one -- mMARCO's 8.8 M passages -- is CUT, not ranked: every 28,672-document stretch of the
+        float64 score row is sorted on its own, its first top_k entries survive, and the survivors (kept in corpus order, so that the stable
+        sort breaks ties by ascending index as the full sort does) go round again until one row holds them -- the same first top_k entries as
+        the full ranking, without its cross-chunk ranking of all N documents."""
         N, k = self.corpus_size, min(top_k, self.corpus_size)
-        step = max(1, int(budget_bytes // max(1, 20 * ops.round_up(max(N, 1), 64))))
+        W = ops.sort_max_n(torch.float64)
+        per_pair = 20 if N <= W else 12 + 24 * min(1.0, (k + 1) / W)      # planes alive per (query, document)
+        step = max(1, int(budget_bytes // max(1, int(per_pair * ops.round_up(max(N, 1), 64)))))
         out = np.empty((len(queries), k), dtype=np.int64)
         for lo in range(0, len(queries), step):
             chunk = queries[lo:lo + step]
-            out[lo:lo + len(chunk)] = self.search_device(chunk).order[:, :k].cpu().numpy()
+            if N <= W:
+                out[lo:lo + len(chunk)] = self.search_device(chunk).order[:, :k].cpu().numpy()
+                continue
+            sc = self.scores(chunk)                                        # [q, N] float64
+            q = sc.shape[0]
+            ids = None                                                     # [q, n] corpus positions of the surviving columns (None: the identity)
+            while True:
+                n = sc.shape[1]
+                C = -(-n // W)
+                if C > 1:                                                  # pad to whole stretches: -inf never survives a real score, NaN sorts first as everywhere
+                    pad = C * W - n
+                    if pad:
+                        sc = torch.cat([sc, torch.full((q, pad), float("-inf"), dtype=sc.dtype, device=sc.device)], 1)
+                        if ids is not None:
+                            ids = torch.cat([ids, torch.full((q, pad), -1, dtype=torch.int64, device=sc.device)], 1)
+                    rows = sc.reshape(q * C, W)
+                else:
+                    rows = sc
+                order, keys, _ = ops.sort_rows_desc(ops.as_plane(rows.contiguous()), want_keys=True)
+                kk = min(k, rows.shape[1])
+                order, keys = order[:, :kk].long(), keys[:, :kk]
+                if C > 1:
+                    base = (torch.arange(C, device=sc.device) * W).repeat(q)[:, None]
+                    cols = (order + base).reshape(q, C * kk)               # columns of this level's row, stretch by stretch: corpus order is kept
+                    ids = cols if ids is None else torch.gather(ids, 1, cols)
+                    sc = keys.reshape(q, C * kk)
+                    continue
+                pos = order if ids is None else torch.gather(ids, 1, order)
+                out[lo:lo + q] = pos[:, :k].cpu().numpy()
+                break
         return out
 
     def search_all(self, queries: list[str], top_k: int) -> list:

@@ -75,12 +75,13 @@ class Ranker:
     @staticmethod
     def bm25_search(queries: list[str], corpus: dict[int, str], do_preprocessing: bool, k1: float, b: float, return_topk: int = None,
                     *, as_device: bool = False):
-        """hybrid.py:49-75. `do_preprocessing=True` needs the spaCy lemmatiser (src/data/preprocessor.py), a third-party
-        NLP model outside the hot path: pass pre-tokenised whitespace text instead."""
-        from .bm25 import BM25
-        if do_preprocessing:
-            raise NotImplementedError("spaCy preprocessing (fr_core_news_md) is out of scope: pass lemmatised text, do_preprocessing=False")
+        """hybrid.py:49-75. `do_preprocessing=True` runs the reference's TextPreprocessor recipe (src/data/preprocessor.py: spaCy
+        fr_core_news_md -- punctuation, numbers and stop words dropped, lemmas, lower case) when that third-party model is installed and
+        raises RuntimeError when it is not (offline: pass lemmatised whitespace text with do_preprocessing=False); never a silent no-op."""
+        from .bm25 import BM25, preprocess
         documents = list(corpus.values())
+        if do_preprocessing:
+            documents, queries = preprocess(documents), preprocess(queries)
         ids = np.array(list(corpus.keys()))
         retriever = BM25(corpus=documents, k1=k1, b=b, device=_device())
         rs = retriever.search_device(queries, ids=ids)

@@ -168,3 +168,22 @@ def test_posting_value_table_gives_the_same_bits(oracle):
         b64, b32 = m.scores(queries, want_f32=True)
         assert torch.equal(a64.view(torch.int64), b64.view(torch.int64)) and torch.equal(a32.view(torch.int32), b32.view(torch.int32))
         np.testing.assert_array_equal(a64.cpu().numpy(), oracle.BM25(docs, k1, b).scores(queries))
+
+
+def test_top_k_of_a_corpus_beyond_one_sort_row_is_cut_not_ranked(oracle):
+    """90,011 documents (four 28,672-document stretches, the last one short), top-1000 and top-7: the hierarchical cut == the first entries of
+    the oracle's full stable ranking, ties (rounded scores, many zeros) by ascending index across stretch borders; queries in budgeted chunks."""
+    from fusion_amd.retrievers.bm25 import BM25
+    rng = np.random.default_rng(43)
+    vocab = np.array([f"w{i}" for i in range(600)])
+    p = 1.0 / np.arange(3, 603); p /= p.sum()
+    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(1, 6)), p=p)) for _ in range(90_011)]      # short documents: few distinct scores, long tie runs
+    queries = [" ".join(rng.choice(vocab, size=int(rng.integers(1, 4)), p=p)) for _ in range(5)] + ["zzz"]  # (the last one: every score 0.0)
+    m = BM25(docs, 1.2, 0.0)
+    om = oracle.BM25(docs, 1.2, 0.0)
+    exp = om.search_all(queries, top_k=1000)
+    got = m.ranked_positions(queries, top_k=1000, budget_bytes=2 * 36 * 90_048)        # two queries at a time
+    assert got.shape == (6, 1000)
+    for q in range(6):
+        assert got[q].tolist() == [x["corpus_id"] for x in exp[q]], q
+    assert m.ranked_positions(queries, top_k=7)[3].tolist() == [x["corpus_id"] for x in exp[3][:7]]
