@@ -20,6 +20,8 @@ NO_SPILL = {
     "sort_rows_kernel<1024, 28, 2, false, 1>": "bm25_rank: float64 keys, whole rows (SORT_ROWS)",
     "sort_rows_kernel<1024, 28, 2, false, 2>": "final_order: rank fusion formed on load (SORT_FUSE)",
     "sort_rows_kernel<1024, 16, 2, false, 1>": "float64 rows of 8k-16k keys",
+    "sort_rows_kernel<1024, 28, 2, false, 3>": "a lexical ranker's float64 rows: zero compaction (SORT_ROWS_ZC)",
+    "sort_rows_kernel<1024, 16, 2, false, 3>": "the same, 8k-16k documents",
     "sort_rows_kernel<1024, 16, 2, false, 2>": "fused final order, 8k-16k documents",
     "sort_rows_kernel<1024, 16, 1, false, 0>": "float32 rows of 8k-16k keys",
     "fuse_nsf_bigtab_kernel<true, 1, 1>": "NCE at the reference's table sizes",
