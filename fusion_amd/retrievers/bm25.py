@@ -43,15 +43,23 @@ LEXICAL_MIN_ZERO_SHARE = 0.3   # expected share of exact zeros per row from whic
 
 def expected_zero_share(df: np.ndarray, n_docs: int, query_terms: list[list[int]]) -> float:
     """Mean over the queries of prod over a query's DISTINCT in-vocabulary terms of (1 - df_t / N): the share of documents expected to hold
-    none of its terms (terms taken as independent) -- i.e. to score exactly 0.0.  Host arithmetic on the index's df table, no device work."""
-    if not query_terms or n_docs <= 0:
+    none of its terms (terms taken as independent) -- i.e. to score exactly 0.0.  Host arithmetic on the index's df table (one np.unique over
+    the batch's (query, term) pairs), no device work."""
+    Q = len(query_terms)
+    if Q == 0 or n_docs <= 0:
         return 0.0
+    lens = np.fromiter((len(t) for t in query_terms), dtype=np.int64, count=Q)
+    flat = np.fromiter((x for t in query_terms for x in t), dtype=np.int64, count=int(lens.sum()))
+    qid = np.repeat(np.arange(Q, dtype=np.int64), lens)
+    keep = flat >= 0
+    V = max(int(df.shape[0]), 1)
+    pairs = np.unique(qid[keep] * V + flat[keep])                     # distinct (query, term) pairs
     miss = 1.0 - df.astype(np.float64) / float(n_docs)
-    tot = 0.0
-    for terms in query_terms:
-        t = np.unique(np.asarray([x for x in terms if x >= 0], dtype=np.int64))
-        tot += float(np.prod(miss[t])) if t.size else 1.0
-    return tot / len(query_terms)
+    with np.errstate(divide="ignore"):
+        logs = np.log(miss[pairs % V])                                # (-inf for a term every document holds: that query expects no zeros)
+    per_query = np.exp(np.bincount(pairs // V, weights=logs, minlength=Q)) if pairs.size else np.ones(Q)
+    per_query = np.nan_to_num(per_query, nan=0.0)
+    return float(per_query.mean())
 
 
 class TFIDF:
@@ -102,14 +110,14 @@ class TFIDF:
 
     # -- queries -> CSR of term ids (kept for the last list of queries: the grid search scores the same queries 187 times) --
     def _query_csr(self, queries: list[str]):
-        if self._qcache is not None and self._qcache[0] is queries:
+        if self._qcache is not None and (self._qcache[0] is queries or self._qcache[0] == queries):
             return self._qcache[1], self._qcache[2]
         qt = [[self.vocab.get(w, -1) for w in q.split()] for q in queries]   # query terms are NOT de-duplicated (bm25.py:112,152)
         qoff = np.zeros(len(qt) + 1, dtype=np.int64)
         np.cumsum([len(x) for x in qt], out=qoff[1:])
         flat = np.array([t for x in qt for t in x] or [0], dtype=np.int32)
         qoff_d, flat_d = torch.from_numpy(qoff).to(self.device), torch.from_numpy(flat).to(self.device)
-        self._qcache = (queries, qoff_d, flat_d)
+        self._qcache = (list(queries), qoff_d, flat_d)   # (a copy: a caller that edits its list in place gets a fresh CSR)
         self.zero_share_estimate = expected_zero_share(self.df_host, self.corpus_size, qt)
         return qoff_d, flat_d
 
