@@ -125,6 +125,13 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). fusion_amd has no CPU or PyTorch fallback for the scoring/fusion path.")
+        # torch FIRST: PyTorch-ROCm ships its own libamdhip64, and a process must hold ONE HIP runtime -- loaded before torch, this library
+        # binds the system's copy, torch then brings its own, and every device pointer torch hands over is foreign to the runtime the kernels
+        # launch through (hipErrorNoDevice on the first launch: seen with build() and smoke() in one process)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             f = getattr(L, name)  # AttributeError if the library does not export what the header declares
